@@ -1,0 +1,370 @@
+"""CPU oracle for the per-image INR fit hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, in plain CPU PyTorch (fp32), the algorithm of the reference
+hot path (jp-schneider/awesome @ 2024_08_07) so that the HIP path can be checked
+against it.  It is pinned against golden vectors produced by the real reference
+classes (tests/golden/*.npz, generator: tools/gen_golden.py) by
+tests/test_oracle_golden.py.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module - and only as the checker / the timed CPU baseline.  The product
+(awesome_amd/) never imports it and has no CPU fallback.
+
+Every function cites the reference lines it follows (paths relative to the
+reference checkout).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+# --------------------------------------------------------------------------------------
+# a1  coordinate grids
+# --------------------------------------------------------------------------------------
+
+
+def positional_grid(w: int, h: int, t: Optional[float] = None, t_max: Optional[float] = None) -> Tensor:
+    """awesome/dataset/transformator.py:25-61 - (2|3, h, w) grid, channels (x, y[, t/t_max]), linspace(0,1)."""
+    y = torch.linspace(0, 1, h)
+    x = torch.linspace(0, 1, w)
+    yy, xx = torch.meshgrid(y, x, indexing="ij")
+    if t is None:
+        return torch.stack((xx, yy), dim=0).float()
+    if t_max is None:
+        raise ValueError("t_max must be set if t is set")
+    return torch.stack((xx, yy, torch.ones_like(xx) * t / t_max), dim=0).float()
+
+
+def howto_grid(h: int, w: int) -> Tensor:
+    """notebooks/how_to/convexity.ipynb cell 7 `create_grid` - (1,2,h,w), x = i/w, y = j/h."""
+    x = torch.arange(0, w)
+    y = torch.arange(0, h)
+    xx, yy = torch.meshgrid(x, y, indexing="xy")
+    grid = torch.stack((xx, yy), dim=0)
+    return grid.unsqueeze(0).float() / torch.tensor([w, h]).float().unsqueeze(-1).unsqueeze(-1)
+
+
+def pixelize(x: Tensor) -> Tensor:
+    """awesome/util/pixelize.py:31-33 - (B,C,H,W) -> (B*H*W, C)."""
+    v = x.permute(0, 2, 3, 1)
+    return v.reshape(-1, v.shape[-1])
+
+
+def unpixelize(x: Tensor, b: int, h: int, w: int) -> Tensor:
+    """awesome/util/pixelize.py:35-37."""
+    return x.reshape(b, h, w, -1).permute(0, 3, 1, 2)
+
+
+# --------------------------------------------------------------------------------------
+# a3/a4/a5  ICNN family.  Parameters are kept in a dict with ConvexNextNet key names
+# (awesome/model/convex_net.py:177-220): input.{weight,bias}, skip.k.ln.{weight,bias},
+# skip.k.skp.weight, out.ln.{weight,bias}, out.skp.weight.
+# --------------------------------------------------------------------------------------
+
+CONVEXNET_KEYMAP = {  # ConvexNet (convex_net.py:10-40) == ConvexNextNet(L=1) under this renaming
+    "W0y.weight": "input.weight", "W0y.bias": "input.bias",
+    "W1z.weight": "skip.0.ln.weight", "W1z.bias": "skip.0.ln.bias", "W1y.weight": "skip.0.skp.weight",
+    "W2z.weight": "out.ln.weight", "W2z.bias": "out.ln.bias", "W2y.weight": "out.skp.weight",
+}
+
+
+def icnn_keys(n_hidden_layers: int) -> List[str]:
+    keys = ["input.weight", "input.bias"]
+    for k in range(n_hidden_layers):
+        keys += [f"skip.{k}.ln.weight", f"skip.{k}.ln.bias", f"skip.{k}.skp.weight"]
+    keys += ["out.ln.weight", "out.ln.bias", "out.skp.weight"]
+    return keys
+
+
+def icnn_num_layers(p: Dict[str, Tensor]) -> int:
+    return sum(1 for k in p if k.startswith("skip.") and k.endswith(".ln.weight"))
+
+
+def icnn_forward(p: Dict[str, Tensor], x: Tensor) -> Tensor:
+    """ConvexNextNet.forward (convex_net.py:205-214) on (N,C) rows -> (N,1) logits."""
+    x_in = x
+    z = F.relu(F.linear(x_in, p["input.weight"], p["input.bias"]))
+    for k in range(icnn_num_layers(p)):
+        z = F.relu(F.linear(z, p[f"skip.{k}.ln.weight"], p[f"skip.{k}.ln.bias"]) + F.linear(x_in, p[f"skip.{k}.skp.weight"]))
+    return F.linear(z, p["out.ln.weight"], p["out.ln.bias"]) + F.linear(x_in, p["out.skp.weight"])
+
+
+def icnn_forward_image(p: Dict[str, Tensor], grid: Tensor) -> Tensor:
+    """@pixelize wrapper: (B,C,H,W) -> (B,1,H,W)."""
+    b, c, h, w = grid.shape
+    return unpixelize(icnn_forward(p, pixelize(grid)), b, h, w)
+
+
+def icnn_clamp_keys(p: Dict[str, Tensor]) -> List[str]:
+    """Keys projected onto >= 0 by enforce_convexity (convex_net.py:151-154, 216-220; ConvexNet :37-40):
+    hidden->hidden and hidden->out `ln.weight`; the skip weights stay free."""
+    return [f"skip.{k}.ln.weight" for k in range(icnn_num_layers(p))] + ["out.ln.weight"]
+
+
+def icnn_enforce_convexity(p: Dict[str, Tensor]) -> None:
+    with torch.no_grad():
+        for k in icnn_clamp_keys(p):
+            p[k].copy_(F.relu(p[k]))
+
+
+# --------------------------------------------------------------------------------------
+# a11  data terms
+# --------------------------------------------------------------------------------------
+
+
+def unaries_weight(target: Tensor, mode: str, ratio: float = 1.0) -> Tensor:
+    """UnariesWeightedLoss._compute_weight (awesome/measures/unaries_weighted_loss.py:35-69).
+    Weight applied to elements with target < 0.5 (foreground); others get 1."""
+    if mode == "none":
+        return torch.ones_like(target)
+    fg = (target < 0.5).sum()
+    bg = (target >= 0.5).sum()
+    cc = bg.float() / fg.float()
+    if mode == "ratio":
+        wv = (cc - 1) * ratio + 1
+    elif mode == "sssdms":
+        wv = torch.round(cc / 10) + 1
+    elif mode == "equal":
+        wv = cc
+    else:
+        raise ValueError(f"Mode {mode} is not supported")
+    w = torch.ones_like(target)
+    w[target < 0.5] = wv
+    return w
+
+
+def weighted_loss(output: Tensor, target: Tensor, kind: str = "se", mode: str = "none", ratio: float = 1.0) -> Tensor:
+    """WeightedLoss.__call__ (awesome/measures/weighted_loss.py:67-92) with criterion SE
+    (awesome/measures/se.py:21-23) or nn.BCELoss, reduction 'mean' over all elements."""
+    if kind == "se":
+        l = (target - output) ** 2
+    elif kind == "bce":
+        l = F.binary_cross_entropy(output, target, reduction="none")
+    else:
+        raise ValueError(kind)
+    if mode != "none":
+        l = l * unaries_weight(target, mode, ratio)
+    return l.mean()
+
+
+def awesome_image_loss(output: Tensor, target: Tensor, alpha=1.0, beta=100.0, gamma=0.1, extra_penalty=False) -> Tensor:
+    """AwesomeImageLoss.__call__ with default BCE criteria (awesome/measures/awesome_image_loss.py:34-53)."""
+    c = output.shape[1] // 2
+    seg, prior = output[:, :c], output[:, c:]
+    loss = F.binary_cross_entropy(seg, target) + alpha * F.binary_cross_entropy(prior, target)
+    if extra_penalty:
+        loss = gamma * loss + beta * torch.mean((prior - (seg > 0.5).float()) ** 2)
+    return loss
+
+
+# --------------------------------------------------------------------------------------
+# a17  metric
+# --------------------------------------------------------------------------------------
+
+
+def miou_binary(output: Tensor, target: Tensor, invert: bool = True) -> float:
+    """MIOU.__call__ (awesome/measures/miou.py:29-48), average='binary': Jaccard of the positive class
+    after the optional 1-x inversion; 0 when the (inverted) target has no positives."""
+    o = output.detach().reshape(-1).float()
+    t = target.detach().reshape(-1).float()
+    if invert:
+        o, t = 1.0 - o, 1.0 - t
+    if bool(torch.all(t == 0.0)):
+        return 0.0
+    ob, tb = o == 1.0, t == 1.0
+    inter = int((ob & tb).sum())
+    union = int((ob | tb).sum())
+    return float(inter) / float(union) if union > 0 else 0.0
+
+
+# --------------------------------------------------------------------------------------
+# a14  optimizers (single-tensor restatement of torch.optim.Adam / Adamax defaults, as used at
+# awesome/run/awesome_config.py:34-41, path_connected_net.py:924-933, convexity how-to cell 7)
+# --------------------------------------------------------------------------------------
+
+
+class AdamState:
+    def __init__(self, params: Dict[str, Tensor]):
+        self.step = 0
+        self.m = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in params.items()}
+
+
+def adam_step(p: Dict[str, Tensor], g: Dict[str, Tensor], st: AdamState, lr: float, betas=(0.9, 0.999), eps=1e-8,
+              weight_decay: float = 0.0) -> None:
+    b1, b2 = betas
+    st.step += 1
+    bc1 = 1 - b1 ** st.step
+    bc2 = 1 - b2 ** st.step
+    step_size = lr / bc1
+    bc2_sqrt = math.sqrt(bc2)
+    with torch.no_grad():
+        for k in p:
+            grad = g[k]
+            if weight_decay != 0:
+                grad = grad + weight_decay * p[k]
+            st.m[k].lerp_(grad, 1 - b1)
+            st.v[k].mul_(b2).addcmul_(grad, grad, value=1 - b2)
+            denom = (st.v[k].sqrt() / bc2_sqrt).add_(eps)
+            p[k].addcdiv_(st.m[k], denom, value=-step_size)
+
+
+def adamax_step(p: Dict[str, Tensor], g: Dict[str, Tensor], st: AdamState, lr: float, betas=(0.9, 0.999), eps=1e-8,
+                weight_decay: float = 0.0) -> None:
+    """torch.optim.Adamax: exp_inf = max(b2*exp_inf, |g|+eps); p -= lr/(1-b1^t) * m/exp_inf (st.v holds exp_inf)."""
+    b1, b2 = betas
+    st.step += 1
+    clr = lr / (1 - b1 ** st.step)
+    with torch.no_grad():
+        for k in p:
+            grad = g[k]
+            if weight_decay != 0:
+                grad = grad + weight_decay * p[k]
+            st.m[k].lerp_(grad, 1 - b1)
+            norm_buf = torch.cat([st.v[k].mul_(b2).unsqueeze(0), grad.abs().add_(eps).unsqueeze(0)], 0)
+            st.v[k].copy_(torch.amax(norm_buf, 0, keepdim=False))
+            p[k].addcdiv_(st.m[k], st.v[k], value=-clr)
+
+
+class PlateauState:
+    """torch.optim.lr_scheduler.ReduceLROnPlateau(mode='min', threshold=1e-4 rel, cooldown=0, min_lr=0, eps=1e-8)
+    as used at path_connected_net.py:932-933, 951."""
+
+    def __init__(self, lr: float, patience: int = 200, factor: float = 0.5, threshold: float = 1e-4, min_lr: float = 0.0,
+                 eps: float = 1e-8):
+        self.lr, self.patience, self.factor, self.threshold, self.min_lr, self.eps = lr, patience, factor, threshold, min_lr, eps
+        self.best = math.inf
+        self.num_bad = 0
+
+    def step(self, metric: float) -> float:
+        if metric < self.best * (1.0 - self.threshold):
+            self.best = metric
+            self.num_bad = 0
+        else:
+            self.num_bad += 1
+        if self.num_bad > self.patience:
+            new_lr = max(self.lr * self.factor, self.min_lr)
+            if self.lr - new_lr > self.eps:
+                self.lr = new_lr
+            self.num_bad = 0
+        return self.lr
+
+
+# --------------------------------------------------------------------------------------
+# a13  the hot loop
+# --------------------------------------------------------------------------------------
+
+
+def fit_icnn(p0: Dict[str, Tensor], grid: Tensor, unaries: Tensor, steps: int, lr: float = 2e-3, loss_kind: str = "se",
+             weight_mode: str = "none", ratio: float = 1.0, optimizer: str = "adam", betas=(0.9, 0.999), eps: float = 1e-8,
+             weight_decay: float = 0.0, plateau: Optional[dict] = None, record_every: int = 0
+             ) -> Tuple[Dict[str, Tensor], List[float], Tensor]:
+    """E x {zero_grad, forward, loss, backward, Adam/Adamax step, clamp[, plateau step]} on one image.
+    Follows _prior_based_pretrain's inner loop (awesome/model/path_connected_net.py:937-962) and the how-to loop
+    (notebooks/how_to/convexity.ipynb cell 9, with plain mean instead of fg/bg re-weighting).
+    grid: (1,C,H,W); unaries: (1,1,H,W).  Returns (params, per-step losses, final logits (1,1,H,W))."""
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in p0.items()}
+    st = AdamState(p)
+    sched = PlateauState(lr, **plateau) if plateau is not None else None
+    losses: List[float] = []
+    cur_lr = lr
+    for _ in range(steps):
+        for v in p.values():
+            v.grad = None
+        out = torch.sigmoid(icnn_forward_image(p, grid))
+        loss = weighted_loss(out, unaries, loss_kind, weight_mode, ratio)
+        loss.backward()
+        g = {k: v.grad for k, v in p.items()}
+        if optimizer == "adam":
+            adam_step(p, g, st, cur_lr, betas, eps, weight_decay)
+        elif optimizer == "adamax":
+            adamax_step(p, g, st, cur_lr, betas, eps, weight_decay)
+        else:
+            raise ValueError(optimizer)
+        icnn_enforce_convexity(p)
+        lv = float(loss.item())
+        losses.append(lv)
+        if sched is not None:
+            cur_lr = sched.step(lv)
+    with torch.no_grad():
+        logits = icnn_forward_image(p, grid)
+    return {k: v.detach() for k, v in p.items()}, losses, logits
+
+
+def loss_and_grads(p0: Dict[str, Tensor], grid: Tensor, unaries: Tensor, loss_kind="se", weight_mode="none", ratio=1.0):
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in p0.items()}
+    out = torch.sigmoid(icnn_forward_image(p, grid))
+    loss = weighted_loss(out, unaries, loss_kind, weight_mode, ratio)
+    loss.backward()
+    return float(loss.item()), {k: v.grad.detach() for k, v in p.items()}
+
+
+# --------------------------------------------------------------------------------------
+# a6-a9  weight-normalised coupling flow (path-connected prior, in-tree variant)
+# --------------------------------------------------------------------------------------
+
+
+def wn_weight(v: Tensor, g: Tensor) -> Tensor:
+    """nn.utils.weight_norm(dim=None): w = g * v / ||v||_F with scalar g (real_nvp/resnet_1d.py:48)."""
+    return v * (g / torch.linalg.norm(v))
+
+
+def wn_linear(sd: Dict[str, Tensor], prefix: str, x: Tensor) -> Tensor:
+    """WNLinear.forward (awesome/model/real_nvp/resnet_1d.py:39-63)."""
+    w = wn_weight(sd[prefix + "linear.weight_v"], sd[prefix + "linear.weight_g"])
+    return F.linear(x, w, sd.get(prefix + "linear.bias"))
+
+
+def normal_block(sd: Dict[str, Tensor], prefix: str, x: Tensor) -> Tensor:
+    """NormalBlock.forward (awesome/model/diffeomorphism_net.py:169-192): tanh(WN2(leaky_relu(WN1 x)))."""
+    h = F.leaky_relu(wn_linear(sd, prefix + "in_linear.", x))
+    return torch.tanh(wn_linear(sd, prefix + "out_linear.", h))
+
+
+def wn_scale(sd: Dict[str, Tensor], prefix: str) -> Tensor:
+    """WNScale.forward (diffeomorphism_net.py:208-232): weight-normed 1x1 linear (default dim=0) of a learnable scalar."""
+    v, g = sd[prefix + "scale.weight_v"], sd[prefix + "scale.weight_g"]
+    w = v * (g / torch.linalg.norm(v, dim=1, keepdim=True))
+    return F.linear(sd[prefix + "weight"], w, sd[prefix + "scale.bias"])
+
+
+def flow1d_forward(sd: Dict[str, Tensor], x: Tensor, num_coupling: int, prefix: str = "") -> Tensor:
+    """NormalizingFlow1D.forward with normal_block backbones (diffeomorphism_net.py:286-300)."""
+    x1, x2 = x[:, :1], x[:, 1:]
+    for i in range(num_coupling):
+        if i % 2 == 0:
+            s = wn_scale(sd, f"{prefix}scale.{i}.") * normal_block(sd, f"{prefix}s.{i}.", x1)
+            x2 = torch.exp(s) * x2 + normal_block(sd, f"{prefix}t.{i}.", x1)
+        else:
+            s = wn_scale(sd, f"{prefix}scale.{i}.") * normal_block(sd, f"{prefix}s.{i}.", x2)
+            x1 = torch.exp(s) * x1 + normal_block(sd, f"{prefix}t.{i}.", x2)
+    return torch.cat([x1, x2], 1)
+
+
+def convex_diffeo_forward(sd: Dict[str, Tensor], x: Tensor, num_coupling: int) -> Tensor:
+    """ConvexDiffeomorphismNet.forward (awesome/model/convex_diffeomorphism_net.py:173-178): ICNN(flow(Ax+b))."""
+    x = F.linear(x, sd["linear.weight"], sd["linear.bias"])
+    xd = flow1d_forward(sd, x, num_coupling, prefix="diffeo_net.")
+    p = {k[len("convex_net."):]: v for k, v in sd.items() if k.startswith("convex_net.")}
+    return icnn_forward(p, xd)
+
+
+# --------------------------------------------------------------------------------------
+# helpers for tests
+# --------------------------------------------------------------------------------------
+
+
+def load_npz_state(npz, prefix: str) -> Dict[str, Tensor]:
+    return {k[len(prefix):]: torch.from_numpy(np.asarray(npz[k])).clone() for k in npz.files if k.startswith(prefix)}
+
+
+def to_convexnext_keys(sd: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    if "W0y.weight" in sd:
+        return {CONVEXNET_KEYMAP[k]: v for k, v in sd.items()}
+    return dict(sd)

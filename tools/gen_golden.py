@@ -1,0 +1,321 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REAL reference classes (CPU, this container only).
+
+This script imports the hot-path classes of jp-schneider/awesome from
+/root/reference (read-only) and records inputs + outputs as small .npz fixtures
+under tests/golden/.  It never runs on the GPU box (the reference does not
+travel); only the fixtures do.  Nothing in the product imports this file.
+
+Import recipe: `awesome/model/__init__.py` eagerly pulls in
+modules that need `toml`, so an empty `awesome.model` package object is
+registered first; the classes used here then import with no stubs.
+
+Usage:  python tools/gen_golden.py [--out tests/golden]
+"""
+import argparse
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+
+
+def _import_reference():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference checkout not present; fixtures can only be generated in the build container")
+    sys.path.insert(0, REF)
+    for sub in ("model", "dataset"):  # skip the eager package __init__ files (they need toml/cv2)
+        pkg = types.ModuleType(f"awesome.{sub}")
+        pkg.__path__ = [os.path.join(REF, "awesome", sub)]
+        sys.modules[f"awesome.{sub}"] = pkg
+    import awesome.model.convex_net as convex_net
+    import awesome.model.diffeomorphism_net as diffeo
+    import awesome.model.real_nvp.resnet_1d as resnet_1d
+    import awesome.measures.se as se
+    import awesome.measures.unaries_weighted_loss as uwl
+    import awesome.measures.miou as miou
+    import awesome.measures.awesome_image_loss as ail
+    import awesome.dataset.transformator as transformator
+    import awesome.transforms.min_max as min_max
+    return types.SimpleNamespace(convex_net=convex_net, diffeo=diffeo, resnet_1d=resnet_1d, se=se, uwl=uwl,
+                                 miou=miou, ail=ail, transformator=transformator, min_max=min_max)
+
+
+def seed_all(seed: int) -> None:
+    # same calls as awesome/run/runner.py:19-25 (CPU part)
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def sd_np(module, prefix="sd."):
+    return {prefix + k: v.detach().cpu().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def grads_np(module, prefix="grad."):
+    return {prefix + k: p.grad.detach().cpu().numpy().copy() for k, p in module.named_parameters()}
+
+
+def disc_unaries(h, w, cy, cx, r):
+    yy, xx = np.mgrid[0:h, 0:w]
+    disc = ((yy - cy) ** 2 + (xx - cx) ** 2) <= r * r
+    return (1.0 - disc.astype(np.float32))  # fg = 0, bg = 1
+
+
+def blob_unaries(h, w, seed):
+    """Smooth random blob with soft (non-binary) unaries in (0,1)."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    cy, cx = rng.uniform(0.35, 0.65, 2) * np.array([h, w])
+    ry, rx = rng.uniform(0.15, 0.3, 2) * np.array([h, w])
+    d = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2
+    u = 1.0 / (1.0 + np.exp(-(d - 1.0) * 4.0))
+    return u.astype(np.float32)
+
+
+def gen_icnn(ref, out):
+    """a3/a4/a5/a11/a14: forward, loss, grads, Adam(+clamp) for the ICNN family."""
+    T = ref.transformator.Transformator
+    cases = [
+        ("convexnet_h130_c2", lambda: ref.convex_net.ConvexNet(n_hidden=130, in_channels=2), 2, 16, 16),
+        ("convexnext_h130_c2_l1", lambda: ref.convex_net.ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=1), 2, 16, 24),
+        ("convexnext_h130_c2_l2", lambda: ref.convex_net.ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=2), 2, 16, 16),
+        ("convexnext_h130_c3_l1", lambda: ref.convex_net.ConvexNextNet(n_hidden=130, in_features=3, n_hidden_layers=1), 3, 16, 16),
+        ("convexnext_h32_c2_l1", lambda: ref.convex_net.ConvexNextNet(n_hidden=32, in_features=2, n_hidden_layers=1), 2, 20, 12),
+        ("convexnext_h64_c3_l2", lambda: ref.convex_net.ConvexNextNet(n_hidden=64, in_features=3, n_hidden_layers=2), 3, 8, 8),
+    ]
+    for ci, (name, ctor, C, H, W) in enumerate(cases):
+        seed_all(100 + ci)
+        model = ctor()
+        if C == 2:
+            grid = T.get_positional_matrices(W, H)
+        else:
+            grid = T.get_positional_matrices(W, H, t=3.0, t_max=7.0)
+        grid = grid[None]  # (1,C,H,W)
+        unaries = torch.from_numpy(blob_unaries(H, W, 7 + ci))[None, None]
+        rec = {"grid": grid.numpy(), "unaries": unaries.numpy()}
+        rec.update(sd_np(model, "sd0."))
+        # forward
+        with torch.no_grad():
+            rec["logits"] = model(grid).numpy()
+        # SE(sigmoid) mean loss + grads (the loss of _prior_based_pretrain, path_connected_net.py:943-951)
+        crit = ref.uwl.UnariesWeightedLoss(ref.se.SE("mean"))
+        model.zero_grad()
+        loss = crit(torch.sigmoid(model(grid)), unaries)
+        loss.backward()
+        rec["se.loss"] = np.float32(loss.item())
+        rec.update(grads_np(model, "se.grad."))
+        # BCE(sigmoid) mean loss + grads
+        model.zero_grad()
+        loss = torch.nn.BCELoss()(torch.sigmoid(model(grid)), unaries)
+        loss.backward()
+        rec["bce.loss"] = np.float32(loss.item())
+        rec.update(grads_np(model, "bce.grad."))
+        # SE + sssdms re-weighting on binary unaries
+        ub = (unaries >= 0.5).float()
+        crit = ref.uwl.UnariesWeightedLoss(ref.se.SE("mean"), mode="sssdms")
+        model.zero_grad()
+        loss = crit(torch.sigmoid(model(grid)), ub)
+        loss.backward()
+        rec["sssdms.loss"] = np.float32(loss.item())
+        rec.update(grads_np(model, "sssdms.grad."))
+        # Adam + clamp trajectory (SE mean), snapshots after 1 and 10 steps
+        opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+        crit = ref.uwl.UnariesWeightedLoss(ref.se.SE("mean"))
+        losses = []
+        for step in range(10):
+            opt.zero_grad()
+            loss = crit(torch.sigmoid(model(grid)), unaries)
+            loss.backward()
+            opt.step()
+            model.enforce_convexity()
+            losses.append(loss.item())
+            if step == 0:
+                rec.update(sd_np(model, "adam1."))
+        rec.update(sd_np(model, "adam10."))
+        rec["adam.losses"] = np.asarray(losses, dtype=np.float32)
+        np.savez_compressed(os.path.join(out, f"icnn_{name}.npz"), **rec)
+        print("wrote", name, "loss", losses[0], "->", losses[-1])
+
+
+def gen_adamax(ref, out):
+    """a13/a14: Adamax + ReduceLROnPlateau + clamp as in _prior_based_pretrain (path_connected_net.py:924-951)."""
+    T = ref.transformator.Transformator
+    seed_all(7)
+    model = ref.convex_net.ConvexNextNet(n_hidden=32, in_features=2, n_hidden_layers=1)
+    grid = T.get_positional_matrices(16, 16)[None]
+    unaries = torch.from_numpy(disc_unaries(16, 16, 8, 7, 4.5))[None, None]
+    rec = {"grid": grid.numpy(), "unaries": unaries.numpy()}
+    rec.update(sd_np(model, "sd0."))
+    opt = torch.optim.Adamax(model.parameters(), lr=1e-2, weight_decay=1e-5)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, patience=5, factor=0.5)
+    crit = ref.uwl.UnariesWeightedLoss(ref.se.SE("mean"))
+    losses, lrs = [], []
+    for step in range(60):
+        opt.zero_grad()
+        loss = crit(torch.sigmoid(model(grid)), unaries)
+        loss.backward()
+        opt.step()
+        model.enforce_convexity()
+        sched.step(loss)
+        losses.append(loss.item())
+        lrs.append(opt.param_groups[0]["lr"])
+    rec.update(sd_np(model, "final."))
+    rec["losses"] = np.asarray(losses, dtype=np.float32)
+    rec["lrs"] = np.asarray(lrs, dtype=np.float64)
+    np.savez_compressed(os.path.join(out, "adamax_plateau_h32.npz"), **rec)
+    print("wrote adamax", losses[0], losses[-1], lrs[-1])
+
+
+def gen_losses(ref, out):
+    """a11/a12: UnariesWeightedLoss modes, AwesomeImageLoss."""
+    seed_all(11)
+    outp = torch.rand(2, 1, 12, 10)
+    tgt = (torch.rand(2, 1, 12, 10) > 0.8).float() * 0.9 + 0.05  # soft unaries, fg (<0.5) majority
+    rec = {"output": outp.numpy(), "target": tgt.numpy()}
+    for mode in ["none", "equal", "ratio", "sssdms"]:
+        for cname, crit in [("se", ref.se.SE("mean")), ("bce", torch.nn.BCELoss())]:
+            kw = dict(mode=mode)
+            if mode == "ratio":
+                kw["ratio"] = 0.35
+            l = ref.uwl.UnariesWeightedLoss(crit, **kw)
+            rec[f"uwl.{cname}.{mode}"] = np.float32(l(outp, tgt).item())
+    # AwesomeImageLoss (awesome_image_loss.py:34-53)
+    out2 = torch.rand(2, 2, 12, 10)
+    rec["output2"] = out2.numpy()
+    tb = (tgt >= 0.5).float()
+    rec["target_bin"] = tb.numpy()
+    l = ref.ail.AwesomeImageLoss(alpha=0.7, beta=100., gamma=0.1, forward_kwargs_criterion=False)
+    rec["ail.plain"] = np.float32(l(out2, tb).item())
+    l.extra_penalty = True
+    rec["ail.penalty"] = np.float32(l(out2, tb).item())
+    np.savez_compressed(os.path.join(out, "losses.npz"), **rec)
+    print("wrote losses")
+
+
+def gen_miou(ref, out):
+    """a17: MIOU(invert=True, average='binary') (miou.py:29-48)."""
+    seed_all(13)
+    m = ref.miou.MIOU(average="binary", invert=True)
+    rec = {}
+    cases = []
+    for i in range(6):
+        o = (torch.rand(9, 11) > 0.5).float()
+        t = (torch.rand(9, 11) > (0.3 + 0.1 * i)).float()
+        cases.append((o, t))
+    cases.append((torch.zeros(5, 5), torch.ones(5, 5)))   # target has no fg after inversion -> 0
+    cases.append((torch.ones(5, 5), torch.zeros(5, 5)))   # pred no fg, target all fg
+    cases.append((torch.zeros(5, 5), torch.zeros(5, 5)))  # perfect, all fg
+    for i, (o, t) in enumerate(cases):
+        rec[f"o{i}"] = o.numpy()
+        rec[f"t{i}"] = t.numpy()
+        rec[f"iou{i}"] = np.float32(m(o, t).item())
+    rec["n"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(out, "miou.npz"), **rec)
+    print("wrote miou")
+
+
+def gen_grid(ref, out):
+    """a1: Transformator.get_positional_matrices (transformator.py:25-61)."""
+    T = ref.transformator.Transformator
+    rec = {}
+    rec["g_7x5"] = T.get_positional_matrices(7, 5).numpy()
+    rec["g_64x64"] = T.get_positional_matrices(64, 64).numpy()
+    rec["g_256x256_row0"] = T.get_positional_matrices(256, 256).numpy()[0, 0]
+    rec["g_6x4_t"] = T.get_positional_matrices(6, 4, t=3.0, t_max=15.0).numpy()
+    np.savez_compressed(os.path.join(out, "grid.npz"), **rec)
+    print("wrote grid")
+
+
+def gen_fit_disc(ref, out):
+    """End-to-end pin: 64x64 disc, ConvexNextNet(L=1), Adam lr 2e-3, 600 steps."""
+    T = ref.transformator.Transformator
+    seed_all(0)
+    model = ref.convex_net.ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=1)
+    grid = T.get_positional_matrices(64, 64)[None]
+    unaries = torch.from_numpy(disc_unaries(64, 64, 32, 32, 15))[None, None]
+    rec = {"unaries": unaries.numpy()}
+    rec.update(sd_np(model, "sd0."))
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    crit = ref.uwl.UnariesWeightedLoss(ref.se.SE("mean"))
+    losses = []
+    for step in range(600):
+        opt.zero_grad()
+        outp = torch.sigmoid(model(grid))
+        loss = crit(outp, unaries)
+        loss.backward()
+        opt.step()
+        model.enforce_convexity()
+        losses.append(loss.item())
+    with torch.no_grad():
+        logits = model(grid)
+        outp = torch.sigmoid(logits)
+    miou = ref.miou.MIOU(average="binary", invert=True)
+    rec["losses"] = np.asarray(losses, dtype=np.float32)
+    rec["final_logits"] = logits.numpy().astype(np.float32)
+    rec["final_mask"] = (outp > 0.5).numpy()
+    rec["final_miou"] = np.float32(miou((outp > 0.5).float(), (unaries > 0.5).float()).item())
+    rec.update(sd_np(model, "final."))
+    np.savez_compressed(os.path.join(out, "fit_disc64.npz"), **rec)
+    print("wrote fit_disc64: loss", losses[0], "->", losses[-1], "miou", rec["final_miou"])
+
+
+def gen_flow(ref, out):
+    """a6-a9: WNLinear, NormalBlock, WNScale, NormalizingFlow1D forward/grad (diffeomorphism_net.py)."""
+    seed_all(21)
+    x = torch.rand(40, 2) * 2 - 0.5
+    rec = {"x": x.numpy()}
+    wn = ref.resnet_1d.WNLinear(3, 5)
+    wn.reset_parameters("relu")
+    x3 = torch.rand(17, 3)
+    rec["wn.x"] = x3.numpy()
+    rec.update(sd_np(wn, "wn.sd."))
+    rec["wn.y"] = wn(x3).detach().numpy()
+    nb = ref.diffeo.NormalBlock(in_channels=1, mid_channels=24, out_channels=1)
+    nb.reset_parameters()
+    x1 = torch.rand(17, 1) * 2 - 1
+    rec["nb.x"] = x1.numpy()
+    rec.update(sd_np(nb, "nb.sd."))
+    rec["nb.y"] = nb(x1).detach().numpy()
+    sc = ref.diffeo.WNScale(dim=1)
+    rec.update(sd_np(sc, "sc.sd."))
+    rec["sc.y"] = sc().detach().numpy()
+    for tag, kw in [("nf6_w130", dict(num_coupling=6, width=130, backbone="normal_block")),
+                    ("nf4_w16", dict(num_coupling=4, width=16, backbone="normal_block"))]:
+        nf = ref.diffeo.NormalizingFlow1D(in_features=2, **kw)
+        nf.reset_parameters()
+        rec.update(sd_np(nf, f"{tag}.sd."))
+        y = nf(x)
+        rec[f"{tag}.y"] = y.detach().numpy()
+        (y ** 2).mean().backward()
+        rec.update(grads_np(nf, f"{tag}.grad."))
+    np.savez_compressed(os.path.join(out, "flow.npz"), **rec)
+    print("wrote flow")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden"))
+    args = ap.parse_args()
+    out = os.path.abspath(args.out)
+    os.makedirs(out, exist_ok=True)
+    torch.set_num_threads(4)
+    ref = _import_reference()
+    gen_grid(ref, out)
+    gen_miou(ref, out)
+    gen_losses(ref, out)
+    gen_icnn(ref, out)
+    gen_adamax(ref, out)
+    gen_flow(ref, out)
+    gen_fit_disc(ref, out)
+    with open(os.path.join(out, "PROVENANCE.txt"), "w") as f:
+        f.write("Generated by tools/gen_golden.py from jp-schneider/awesome @ 2024_08_07 (reference classes imported on CPU),\n")
+        f.write(f"torch {torch.__version__}, numpy {np.__version__}.\n")
+
+
+if __name__ == "__main__":
+    main()
