@@ -1,0 +1,99 @@
+"""ctypes binding of libinrfit.so (include/inrfit.h).  There is NO CPU fallback: if the HIP library is missing or a
+call fails, an exception is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libinrfit.so")
+
+# enums (include/inrfit.h)
+INR_MODEL_ICNN = 1
+INR_GRID_SEPARABLE, INR_GRID_EXPLICIT = 0, 1
+INR_LOSS_SE, INR_LOSS_BCE = 0, 1
+INR_WEIGHT_NONE, INR_WEIGHT_EQUAL, INR_WEIGHT_RATIO, INR_WEIGHT_SSSDMS, INR_WEIGHT_EXPLICIT = 0, 1, 2, 3, 4
+INR_OPT_ADAM, INR_OPT_ADAMAX = 0, 1
+INR_OPT_HEADER_FLOATS = 8
+INRFIT_ABI_VERSION = 1
+
+LOSS_KINDS = {"se": INR_LOSS_SE, "bce": INR_LOSS_BCE}
+WEIGHT_MODES = {"none": INR_WEIGHT_NONE, "equal": INR_WEIGHT_EQUAL, "ratio": INR_WEIGHT_RATIO, "sssdms": INR_WEIGHT_SSSDMS,
+                "explicit": INR_WEIGHT_EXPLICIT}
+OPT_KINDS = {"adam": INR_OPT_ADAM, "adamax": INR_OPT_ADAMAX}
+
+
+class InrModelDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n_hidden", C.c_int32), ("in_features", C.c_int32), ("n_layers", C.c_int32)]
+
+
+class InrGridDesc(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("n_points", C.c_int64),
+                ("xs", C.c_void_p), ("ys", C.c_void_p), ("ts", C.c_void_p), ("coords", C.c_void_p),
+                ("coords_image_stride", C.c_int64)]
+
+
+class InrLossDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("weight_mode", C.c_int32), ("ratio", C.c_float), ("c_fg", C.c_float),
+                ("c_bg", C.c_float)]
+
+
+class InrOptDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("clamp", C.c_int32), ("plateau", C.c_int32), ("plateau_patience", C.c_int32),
+                ("plateau_factor", C.c_float), ("plateau_threshold", C.c_float), ("plateau_min_lr", C.c_float),
+                ("plateau_eps", C.c_float)]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "inrfit_query": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "inrfit_supported": (C.c_int, [C.POINTER(InrModelDesc)]),
+    "inrfit_param_count": (C.c_int64, [C.POINTER(InrModelDesc)]),
+    "inrfit_opt_state_floats": (C.c_int64, [C.POINTER(InrModelDesc)]),
+    "inrfit_workspace_bytes": (C.c_int64, [C.POINTER(InrModelDesc), C.POINTER(InrGridDesc), C.c_int]),
+    "inrfit_forward": (C.c_int, [C.POINTER(InrModelDesc), C.c_void_p, C.POINTER(InrGridDesc), C.c_int, C.c_void_p,
+                                 C.c_void_p]),
+    "inrfit_loss_grad": (C.c_int, [C.POINTER(InrModelDesc), C.c_void_p, C.POINTER(InrGridDesc), C.c_void_p,
+                                   C.POINTER(InrLossDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                   C.c_void_p]),
+    "inrfit_fit": (C.c_int, [C.POINTER(InrModelDesc), C.c_void_p, C.c_void_p, C.POINTER(InrGridDesc), C.c_void_p,
+                             C.POINTER(InrLossDesc), C.POINTER(InrOptDesc), C.c_int, C.c_int, C.c_int, C.c_void_p,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_miou": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_void_p,
+                              C.c_void_p]),
+    "inrfit_strerror": (C.c_char_p, [C.c_int]),
+}
+
+_lib = None
+
+
+class InrfitError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libinrfit.so; raises if it has not been built (python -m awesome_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise InrfitError(f"{LIB_PATH} not found: build the HIP extension first (python -m awesome_amd.build). "
+                          "awesome_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    ver = C.c_int(0)
+    lib.inrfit_query(C.byref(ver), None, None)
+    if ver.value != INRFIT_ABI_VERSION:
+        raise InrfitError(f"libinrfit ABI {ver.value} != expected {INRFIT_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().inrfit_strerror(rc)
+        raise InrfitError(f"{what} failed: {msg.decode() if msg else rc} ({rc})")

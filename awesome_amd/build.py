@@ -1,0 +1,41 @@
+"""Build libinrfit.so (hipcc, gfx950) in-tree.  `python -m awesome_amd.build`."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "inrfit.hip")
+OUT = os.path.join(HERE, "csrc", "libinrfit.so")
+INCLUDE = os.path.join(ROOT, "include")
+
+
+def hipcc_path() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    deps = [SRC, os.path.join(INCLUDE, "inrfit.h")]
+    return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile the HIP C-ABI library for gfx950.  Cross-compiles without a GPU."""
+    if not force and not needs_build():
+        return OUT
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", f"-I{INCLUDE}", SRC, "-o", OUT]
+    if verbose:
+        print("[awesome_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

@@ -1,0 +1,153 @@
+/*
+ * inrfit.h - C ABI of libinrfit.so: the MI355X (gfx950) implementation of the per-image INR fit hot path of
+ * jp-schneider/awesome (dense-grid input-convex coordinate MLP: forward, loss, backward, Adam/Adamax, convexity clamp).
+ *
+ * The reference has no FFI: its hot path is Python/PyTorch.  Each entry point below states the reference
+ * code it replaces (paths relative to the reference checkout).  The binding a maintainer would add on the reference side
+ * is a ctypes stub; this repo's own host side is awesome_amd/_lib.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch tensors' data_ptr()), unless marked "host";
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous w.r.t. the host;
+ *   - return value: 0 on success, negative INR_E* for argument/launch errors (synchronous);
+ *     per-image numerical failures (NaN/Inf loss) are reported in the `status` device array of inrfit_fit;
+ *   - no global mutable state: thread-safe for distinct streams; one process per GPU;
+ *   - all arithmetic is fp32 (the reference's AwesomeConfig.dtype default, awesome/run/awesome_config.py:193).
+ *
+ * Flat parameter vector of the ICNN (ConvexNet == ConvexNextNet(L=1), awesome/model/convex_net.py:10-40,177-220),
+ * h = n_hidden, C = in_features, L = n_layers; row-major like the torch state_dict tensors:
+ *     input.weight [h][C] | input.bias [h] |
+ *     for k in 0..L-1: skip.k.ln.weight [h][h] | skip.k.ln.bias [h] | skip.k.skp.weight [h][C] |
+ *     out.ln.weight [h] | out.ln.bias [1] | out.skp.weight [C]
+ *   P = h*C + h + L*(h*h + h + h*C) + h + 1 + C            (17813 for h=130, C=2, L=1)
+ */
+#ifndef INRFIT_H
+#define INRFIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INRFIT_ABI_VERSION 1
+
+enum {
+    INR_OK = 0,
+    INR_EINVAL = -1,      /* bad argument (null pointer, non-positive size, unknown enum) */
+    INR_EUNSUPPORTED = -2,/* model shape not built into this library (see inrfit_query / inrfit_supported) */
+    INR_EWORKSPACE = -3,  /* workspace too small */
+    INR_ELAUNCH = -4,     /* HIP launch failure (hipGetLastError) */
+    INR_ENODEVICE = -5    /* no gfx950 device / wrong architecture */
+};
+
+enum { INR_MODEL_ICNN = 1 };
+enum { INR_GRID_SEPARABLE = 0, INR_GRID_EXPLICIT = 1 };
+enum { INR_LOSS_SE = 0, INR_LOSS_BCE = 1 };
+enum { INR_WEIGHT_NONE = 0, INR_WEIGHT_EQUAL = 1, INR_WEIGHT_RATIO = 2, INR_WEIGHT_SSSDMS = 3, INR_WEIGHT_EXPLICIT = 4 };
+enum { INR_OPT_ADAM = 0, INR_OPT_ADAMAX = 1 };
+enum { INR_STATUS_OK = 0, INR_STATUS_NONFINITE = 1 };
+
+/* awesome/model/convex_net.py:177-203 constructor arguments (n_hidden, in_features, n_hidden_layers). */
+typedef struct InrModelDesc {
+    int32_t kind;        /* INR_MODEL_ICNN */
+    int32_t n_hidden;    /* h */
+    int32_t in_features; /* C: 2 (x,y) or 3 (x,y,t) */
+    int32_t n_layers;    /* L hidden skip layers (ConvexNet: 1) */
+} InrModelDesc;
+
+/* The dense coordinate grid every image is evaluated on.
+ * SEPARABLE: point p = row*width + col has coords (xs[col], ys[row][, ts[image]]) - the layout produced by
+ *            Transformator.get_positional_matrices (awesome/dataset/transformator.py:25-61) and the how-to grid
+ *            (notebooks/how_to/convexity.ipynb cell 7); xs/ys are tiny 1-D arrays so their values are exactly the
+ *            caller's (torch.linspace / arange/n), nothing is re-derived in the kernel.
+ * EXPLICIT:  coords is channel-planar [C][n_points] per image (the (B,C,H,W) tensor the reference feeds through
+ *            @pixelize, awesome/util/pixelize.py:31-33); image i starts at coords + i*coords_image_stride
+ *            (stride 0 = one grid shared by all images). */
+typedef struct InrGridDesc {
+    int32_t mode;
+    int32_t width, height;
+    int64_t n_points; /* width*height for SEPARABLE */
+    const float* xs;  /* [width]  */
+    const float* ys;  /* [height] */
+    const float* ts;  /* [n_images] or NULL (C == 2) */
+    const float* coords;
+    int64_t coords_image_stride; /* in floats */
+} InrGridDesc;
+
+/* Data term on sigmoid(logit) vs. unaries: SE (awesome/measures/se.py:21-23) or BCE (torch.nn.BCELoss), 'mean'
+ * reduction, optionally re-weighted per class as UnariesWeightedLoss._compute_weight does
+ * (awesome/measures/unaries_weighted_loss.py:35-69; weight applies to target < 0.5).
+ * EXPLICIT: per-element coefficient is c_fg (target < 0.5) or c_bg, normalisation included - expresses the how-to
+ * loop's (1-w)*mean_bg + w*mean_fg (notebooks/how_to/convexity.ipynb cell 9). */
+typedef struct InrLossDesc {
+    int32_t kind;
+    int32_t weight_mode;
+    float ratio;
+    float c_fg, c_bg;
+} InrLossDesc;
+
+/* torch.optim.Adam / Adamax defaults (awesome/run/awesome_config.py:34-41; path_connected_net.py:924-929),
+ * enforce_convexity after every step (convex_net.py:216-220; hook awesome/run/awesome_runner.py:294-297),
+ * ReduceLROnPlateau(mode='min', rel threshold) stepped with the loss every step (path_connected_net.py:932-933,951). */
+typedef struct InrOptDesc {
+    int32_t kind;
+    float lr, beta1, beta2, eps, weight_decay;
+    int32_t clamp;
+    int32_t plateau;
+    int32_t plateau_patience;
+    float plateau_factor, plateau_threshold, plateau_min_lr, plateau_eps;
+} InrOptDesc;
+
+/* Per-image optimizer state, `opt_state` = n_images * inrfit_opt_state_floats(model) floats:
+ *   exp_avg [P] | exp_avg_sq or exp_inf [P] | header [INR_OPT_HEADER_FLOATS]
+ * header: [0] lr (current), [1] plateau best, [2] plateau num_bad (as float), [3] last loss, rest reserved.
+ * Zero-initialise for a cold fit (header lr is taken from InrOptDesc when step0 == 0). */
+#define INR_OPT_HEADER_FLOATS 8
+
+/* Capabilities. max_hidden: largest n_hidden any built kernel supports; lds_bytes: LDS used by the h=130 kernel. */
+int inrfit_query(int* abi_version, int* max_hidden, int* lds_bytes);
+/* 1 if (h, C, L) has a compiled kernel, else 0. */
+int inrfit_supported(const InrModelDesc* model);
+int64_t inrfit_param_count(const InrModelDesc* model);
+int64_t inrfit_opt_state_floats(const InrModelDesc* model);
+/* Scratch the step kernels need (per-workgroup gradient slabs, per-image loss coefficients). */
+int64_t inrfit_workspace_bytes(const InrModelDesc* model, const InrGridDesc* grid, int n_images);
+
+/* logits[n_images][n_points] = f_theta(grid).  Replaces ConvexNet/ConvexNextNet.forward
+ * (awesome/model/convex_net.py:26-35, 205-214) incl. the @pixelize reshapes, for n_images parameter sets at once
+ * (the PriorCache axis, awesome/util/prior_cache.py:49-59). */
+int inrfit_forward(const InrModelDesc* model, const float* params, const InrGridDesc* grid, int n_images,
+                   float* logits, void* stream);
+
+/* loss_out[n_images], grads[n_images][P] (same flat order as params) of the data term at `params`.
+ * Replaces one forward + criterion + loss.backward() of the hot loop (awesome/model/path_connected_net.py:941-948;
+ * awesome/agent/torch_agent.py:470-491) - used by the autograd.Function bridge so the stock training loop still works. */
+int inrfit_loss_grad(const InrModelDesc* model, const float* params, const InrGridDesc* grid, const float* targets,
+                     const InrLossDesc* loss, int n_images, float* loss_out, float* grads, void* workspace,
+                     int64_t workspace_bytes, void* stream);
+
+/* `steps` full-batch optimisation steps of n_images independent fits, entirely on device:
+ *   E x { forward, loss, backward, Adam/Adamax step, clamp, plateau.step(loss) }
+ * Replaces the inner loops of _prior_based_pretrain (awesome/model/path_connected_net.py:937-962), the how-to loop
+ * (notebooks/how_to/convexity.ipynb cell 9) and learn_convex_net (path_connected_net.py:364-379).
+ * params/opt_state are updated in place; step0 = number of optimizer steps already taken (bias correction);
+ * loss_hist (optional) [n_images][steps]: loss at the parameters BEFORE each step, as the reference logs it;
+ * final_logits (optional) [n_images][n_points]: logits at the final parameters; status [n_images] int32. */
+int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const InrGridDesc* grid, const float* targets,
+               const InrLossDesc* loss, const InrOptDesc* opt, int n_images, int steps, int step0, float* loss_hist,
+               float* final_logits, int32_t* status, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* iou[n_images]: binary Jaccard of the class selected by `invert` between (out > thr_out) and (tgt > thr_tgt);
+ * 0 if the target has no member of that class.  Replaces MIOU(invert=True, average='binary')
+ * (awesome/measures/miou.py:29-48) and the IoU gate of the fit loop (path_connected_net.py:964-972). */
+int inrfit_miou(const float* out, const float* tgt, int n_images, int64_t n_points, float thr_out, float thr_tgt, int invert,
+                float* iou, void* stream);
+
+const char* inrfit_strerror(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INRFIT_H */

@@ -1,0 +1,215 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the reference's golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import inr_oracle as O  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import awesome_amd
+    awesome_amd._lib.load()
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return awesome_amd
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _spec_from_sd(amd, p):
+    h, c = p["input.weight"].shape
+    return amd.IcnnSpec(n_hidden=h, in_features=c, n_layers=O.icnn_num_layers(p))
+
+
+L1_CASES = ["convexnet_h130_c2", "convexnext_h130_c2_l1", "convexnext_h130_c3_l1", "convexnext_h32_c2_l1"]
+
+
+@pytest.mark.parametrize("name", L1_CASES)
+def test_forward_matches_reference(amd, golden_dir, name):
+    z = _load(golden_dir, f"icnn_{name}.npz")
+    p = O.to_convexnext_keys(O.load_npz_state(z, "sd0."))
+    spec = _spec_from_sd(amd, p)
+    dev = torch.device("cuda:0")
+    grid_t = torch.from_numpy(z["grid"])  # (1,C,H,W)
+    flat = amd.pack_state_dict(spec, p, dev)[None]
+    logits = amd.forward(spec, flat, amd.Grid.from_image_grid(grid_t.to(dev)))
+    ref = z["logits"].reshape(1, -1)
+    # fp32 tolerance: |logit| ~ 1, K = 130 dot products in a different summation order
+    np.testing.assert_allclose(logits.cpu().numpy(), ref, rtol=0, atol=5e-6)
+    # separable grid description gives the same result as the explicit one
+    _, C, H, W = grid_t.shape
+    ts = None
+    if C == 3:
+        ts = grid_t[0, 2, 0, :1].to(dev)
+    g2 = amd.Grid.separable(grid_t[0, 0, 0, :].to(dev), grid_t[0, 1, :, 0].to(dev), ts)
+    logits2 = amd.forward(spec, flat, g2)
+    assert torch.equal(logits, logits2)
+
+
+@pytest.mark.parametrize("name", L1_CASES)
+@pytest.mark.parametrize("tag,kind,mode", [("se", "se", "none"), ("bce", "bce", "none"), ("sssdms", "se", "sssdms")])
+def test_loss_and_grads_match_reference(amd, golden_dir, name, tag, kind, mode):
+    z = _load(golden_dir, f"icnn_{name}.npz")
+    sd_raw = O.load_npz_state(z, "sd0.")
+    p = O.to_convexnext_keys(sd_raw)
+    spec = _spec_from_sd(amd, p)
+    dev = torch.device("cuda:0")
+    grid = amd.Grid.from_image_grid(torch.from_numpy(z["grid"]).to(dev))
+    un = torch.from_numpy(z["unaries"])
+    if mode == "sssdms":
+        un = (un >= 0.5).float()
+    flat = amd.pack_state_dict(spec, p, dev)[None]
+    loss, grads = amd.loss_grad(spec, flat, grid, un.reshape(1, -1).to(dev), loss=kind, weight_mode=mode)
+    assert float(loss[0]) == pytest.approx(float(z[f"{tag}.loss"]), rel=1e-5)
+    g = amd.unpack_params(spec, grads[0].cpu())
+    is_cn = "W0y.weight" in sd_raw
+    for k_raw in sd_raw:
+        k = O.CONVEXNET_KEYMAP[k_raw] if is_cn else k_raw
+        ref = z[f"{tag}.grad.{k_raw}"]
+        scale = max(1e-8, float(np.abs(ref).max()))
+        np.testing.assert_allclose(g[k].numpy(), ref, rtol=2e-4, atol=2e-6 * scale + 1e-9, err_msg=f"{tag} {k_raw}")
+
+
+@pytest.mark.parametrize("name", L1_CASES)
+def test_adam_clamp_trajectory(amd, golden_dir, name):
+    z = _load(golden_dir, f"icnn_{name}.npz")
+    sd_raw = O.load_npz_state(z, "sd0.")
+    is_cn = "W0y.weight" in sd_raw
+    p = O.to_convexnext_keys(sd_raw)
+    spec = _spec_from_sd(amd, p)
+    dev = torch.device("cuda:0")
+    grid = amd.Grid.from_image_grid(torch.from_numpy(z["grid"]).to(dev))
+    un = torch.from_numpy(z["unaries"]).reshape(1, -1).to(dev)
+    for steps, tag in [(1, "adam1."), (10, "adam10.")]:
+        flat = amd.pack_state_dict(spec, p, dev)[None].clone()
+        res = amd.fit(spec, flat, grid, un, steps, lr=2e-3)
+        assert int(res.status[0]) == 0
+        np.testing.assert_allclose(res.loss_hist[0].cpu().numpy(), z["adam.losses"][:steps], rtol=2e-5)
+        got = amd.unpack_params(spec, res.params[0].cpu())
+        for k_raw in sd_raw:
+            k = O.CONVEXNET_KEYMAP[k_raw] if is_cn else k_raw
+            np.testing.assert_allclose(got[k].numpy(), z[tag + k_raw], rtol=2e-4, atol=5e-6, err_msg=f"{tag}{k_raw}")
+        for k in spec.clamp_keys():
+            assert float(got[k].min()) >= 0.0
+
+
+def test_adamax_plateau_weight_decay(amd, golden_dir):
+    z = _load(golden_dir, "adamax_plateau_h32.npz")
+    p = O.load_npz_state(z, "sd0.")
+    spec = _spec_from_sd(amd, p)
+    dev = torch.device("cuda:0")
+    grid = amd.Grid.from_image_grid(torch.from_numpy(z["grid"]).to(dev))
+    un = torch.from_numpy(z["unaries"]).reshape(1, -1).to(dev)
+    n = len(z["losses"])
+    flat = amd.pack_state_dict(spec, p, dev)[None].clone()
+    res = amd.fit(spec, flat, grid, un, n, lr=1e-2, optimizer="adamax", weight_decay=1e-5,
+                  plateau=dict(patience=5, factor=0.5))
+    np.testing.assert_allclose(res.loss_hist[0].cpu().numpy(), z["losses"], rtol=5e-4)
+    hdr = res.opt_state[0, 2 * spec.n_params:].cpu().numpy()
+    assert hdr[2] == pytest.approx(float(z["lrs"][-1]), rel=1e-6)  # same LR schedule decisions as torch
+    got = amd.unpack_params(spec, res.params[0].cpu())
+    for k in p:
+        np.testing.assert_allclose(got[k].numpy(), z["final." + k], rtol=5e-3, atol=5e-5, err_msg=k)
+
+
+def test_fit_disc64_end_to_end(amd, golden_dir):
+    """600 steps on the 64x64 disc: loss curve, mask and mIoU of the reference run."""
+    z = _load(golden_dir, "fit_disc64.npz")
+    p = O.load_npz_state(z, "sd0.")
+    spec = _spec_from_sd(amd, p)
+    dev = torch.device("cuda:0")
+    grid = amd.Grid.linspace(64, 64, dev)
+    un = torch.from_numpy(z["unaries"]).reshape(1, -1).to(dev)
+    flat = amd.pack_state_dict(spec, p, dev)[None].clone()
+    res = amd.fit(spec, flat, grid, un, 600, lr=2e-3)
+    hist = res.loss_hist[0].cpu().numpy()
+    np.testing.assert_allclose(hist[:50], z["losses"][:50], rtol=2e-4)
+    assert hist[-1] == pytest.approx(float(z["losses"][-1]), rel=5e-2)
+    prob = torch.sigmoid(res.logits)
+    iou = amd.miou((prob > 0.5).float(), (un > 0.5).float(), invert=True)
+    assert abs(float(iou[0]) - float(z["final_miou"])) <= 1e-3  # north-star tolerance on mIoU
+    mask = (prob > 0.5).cpu().numpy().reshape(64, 64)
+    assert (mask != z["final_mask"].reshape(64, 64)).mean() < 2e-3
+
+
+def test_batched_ragged_and_explicit(amd):
+    """Several images at once, N not a multiple of the 64-point chunk, per-image explicit grids; vs the oracle."""
+    torch.manual_seed(5)
+    dev = torch.device("cuda:0")
+    spec = amd.IcnnSpec(n_hidden=64, in_features=3, n_layers=1)
+    n_img, H, W = 3, 7, 11  # N = 77
+    ps, flats, grids, uns = [], [], [], []
+    for i in range(n_img):
+        p = {k: (torch.rand(shp) - 0.4) * 0.5 for k, shp in spec.keys_shapes()}
+        ps.append(p)
+        flats.append(amd.pack_state_dict(spec, p))
+        grids.append(torch.rand(1, 3, H, W) * 2 - 0.5)  # negative coordinates too
+        uns.append(torch.rand(1, 1, H, W))
+    flat = torch.stack(flats).to(dev)
+    grid = amd.Grid.explicit(torch.cat(grids).reshape(n_img, 3, H * W).to(dev))
+    un = torch.cat(uns).reshape(n_img, -1).to(dev)
+    logits = amd.forward(spec, flat, grid).cpu()
+    loss, grads = amd.loss_grad(spec, flat, grid, un, loss="bce", weight_mode="equal")
+    for i in range(n_img):
+        ref = O.icnn_forward_image(ps[i], grids[i]).reshape(-1)
+        np.testing.assert_allclose(logits[i].numpy(), ref.numpy(), atol=5e-6, rtol=1e-5)
+        l_ref, g_ref = O.loss_and_grads(ps[i], grids[i], uns[i], "bce", "equal")
+        assert float(loss[i]) == pytest.approx(l_ref, rel=2e-5)
+        g = amd.unpack_params(spec, grads[i].cpu())
+        for k in g_ref:
+            scale = float(g_ref[k].abs().max())
+            np.testing.assert_allclose(g[k].numpy(), g_ref[k].numpy(), rtol=2e-4, atol=2e-6 * scale + 1e-9, err_msg=k)
+
+
+def test_miou_kernel(amd, golden_dir):
+    z = _load(golden_dir, "miou.npz")
+    dev = torch.device("cuda:0")
+    for i in range(int(z["n"])):
+        o, t = torch.from_numpy(z[f"o{i}"]).reshape(1, -1).to(dev), torch.from_numpy(z[f"t{i}"]).reshape(1, -1).to(dev)
+        got = float(amd.miou(o, t, invert=True)[0])
+        assert got == pytest.approx(float(z[f"iou{i}"]), abs=1e-7), i
+
+
+def test_large_grid_properties(amd):
+    """256x256 (BASELINE size): size-independent properties - determinism, batch independence, linearity of the
+    gradient in the loss coefficient, clamp invariant."""
+    dev = torch.device("cuda:0")
+    spec = amd.IcnnSpec(130, 2, 1)
+    torch.manual_seed(1)
+    p = {k: (torch.rand(shp) - 0.45) * 0.3 for k, shp in spec.keys_shapes()}
+    flat1 = amd.pack_state_dict(spec, p, dev)[None]
+    grid = amd.Grid.linspace(256, 256, dev)
+    yy, xx = torch.meshgrid(torch.arange(256), torch.arange(256), indexing="ij")
+    un = (((yy - 120) ** 2 + (xx - 140) ** 2) > 60 ** 2).float().reshape(1, -1).to(dev)
+    l1, g1 = amd.loss_grad(spec, flat1, grid, un)
+    l2, g2 = amd.loss_grad(spec, flat1, grid, un)
+    assert torch.equal(l1, l2) and torch.equal(g1, g2)  # bitwise reproducible (no atomics)
+    # the same image twice in a batch behaves like two independent single fits
+    lb, gb = amd.loss_grad(spec, flat1.repeat(2, 1), grid, un.repeat(2, 1))
+    np.testing.assert_allclose(gb[0].cpu().numpy(), gb[1].cpu().numpy(), rtol=0, atol=0)
+    np.testing.assert_allclose(gb[0].cpu().numpy(), g1[0].cpu().numpy(), rtol=1e-4, atol=1e-7)
+    # gradient is linear in the per-class coefficients
+    la, ga = amd.loss_grad(spec, flat1, grid, un, weight_mode="explicit", c_fg=1e-5, c_bg=2e-5)
+    lc, gc = amd.loss_grad(spec, flat1, grid, un, weight_mode="explicit", c_fg=3e-5, c_bg=6e-5)
+    np.testing.assert_allclose(gc.cpu().numpy(), 3 * ga.cpu().numpy(), rtol=1e-4, atol=1e-9)
+    # oracle agreement at full size for loss + gradient
+    l_ref, g_ref = O.loss_and_grads(p, O.positional_grid(256, 256)[None], un.cpu().reshape(1, 1, 256, 256))
+    assert float(l1[0]) == pytest.approx(l_ref, rel=2e-5)
+    g = amd.unpack_params(spec, g1[0].cpu())
+    for k in g_ref:
+        scale = float(g_ref[k].abs().max())
+        np.testing.assert_allclose(g[k].numpy(), g_ref[k].numpy(), rtol=5e-4, atol=5e-6 * scale + 1e-10, err_msg=k)
+    # 20 steps: clamp invariant + loss decreases
+    params = flat1.clone()
+    res = amd.fit(spec, params, grid, un, 20, lr=2e-3)
+    got = amd.unpack_params(spec, res.params[0].cpu())
+    for k in spec.clamp_keys():
+        assert float(got[k].min()) >= 0.0
+    h = res.loss_hist[0].cpu().numpy()
+    assert np.isfinite(h).all() and h[-1] < h[0]
