@@ -416,6 +416,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 const float d = tg - pr;
                 l = d * d * cw;
                 dy = 2.f * (pr - tg) * pr * (1.f - pr) * cw;
+            } else if (a.loss_kind == INR_LOSS_EXTERNAL) {
+                l = 0.f;
+                dy = tg;  // `targets` carries dL/dlogit
             } else {
                 const float lp = fmaxf(logf(pr), -100.f), lq = fmaxf(logf(1.f - pr), -100.f);
                 l = -(tg * lp + (1.f - tg) * lq) * cw;
@@ -908,7 +911,7 @@ static int launch_step(const KernelEntry* e, const Workspace& w, const float* pa
 
 static int check_loss(const InrLossDesc* l) {
     if (!l) return INR_EINVAL;
-    if (l->kind != INR_LOSS_SE && l->kind != INR_LOSS_BCE) return INR_EINVAL;
+    if (l->kind != INR_LOSS_SE && l->kind != INR_LOSS_BCE && l->kind != INR_LOSS_EXTERNAL) return INR_EINVAL;
     if (l->weight_mode < INR_WEIGHT_NONE || l->weight_mode > INR_WEIGHT_EXPLICIT) return INR_EINVAL;
     return INR_OK;
 }
@@ -939,6 +942,55 @@ int inrfit_loss_grad(const InrModelDesc* model, const float* params, const InrGr
     u.mode = 1;
     hipLaunchKernelGGL(icnn_update_kernel, dim3((e->P + 1 + UPD_PARAMS - 1) / UPD_PARAMS, n_images), dim3(UPD_PARAMS, UPD_GROUPS), 0, s, u);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
+}
+
+int inrfit_backward(const InrModelDesc* model, const float* params, const InrGridDesc* grid, const float* dlogits,
+                    int n_images, float* grads, void* workspace, int64_t workspace_bytes, void* stream) {
+    const KernelEntry* e = find_entry(model);
+    if (!e) return INR_EUNSUPPORTED;
+    if (!params || !dlogits || !grads || !workspace) return INR_EINVAL;
+    int rc = check_grid(grid, e, n_images);
+    if (rc) return rc;
+    const Workspace w = carve(e, grid->n_points, n_images, workspace);
+    if (workspace_bytes < w.bytes) return INR_EWORKSPACE;
+    if ((rc = set_lds(e))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    InrLossDesc ld{};
+    ld.kind = INR_LOSS_EXTERNAL;
+    ld.weight_mode = INR_WEIGHT_NONE;
+    hipLaunchKernelGGL(loss_coef_kernel, dim3(n_images), dim3(256), 0, s, dlogits, (long long)grid->n_points, ld, w.coef);
+    if ((rc = launch_step(e, w, params, grid, dlogits, &ld, n_images, nullptr, s))) return rc;
+    UpdArgs u{};
+    u.slabs = w.slabs;
+    u.grads_out = grads;
+    u.loss_out = w.coef;  // scratch: the loss slot is unused in this mode
+    u.P = e->P;
+    u.PS = w.PS;
+    u.wgs = w.wgs;
+    u.n_images = n_images;
+    u.mode = 1;
+    hipLaunchKernelGGL(icnn_update_kernel, dim3((e->P + 1 + UPD_PARAMS - 1) / UPD_PARAMS, n_images),
+                       dim3(UPD_PARAMS, UPD_GROUPS), 0, s, u);
+    return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
+}
+
+int inrfit_step_only(const InrModelDesc* model, const float* params, const InrGridDesc* grid, const float* targets,
+                     const InrLossDesc* loss, int n_images, int iters, void* workspace, int64_t workspace_bytes,
+                     void* stream) {
+    const KernelEntry* e = find_entry(model);
+    if (!e) return INR_EUNSUPPORTED;
+    if (!params || !targets || !workspace || iters < 0) return INR_EINVAL;
+    int rc = check_grid(grid, e, n_images);
+    if (rc) return rc;
+    if ((rc = check_loss(loss))) return rc;
+    const Workspace w = carve(e, grid->n_points, n_images, workspace);
+    if (workspace_bytes < w.bytes) return INR_EWORKSPACE;
+    if ((rc = set_lds(e))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(loss_coef_kernel, dim3(n_images), dim3(256), 0, s, targets, (long long)grid->n_points, *loss, w.coef);
+    for (int it = 0; it < iters; ++it)
+        if ((rc = launch_step(e, w, params, grid, targets, loss, n_images, nullptr, s))) return rc;
+    return INR_OK;
 }
 
 int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const InrGridDesc* grid, const float* targets,

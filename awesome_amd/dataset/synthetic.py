@@ -1,0 +1,58 @@
+"""Deterministic synthetic inputs for the BASELINE configs.  No files, no network.
+
+The reference's datasets (SISBOSI / FBMS-59, awesome/dataset/*) need data that is not on disk; the hot path only needs
+per-image unaries in [0,1] with the reference's convention fg = 0, bg = 1 (notebooks/how_to/convexity.ipynb cell 7,
+awesome/model/path_connected_net.py:832-836)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def _convex_hull(pts: np.ndarray) -> np.ndarray:
+    """Andrew monotone chain; returns hull vertices counter-clockwise."""
+    pts = pts[np.lexsort((pts[:, 1], pts[:, 0]))]
+
+    def cross(o, a, b):
+        return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])
+
+    lower, upper = [], []
+    for p in pts:
+        while len(lower) >= 2 and cross(lower[-2], lower[-1], p) <= 0:
+            lower.pop()
+        lower.append(p)
+    for p in pts[::-1]:
+        while len(upper) >= 2 and cross(upper[-2], upper[-1], p) <= 0:
+            upper.pop()
+        upper.append(p)
+    return np.asarray(lower[:-1] + upper[:-1])
+
+
+def convex_blob_mask(size: int = 256, seed: int = 0, n_vertices: int = 8) -> np.ndarray:
+    """C2 'convex blob': convex hull of K vertices at sorted random angles, radii U(40,90)/256*size around a centre
+    U(96,160)/256*size, rasterised by half-plane tests.  Returns a bool (size,size) mask (True = object)."""
+    rng = np.random.RandomState(seed)
+    s = size / 256.0
+    ang = np.sort(rng.uniform(0.0, 2.0 * np.pi, n_vertices))
+    rad = rng.uniform(40.0, 90.0, n_vertices) * s
+    cx, cy = rng.uniform(96.0, 160.0, 2) * s
+    pts = np.stack([cx + rad * np.cos(ang), cy + rad * np.sin(ang)], 1)
+    hull = _convex_hull(pts)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float64)
+    inside = np.ones((size, size), dtype=bool)
+    for i in range(len(hull)):
+        a, b = hull[i], hull[(i + 1) % len(hull)]
+        inside &= ((b[0] - a[0]) * (yy - a[1]) - (b[1] - a[1]) * (xx - a[0])) >= 0.0
+    return inside
+
+
+def convex_blob_unaries(size: int = 256, seed: int = 0) -> torch.Tensor:
+    """(size,size) float32 unaries, fg (object) = 0, bg = 1."""
+    return torch.from_numpy(1.0 - convex_blob_mask(size, seed).astype(np.float32))
+
+
+def disc_unaries(h: int, w: int, cy: float, cx: float, r: float) -> torch.Tensor:
+    """C1 disc: fg = 0 inside the disc, bg = 1."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    disc = ((yy - cy) ** 2 + (xx - cx) ** 2) <= r * r
+    return torch.from_numpy(1.0 - disc.astype(np.float32))

@@ -229,6 +229,40 @@ def loss_grad(spec: IcnnSpec, params: Tensor, grid: Grid, targets: Tensor, loss:
     return loss_out, grads
 
 
+def backward(spec: IcnnSpec, params: Tensor, grid: Grid, dlogits: Tensor) -> Tensor:
+    """Vector-Jacobian product: grads [n_images, P] = dlogits [n_images, N] . d logits / d params (forward recomputed)."""
+    _check_spec(spec)
+    params = _check_dev(params, "params")
+    dlogits = _check_dev(dlogits, "dlogits")
+    if params.dim() == 1:
+        params = params[None]
+    n_images = params.shape[0]
+    dlogits = dlogits.reshape(n_images, -1)
+    assert dlogits.shape[1] == grid.n_points
+    ws = _workspace(spec, grid, n_images)
+    grads = torch.empty_like(params)
+    md, gd = spec.desc(), grid.desc()
+    rc = L.load().inrfit_backward(C.byref(md), params.data_ptr(), C.byref(gd), dlogits.data_ptr(), n_images,
+                                  grads.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream_ptr(params.device))
+    L.check(rc, "inrfit_backward")
+    return grads
+
+
+def step_only(spec: IcnnSpec, params: Tensor, grid: Grid, targets: Tensor, iters: int, loss: str = "se",
+              weight_mode: str = "none", workspace: Optional[Tensor] = None) -> Tensor:
+    """Measurement hook: launch only the fused step kernel `iters` times on the current stream."""
+    _check_spec(spec)
+    params = _check_dev(params, "params")
+    targets = _check_dev(targets, "targets")
+    n_images = params.shape[0]
+    ws = workspace if workspace is not None else _workspace(spec, grid, n_images)
+    md, gd, ld = spec.desc(), grid.desc(), _loss_desc(loss, weight_mode, 1.0, 0.0, 0.0)
+    rc = L.load().inrfit_step_only(C.byref(md), params.data_ptr(), C.byref(gd), targets.data_ptr(), C.byref(ld), n_images,
+                                   int(iters), ws.data_ptr(), ws.numel() * 4, _stream_ptr(params.device))
+    L.check(rc, "inrfit_step_only")
+    return ws
+
+
 @dataclass
 class FitResult:
     params: Tensor            # [n_images, P] final parameters (same storage as the input)

@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py - INR-fits/sec on synthetic 256x256 grids with the convexity prior (BASELINE.json metric).
+
+One "step" = one complete cold fit of the workload on every GPU:
+    ConvexNextNet(n_hidden=130, n_hidden_layers=1, in_features=2), 256x256 linspace grid, binary unaries of a seeded
+    convex blob (fg = 0), loss mean((sigmoid(f) - u)^2), Adam(lr=2e-3), clamp after every step, E = 2000 full-batch
+    steps, fp32  (notebooks/how_to/convexity.ipynb cells 7-9; path_connected_net.py:756 num_epochs).
+Workload per GPU: BASELINE configs[1] - a single image (`--images-per-gpu 1`, the default).  Every rank fits its own
+images (no data-path collective; "weak" scaling), RCCL is used for the barrier / max-time reduction only.
+
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched through torch.distributed.run)
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (icnn_step_kernel): algorithmic FLOPs per launch
+(105,312 flop/point/step x 65,536 points x images) / its average launch duration measured live with events on the launch
+stream.  `cpu_baseline` times the CPU oracle (torch, all host threads) on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FWD_FLOP_PER_POINT = 35104           # 2h^2 + 10h + 4, h = 130, C = 2, L = 1
+STEP_FLOP_PER_POINT = 3 * FWD_FLOP_PER_POINT   # forward + backward(dX) + backward(dW)  
+PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed fits per GPU")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed fits per GPU")
+    ap.add_argument("--epochs", type=int, default=2000, help="optimizer steps per fit (E)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--images-per-gpu", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-steps", type=int, default=60)
+    ap.add_argument("--kernel-iters", type=int, default=200, help="step-kernel launches for the roofline timing")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)  # "nccl" == RCCL on ROCm
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import awesome_amd as A
+    from awesome_amd.dataset import convex_blob_unaries
+    from awesome_amd.model import ConvexNextNet
+
+    S, E, B = args.size, args.epochs, args.images_per_gpu
+    N = S * S
+    spec = A.IcnnSpec(130, 2, 1)
+    # image i of rank r is blob seed r*B + i; initial weights: the reference's seeded default init
+    seeds = [rank * B + i for i in range(B)]
+    unaries = torch.stack([convex_blob_unaries(S, s).reshape(-1) for s in seeds]).to(dev)
+    init = []
+    for s in seeds:
+        torch.manual_seed(s)
+        init.append(ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=1).flat_parameters())
+    init = torch.stack(init).to(dev)
+    grid = A.Grid.linspace(S, S, dev)
+
+    def one_fit():
+        params = init.clone()
+        return A.fit(spec, params, grid, unaries, E, lr=2e-3, loss="se", optimizer="adam", clamp=True, record_loss=False,
+                     want_logits=True)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    res = None
+    for _ in range(args.warmup):
+        res = one_fit()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = one_fit()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # quality of the last fit: fg-mIoU of the thresholded prior vs the unaries (the reference's IoU gate metric)
+    prob = torch.sigmoid(res.logits)
+    iou = A.miou((prob > 0.5).float(), (unaries > 0.5).float(), invert=True)
+    status_bad = int((res.status != 0).sum().item())
+    if world > 1:
+        gathered = [torch.zeros_like(iou) for _ in range(world)]
+        dist.all_gather(gathered, iou)   # the only data collective: a few bytes of metrics
+        iou_all = torch.cat(gathered)
+    else:
+        iou_all = iou
+    miou = float(iou_all.mean().item())
+
+    # ---- roofline of the dominant kernel: average launch duration, events on the launch stream ---------------------
+    params = res.params
+    ws = A.icnn.step_only(spec, params, grid, unaries, 5)           # warm
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    A.icnn.step_only(spec, params, grid, unaries, args.kernel_iters, workspace=ws)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    kernel_ms = e0.elapsed_time(e1) / args.kernel_iters
+    flop_per_launch = STEP_FLOP_PER_POINT * N * B
+    achieved = flop_per_launch / (kernel_ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+                "kernel": "icnn_step_kernel<130,2,train>", "kernel_us": round(kernel_ms * 1e3, 2),
+                "flop_per_launch": flop_per_launch}
+
+    out = None
+    if rank == 0:
+        fits = args.steps * B * world
+        value = fits / elapsed
+        out = {
+            "metric": "INR-fits/sec (256x256 grid, convexity prior)", "value": round(value, 4), "unit": "fits/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{B} x {S}x{S} synthetic convex blob per GPU, ConvexNextNet(h=130,L=1), "
+                                   f"SE(sigmoid) mean, Adam lr 2e-3, clamp, E={E} full-batch steps (BASELINE configs[1])",
+                       "images_per_gpu": B, "grid": f"{S}x{S}", "epochs_per_fit": E, "parallelism": f"dp{world} (independent fits)"},
+            "miou_vs_unaries": round(miou, 5), "nonfinite_fits": status_bad,
+            "us_per_optimizer_step": round(elapsed / args.steps / E * 1e6, 2),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, init[0].cpu(), unaries[0].cpu(), spec)
+            out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, flat0, unaries0, spec):
+    """The CPU oracle (pure torch restatement of the reference loop, parity-pinned to the reference's golden vectors)
+    timed on this host: `cpu_sample_steps` optimizer steps of the same 256x256 fit, extrapolated to E steps."""
+    import torch
+    import awesome_amd as A
+    from oracle import inr_oracle as O   # the thing being timed as the CPU baseline (kind = "port")
+
+    S, E = args.size, args.epochs
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    threads = max(1, min(cores, 16))   # the GPU box's CPU share for one GPU; more threads oversubscribe and run slower
+    torch.set_num_threads(threads)
+    p = A.unpack_params(spec, flat0)
+    grid = O.positional_grid(S, S)[None]
+    un = unaries0.reshape(1, 1, S, S)
+    O.fit_icnn(p, grid, un, 3, lr=2e-3)   # warm-up
+    n = args.cpu_sample_steps
+    t0 = time.perf_counter()
+    O.fit_icnn(p, grid, un, n, lr=2e-3)
+    dt = time.perf_counter() - t0
+    s_per_step = dt / n
+    return {"value": round(1.0 / (s_per_step * E), 6), "unit": "fits/s", "cores": threads, "kind": "port",
+            "sample": f"{n} of {E} optimizer steps of the same {S}x{S} fit ({dt:.1f} s, {s_per_step * 1e3:.1f} ms/step), "
+                      f"torch {torch.__version__} CPU, extrapolated linearly",
+            "ms_per_optimizer_step": round(s_per_step * 1e3, 2)}
+
+
+if __name__ == "__main__":
+    main()

@@ -44,7 +44,7 @@ enum {
 
 enum { INR_MODEL_ICNN = 1 };
 enum { INR_GRID_SEPARABLE = 0, INR_GRID_EXPLICIT = 1 };
-enum { INR_LOSS_SE = 0, INR_LOSS_BCE = 1 };
+enum { INR_LOSS_SE = 0, INR_LOSS_BCE = 1, INR_LOSS_EXTERNAL = 2 /* inrfit_backward only: dL/dlogit supplied */ };
 enum { INR_WEIGHT_NONE = 0, INR_WEIGHT_EQUAL = 1, INR_WEIGHT_RATIO = 2, INR_WEIGHT_SSSDMS = 3, INR_WEIGHT_EXPLICIT = 4 };
 enum { INR_OPT_ADAM = 0, INR_OPT_ADAMAX = 1 };
 enum { INR_STATUS_OK = 0, INR_STATUS_NONFINITE = 1 };
@@ -102,8 +102,10 @@ typedef struct InrOptDesc {
 
 /* Per-image optimizer state, `opt_state` = n_images * inrfit_opt_state_floats(model) floats:
  *   exp_avg [P] | exp_avg_sq or exp_inf [P] | header [INR_OPT_HEADER_FLOATS]
- * header: [0] lr (current), [1] plateau best, [2] plateau num_bad (as float), [3] last loss, rest reserved.
- * Zero-initialise for a cold fit (header lr is taken from InrOptDesc when step0 == 0). */
+ * header: [0],[1] lr of odd/even steps (double buffer, internal), [2] current lr, [3] plateau best,
+ *         [4] plateau num_bad (as float), [5] last loss, [6],[7] reserved.
+ * Zero-initialise for a cold fit (step0 == 0 takes lr from InrOptDesc and resets the plateau state;
+ * step0 > 0 continues from header[2..4]). */
 #define INR_OPT_HEADER_FLOATS 8
 
 /* Capabilities. max_hidden: largest n_hidden any built kernel supports; lds_bytes: LDS used by the h=130 kernel. */
@@ -128,6 +130,12 @@ int inrfit_loss_grad(const InrModelDesc* model, const float* params, const InrGr
                      const InrLossDesc* loss, int n_images, float* loss_out, float* grads, void* workspace,
                      int64_t workspace_bytes, void* stream);
 
+/* grads[n_images][P] = sum_p dlogits[image][p] * d logit_p / d params: the vector-Jacobian product of the forward
+ * (forward is recomputed, nothing is saved).  Replaces autograd's backward through ConvexNextNet.forward for an
+ * arbitrary downstream criterion (AwesomeImageLoss, FBMSJointLoss, ... - awesome/agent/torch_agent.py:478-491). */
+int inrfit_backward(const InrModelDesc* model, const float* params, const InrGridDesc* grid, const float* dlogits,
+                    int n_images, float* grads, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* `steps` full-batch optimisation steps of n_images independent fits, entirely on device:
  *   E x { forward, loss, backward, Adam/Adamax step, clamp, plateau.step(loss) }
  * Replaces the inner loops of _prior_based_pretrain (awesome/model/path_connected_net.py:937-962), the how-to loop
@@ -144,6 +152,12 @@ int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const
  * (awesome/measures/miou.py:29-48) and the IoU gate of the fit loop (path_connected_net.py:964-972). */
 int inrfit_miou(const float* out, const float* tgt, int n_images, int64_t n_points, float thr_out, float thr_tgt, int invert,
                 float* iou, void* stream);
+
+/* Measurement hook (bench.py, rocprof): launch ONLY the fused forward+loss+backward step kernel `iters` times
+ * back-to-back on `stream` (no optimizer step), so its average duration can be bracketed with events. */
+int inrfit_step_only(const InrModelDesc* model, const float* params, const InrGridDesc* grid, const float* targets,
+                     const InrLossDesc* loss, int n_images, int iters, void* workspace, int64_t workspace_bytes,
+                     void* stream);
 
 const char* inrfit_strerror(int code);
 
