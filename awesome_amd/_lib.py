@@ -53,7 +53,7 @@ EXPORTS = {
     "inrfit_opt_state_floats": (C.c_int64, [C.POINTER(InrModelDesc)]),
     "inrfit_workspace_bytes": (C.c_int64, [C.POINTER(InrModelDesc), C.POINTER(InrGridDesc), C.c_int]),
     "inrfit_forward": (C.c_int, [C.POINTER(InrModelDesc), C.c_void_p, C.POINTER(InrGridDesc), C.c_int, C.c_void_p,
-                                 C.c_void_p]),
+                                 C.c_void_p, C.c_int64, C.c_void_p]),
     "inrfit_loss_grad": (C.c_int, [C.POINTER(InrModelDesc), C.c_void_p, C.POINTER(InrGridDesc), C.c_void_p,
                                    C.POINTER(InrLossDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                    C.c_void_p]),

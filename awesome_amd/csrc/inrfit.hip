@@ -107,15 +107,19 @@ struct Cfg {
     static constexpr int A_G_MAX = REM == 0 ? 4 : (REM + 3) / 4;         // lane groups that write tile TL of stage A
     static constexpr int B_G_MAX = (POS_MAX % 16) / 4 + 1;               // lane groups that write the last tile of stage B
 
-    // LDS carve (floats)
-    static constexpr int OFF_W = 0;
-    static constexpr int OFF_STA = OFF_W + (H + 1) * S + 16;  // +16 zero floats: tail reads of the zero row
-    static constexpr int OFF_STB = OFF_STA + SP * SA + 16;
-    static constexpr int OFF_WIN = OFF_STB + SP * SB + 16;  // [C][PT]
+    // LDS carve (floats).  [0, IMG_FLOATS) is the "parameter image": it is kept in global memory in exactly this
+    // layout (written by pack_image_kernel / icnn_update_kernel) and copied verbatim at kernel start.
+    static constexpr int OFF_W = 0;                           // W1ext [H+1][S] (+16 zero floats: tail reads of the zero row)
+    static constexpr int OFF_WIN = OFF_W + (H + 1) * S + 16;  // [C][PT]
     static constexpr int OFF_BIN = OFF_WIN + C * PT;
     static constexpr int OFF_FLOOR = OFF_BIN + PT;
     static constexpr int OFF_WO = OFF_FLOOR + PT;
-    static constexpr int LDS_FLOATS = OFF_WO + PT;
+    static constexpr int OFF_SC = OFF_WO + PT;                // scalars: b_o, s_o[0..C-1]
+    static constexpr int IMG_FLOATS = OFF_SC + 8;
+    static_assert(IMG_FLOATS % 4 == 0, "image must be float4-copyable");
+    static constexpr int OFF_STA = IMG_FLOATS;
+    static constexpr int OFF_STB = OFF_STA + SP * SA + 16;
+    static constexpr int LDS_FLOATS = OFF_STB + SP * SB + 16;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
 
     // flat parameter offsets (L = 1), include/inrfit.h
@@ -136,8 +140,38 @@ struct Cfg {
     static constexpr int tile_end(int w) { return (w + 1) * TPW < NTILES ? (w + 1) * TPW : NTILES; }
 };
 
+// run-time description of the parameter image (same numbers as Cfg<H,C>), for the kernels that are not templated
+struct ImgMap {
+    int H, C, S, PT, floats;
+    int off_win, off_bin, off_floor, off_wo, off_sc;
+    int ext[4];
+    int p_bin, p_w1, p_b1, p_s1, p_wo, p_bo, p_so, P;
+};
+
+// image offset of flat parameter j
+__device__ __forceinline__ int image_offset(const ImgMap& m, int j) {
+    if (j < m.p_bin) {                       // input.weight [H][C]
+        const int i = j / m.C, c = j - i * m.C;
+        return m.off_win + c * m.PT + i;
+    }
+    if (j < m.p_w1) return m.off_bin + (j - m.p_bin);
+    if (j < m.p_b1) {                        // skip.0.ln.weight [H][H]
+        const int q = j - m.p_w1;
+        const int o = q / m.H, i = q - o * m.H;
+        return o * m.S + i;
+    }
+    if (j < m.p_s1) return (j - m.p_b1) * m.S + m.ext[0];
+    if (j < m.p_wo) {                        // skip.0.skp.weight [H][C]
+        const int q = j - m.p_s1;
+        const int o = q / m.C, c = q - o * m.C;
+        return o * m.S + m.ext[1 + c];
+    }
+    if (j < m.p_bo) return m.off_wo + (j - m.p_wo);
+    return m.off_sc + (j - m.p_bo);          // b_o, s_o[c]
+}
+
 struct StepArgs {
-    const float* params;   // [n_images][P]
+    const float* wimg;     // [n_images][IMG_FLOATS] parameter images
     const float* targets;  // [n_images][N]            (TRAIN)
     const float* coef;     // [n_images][2] c_fg, c_bg (TRAIN)
     float* slabs;          // [n_images][wgs][PS]      (TRAIN)
@@ -272,48 +306,35 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
     const int l15 = lane & 15, g = lane >> 4;
     const int img = blockIdx.x / a.wgs;
     const int wg = blockIdx.x - img * a.wgs;
-    const float* __restrict__ prm = a.params + (size_t)img * G::P;
     const long long N = a.N;
 
-    // ---- stage the parameters into LDS -------------------------------------------------------------------------
-    for (int i = tid; i < (H + 1) * S + 16; i += WG_THREADS) Wimg[i] = 0.f;
-    for (int i = tid; i < G::LDS_FLOATS - G::OFF_WIN; i += WG_THREADS) WinT[i] = 0.f;
-    if (TRAIN)
-        for (int i = tid; i < G::OFF_WIN - G::OFF_STA; i += WG_THREADS) stA[i] = 0.f;
-    __syncthreads();
-    for (int i = tid; i < H * H; i += WG_THREADS) {
-        const int o = i / H, c = i - o * H;
-        Wimg[o * S + c] = prm[G::P_W1 + i];
-    }
-    for (int i = tid; i < H; i += WG_THREADS) {
-        Wimg[i * S + G::ext_pos(0)] = prm[G::P_B1 + i];
+    // ---- copy the parameter image into LDS (all loads in flight at once) ------------------------------------------
+    {
+        const f32x4* __restrict__ src = (const f32x4*)(a.wimg + (size_t)img * G::IMG_FLOATS);
+        constexpr int NV4 = G::IMG_FLOATS / 4;
+        constexpr int NIT = (NV4 + WG_THREADS - 1) / WG_THREADS;
+        f32x4 tmp[NIT];
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            Wimg[i * S + G::ext_pos(1 + c)] = prm[G::P_S1 + i * C + c];
-            WinT[c * PT + i] = prm[G::P_WIN + i * C + c];
+        for (int k = 0; k < NIT; ++k) {
+            const int i = tid + k * WG_THREADS;
+            if (i < NV4) tmp[k] = src[i];
         }
-        binT[i] = prm[G::P_BIN + i];
-        woT[i] = prm[G::P_WO + i];
-    }
-    if (tid == 0) {
-        binT[G::ext_pos(0)] = 1.f;  // ext input "1"
-        floorT[G::ext_pos(0)] = -INFINITY;
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            WinT[c * PT + G::ext_pos(1 + c)] = 1.f;  // ext input x_c (no relu: floor = -inf)
-            floorT[G::ext_pos(1 + c)] = -INFINITY;
+        for (int k = 0; k < NIT; ++k) {
+            const int i = tid + k * WG_THREADS;
+            if (i < NV4) ((f32x4*)smem)[i] = tmp[k];
         }
     }
-    const float b_o = prm[G::P_BO];
-    float s_o[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) s_o[c] = prm[G::P_SO + c];
     float cfg_ = 0.f, cbg_ = 0.f;
     if (TRAIN) {
         cfg_ = a.coef[2 * img];
         cbg_ = a.coef[2 * img + 1];
     }
     __syncthreads();
+    const float b_o = smem[G::OFF_SC];
+    float s_o[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) s_o[c] = smem[G::OFF_SC + 1 + c];
 
     // per-lane LDS row offsets of the weight image: forward reads row (16t + l15), clamped to the zero row H
     int frow[MT];
@@ -556,6 +577,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
 // slab reduction + optimizer step
 // ---------------------------------------------------------------------------------------------------------------------
 struct UpdArgs {
+    float* wimg;          // [n_images][img.floats] parameter images (kept in step with params)
+    ImgMap img;
     float* params;        // [n_images][P]
     float* opt_state;     // [n_images][2P + HDR]
     const float* slabs;   // [n_images][wgs][PS]
@@ -656,8 +679,38 @@ __global__ __launch_bounds__(UPD_PARAMS * UPD_GROUPS) void icnn_update_kernel(co
     }
     if (u.opt.clamp && ((j >= u.clamp_lo0 && j < u.clamp_hi0) || (j >= u.clamp_lo1 && j < u.clamp_hi1))) p = fmaxf(p, 0.f);
     u.params[(size_t)img * u.P + j] = p;
+    u.wimg[(size_t)img * u.img.floats + image_offset(u.img, j)] = p;
     st[j] = m;
     st[u.P + j] = v;
+}
+
+// params -> parameter image (zeros, ext-input constants, then every parameter at its image offset)
+__global__ __launch_bounds__(256) void pack_image_kernel(const float* __restrict__ params, float* __restrict__ wimg,
+                                                         const ImgMap m) {
+    const int img = blockIdx.y;
+    float* __restrict__ dst = wimg + (size_t)img * m.floats;
+    const float* __restrict__ src = params + (size_t)img * m.P;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m.floats) return;
+    // which parameter (if any) lives at image offset i?  Invert image_offset by scanning is too slow; instead every
+    // thread first writes the constant background of its slot, and parameter threads overwrite afterwards (2nd launch).
+    float v = 0.f;
+    if (i == m.off_bin + m.ext[0]) v = 1.f;                       // ext input "1": bias slot
+    for (int c = 0; c < m.C; ++c) {
+        if (i == m.off_win + c * m.PT + m.ext[1 + c]) v = 1.f;    // ext input x_c
+        if (i == m.off_floor + m.ext[1 + c]) v = -INFINITY;       // no relu on ext inputs
+    }
+    if (i == m.off_floor + m.ext[0]) v = -INFINITY;
+    dst[i] = v;
+    (void)src;
+}
+
+__global__ __launch_bounds__(256) void pack_params_kernel(const float* __restrict__ params, float* __restrict__ wimg,
+                                                          const ImgMap m) {
+    const int img = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m.P) return;
+    wimg[(size_t)img * m.floats + image_offset(m, j)] = params[(size_t)img * m.P + j];
 }
 
 // per-image loss coefficients (c_fg, c_bg): 'mean' normalisation x UnariesWeightedLoss class weight
@@ -758,13 +811,20 @@ struct KernelEntry {
     int lds_bytes;
     int P;
     int clamp_lo0, clamp_hi0, clamp_lo1, clamp_hi1;
+    ImgMap img;
 };
 
 template <int H, int C>
 constexpr KernelEntry make_entry() {
     using G = Cfg<H, C>;
+    ImgMap m{};
+    m.H = H; m.C = C; m.S = G::S; m.PT = G::PT; m.floats = G::IMG_FLOATS;
+    m.off_win = G::OFF_WIN; m.off_bin = G::OFF_BIN; m.off_floor = G::OFF_FLOOR; m.off_wo = G::OFF_WO; m.off_sc = G::OFF_SC;
+    for (int e = 0; e < 4; ++e) m.ext[e] = e < G::NEXT ? G::ext_pos(e) : 0;
+    m.p_bin = G::P_BIN; m.p_w1 = G::P_W1; m.p_b1 = G::P_B1; m.p_s1 = G::P_S1; m.p_wo = G::P_WO; m.p_bo = G::P_BO;
+    m.p_so = G::P_SO; m.P = G::P;
     return KernelEntry{H, C, icnn_step_kernel<H, C, true>, icnn_step_kernel<H, C, false>, G::LDS_BYTES, G::P,
-                       G::P_W1, G::P_W1 + H * H, G::P_WO, G::P_WO + H};
+                       G::P_W1, G::P_W1 + H * H, G::P_WO, G::P_WO + H, m};
 }
 
 const KernelEntry kEntries[] = {
@@ -823,6 +883,7 @@ int set_lds(const KernelEntry* e) {
 
 struct Workspace {
     float* coef;
+    float* wimg;
     float* slabs;
     int wgs, PS;
     long long bytes;
@@ -833,10 +894,12 @@ Workspace carve(const KernelEntry* e, long long n_points, int n_images, void* ba
     w.wgs = wgs_per_image(n_points, n_images);
     w.PS = (e->P + 1 + 3) / 4 * 4;
     const long long coef_bytes = ((long long)n_images * 2 * 4 + 255) / 256 * 256;
+    const long long img_bytes = ((long long)n_images * e->img.floats * 4 + 255) / 256 * 256;
     const long long slab_bytes = (long long)n_images * w.wgs * w.PS * 4;
     w.coef = (float*)base;
-    w.slabs = (float*)((char*)base + coef_bytes);
-    w.bytes = coef_bytes + slab_bytes;
+    w.wimg = (float*)((char*)base + coef_bytes);
+    w.slabs = (float*)((char*)base + coef_bytes + img_bytes);
+    w.bytes = coef_bytes + img_bytes + slab_bytes;
     return w;
 }
 
@@ -871,30 +934,16 @@ int64_t inrfit_workspace_bytes(const InrModelDesc* model, const InrGridDesc* gri
     return carve(e, grid->n_points, n_images, nullptr).bytes;
 }
 
-int inrfit_forward(const InrModelDesc* model, const float* params, const InrGridDesc* grid, int n_images, float* logits,
-                   void* stream) {
-    const KernelEntry* e = find_entry(model);
-    if (!e) return INR_EUNSUPPORTED;
-    if (!params || !logits) return INR_EINVAL;
-    int rc = check_grid(grid, e, n_images);
-    if (rc) return rc;
-    if ((rc = set_lds(e))) return rc;
-    StepArgs a{};
-    a.params = params;
-    a.logits = logits;
-    a.grid = *grid;
-    a.N = grid->n_points;
-    a.n_images = n_images;
-    a.wgs = wgs_per_image(grid->n_points, n_images);
-    a.PS = 0;
-    hipLaunchKernelGGL(e->fwd, dim3((unsigned)(n_images * a.wgs)), dim3(WG_THREADS), e->lds_bytes, (hipStream_t)stream, a);
+static int launch_pack(const KernelEntry* e, const Workspace& w, const float* params, int n_images, hipStream_t s) {
+    hipLaunchKernelGGL(pack_image_kernel, dim3((e->img.floats + 255) / 256, n_images), dim3(256), 0, s, params, w.wimg, e->img);
+    hipLaunchKernelGGL(pack_params_kernel, dim3((e->P + 255) / 256, n_images), dim3(256), 0, s, params, w.wimg, e->img);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 
-static int launch_step(const KernelEntry* e, const Workspace& w, const float* params, const InrGridDesc* grid,
-                       const float* targets, const InrLossDesc* loss, int n_images, float* logits, hipStream_t s) {
+static int launch_step(const KernelEntry* e, const Workspace& w, bool train, const InrGridDesc* grid, const float* targets,
+                       int loss_kind, int n_images, float* logits, hipStream_t s) {
     StepArgs a{};
-    a.params = params;
+    a.wimg = w.wimg;
     a.targets = targets;
     a.coef = w.coef;
     a.slabs = w.slabs;
@@ -904,8 +953,8 @@ static int launch_step(const KernelEntry* e, const Workspace& w, const float* pa
     a.n_images = n_images;
     a.wgs = w.wgs;
     a.PS = w.PS;
-    a.loss_kind = loss->kind;
-    hipLaunchKernelGGL(e->train, dim3((unsigned)(n_images * w.wgs)), dim3(WG_THREADS), e->lds_bytes, s, a);
+    a.loss_kind = loss_kind;
+    hipLaunchKernelGGL(train ? e->train : e->fwd, dim3((unsigned)(n_images * w.wgs)), dim3(WG_THREADS), e->lds_bytes, s, a);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 
@@ -916,21 +965,22 @@ static int check_loss(const InrLossDesc* l) {
     return INR_OK;
 }
 
-int inrfit_loss_grad(const InrModelDesc* model, const float* params, const InrGridDesc* grid, const float* targets,
-                     const InrLossDesc* loss, int n_images, float* loss_out, float* grads, void* workspace,
-                     int64_t workspace_bytes, void* stream) {
+// common argument checks + workspace carve
+static int prepare(const InrModelDesc* model, const InrGridDesc* grid, int n_images, void* workspace, int64_t workspace_bytes,
+                   const KernelEntry** e_out, Workspace* w_out) {
     const KernelEntry* e = find_entry(model);
     if (!e) return INR_EUNSUPPORTED;
-    if (!params || !targets || !loss_out || !grads || !workspace) return INR_EINVAL;
+    if (!workspace) return INR_EINVAL;
     int rc = check_grid(grid, e, n_images);
     if (rc) return rc;
-    if ((rc = check_loss(loss))) return rc;
-    const Workspace w = carve(e, grid->n_points, n_images, workspace);
-    if (workspace_bytes < w.bytes) return INR_EWORKSPACE;
+    *w_out = carve(e, grid->n_points, n_images, workspace);
+    if (workspace_bytes < w_out->bytes) return INR_EWORKSPACE;
     if ((rc = set_lds(e))) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(loss_coef_kernel, dim3(n_images), dim3(256), 0, s, targets, (long long)grid->n_points, *loss, w.coef);
-    if ((rc = launch_step(e, w, params, grid, targets, loss, n_images, nullptr, s))) return rc;
+    *e_out = e;
+    return INR_OK;
+}
+
+static void launch_reduce(const KernelEntry* e, const Workspace& w, int n_images, float* grads, float* loss_out, hipStream_t s) {
     UpdArgs u{};
     u.slabs = w.slabs;
     u.grads_out = grads;
@@ -940,79 +990,91 @@ int inrfit_loss_grad(const InrModelDesc* model, const float* params, const InrGr
     u.wgs = w.wgs;
     u.n_images = n_images;
     u.mode = 1;
-    hipLaunchKernelGGL(icnn_update_kernel, dim3((e->P + 1 + UPD_PARAMS - 1) / UPD_PARAMS, n_images), dim3(UPD_PARAMS, UPD_GROUPS), 0, s, u);
+    hipLaunchKernelGGL(icnn_update_kernel, dim3((e->P + 1 + UPD_PARAMS - 1) / UPD_PARAMS, n_images),
+                       dim3(UPD_PARAMS, UPD_GROUPS), 0, s, u);
+}
+
+int inrfit_forward(const InrModelDesc* model, const float* params, const InrGridDesc* grid, int n_images, float* logits,
+                   void* workspace, int64_t workspace_bytes, void* stream) {
+    const KernelEntry* e;
+    Workspace w;
+    if (!params || !logits) return INR_EINVAL;
+    int rc = prepare(model, grid, n_images, workspace, workspace_bytes, &e, &w);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = launch_pack(e, w, params, n_images, s))) return rc;
+    return launch_step(e, w, false, grid, nullptr, 0, n_images, logits, s);
+}
+
+int inrfit_loss_grad(const InrModelDesc* model, const float* params, const InrGridDesc* grid, const float* targets,
+                     const InrLossDesc* loss, int n_images, float* loss_out, float* grads, void* workspace,
+                     int64_t workspace_bytes, void* stream) {
+    const KernelEntry* e;
+    Workspace w;
+    if (!params || !targets || !loss_out || !grads) return INR_EINVAL;
+    int rc = check_loss(loss);
+    if (rc) return rc;
+    if ((rc = prepare(model, grid, n_images, workspace, workspace_bytes, &e, &w))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(loss_coef_kernel, dim3(n_images), dim3(256), 0, s, targets, (long long)grid->n_points, *loss, w.coef);
+    if ((rc = launch_pack(e, w, params, n_images, s))) return rc;
+    if ((rc = launch_step(e, w, true, grid, targets, loss->kind, n_images, nullptr, s))) return rc;
+    launch_reduce(e, w, n_images, grads, loss_out, s);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 
 int inrfit_backward(const InrModelDesc* model, const float* params, const InrGridDesc* grid, const float* dlogits,
                     int n_images, float* grads, void* workspace, int64_t workspace_bytes, void* stream) {
-    const KernelEntry* e = find_entry(model);
-    if (!e) return INR_EUNSUPPORTED;
-    if (!params || !dlogits || !grads || !workspace) return INR_EINVAL;
-    int rc = check_grid(grid, e, n_images);
+    const KernelEntry* e;
+    Workspace w;
+    if (!params || !dlogits || !grads) return INR_EINVAL;
+    int rc = prepare(model, grid, n_images, workspace, workspace_bytes, &e, &w);
     if (rc) return rc;
-    const Workspace w = carve(e, grid->n_points, n_images, workspace);
-    if (workspace_bytes < w.bytes) return INR_EWORKSPACE;
-    if ((rc = set_lds(e))) return rc;
     hipStream_t s = (hipStream_t)stream;
-    InrLossDesc ld{};
-    ld.kind = INR_LOSS_EXTERNAL;
-    ld.weight_mode = INR_WEIGHT_NONE;
-    hipLaunchKernelGGL(loss_coef_kernel, dim3(n_images), dim3(256), 0, s, dlogits, (long long)grid->n_points, ld, w.coef);
-    if ((rc = launch_step(e, w, params, grid, dlogits, &ld, n_images, nullptr, s))) return rc;
-    UpdArgs u{};
-    u.slabs = w.slabs;
-    u.grads_out = grads;
-    u.loss_out = w.coef;  // scratch: the loss slot is unused in this mode
-    u.P = e->P;
-    u.PS = w.PS;
-    u.wgs = w.wgs;
-    u.n_images = n_images;
-    u.mode = 1;
-    hipLaunchKernelGGL(icnn_update_kernel, dim3((e->P + 1 + UPD_PARAMS - 1) / UPD_PARAMS, n_images),
-                       dim3(UPD_PARAMS, UPD_GROUPS), 0, s, u);
+    if ((rc = launch_pack(e, w, params, n_images, s))) return rc;
+    if ((rc = launch_step(e, w, true, grid, dlogits, INR_LOSS_EXTERNAL, n_images, nullptr, s))) return rc;
+    launch_reduce(e, w, n_images, grads, w.coef /* scratch: the loss slot is unused in this mode */, s);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 
 int inrfit_step_only(const InrModelDesc* model, const float* params, const InrGridDesc* grid, const float* targets,
                      const InrLossDesc* loss, int n_images, int iters, void* workspace, int64_t workspace_bytes,
                      void* stream) {
-    const KernelEntry* e = find_entry(model);
-    if (!e) return INR_EUNSUPPORTED;
-    if (!params || !targets || !workspace || iters < 0) return INR_EINVAL;
-    int rc = check_grid(grid, e, n_images);
+    const KernelEntry* e;
+    Workspace w;
+    if (!params || !targets || iters < 0) return INR_EINVAL;
+    int rc = check_loss(loss);
     if (rc) return rc;
-    if ((rc = check_loss(loss))) return rc;
-    const Workspace w = carve(e, grid->n_points, n_images, workspace);
-    if (workspace_bytes < w.bytes) return INR_EWORKSPACE;
-    if ((rc = set_lds(e))) return rc;
+    if ((rc = prepare(model, grid, n_images, workspace, workspace_bytes, &e, &w))) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(loss_coef_kernel, dim3(n_images), dim3(256), 0, s, targets, (long long)grid->n_points, *loss, w.coef);
+    if ((rc = launch_pack(e, w, params, n_images, s))) return rc;
     for (int it = 0; it < iters; ++it)
-        if ((rc = launch_step(e, w, params, grid, targets, loss, n_images, nullptr, s))) return rc;
+        if ((rc = launch_step(e, w, true, grid, targets, loss->kind, n_images, nullptr, s))) return rc;
     return INR_OK;
 }
 
 int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const InrGridDesc* grid, const float* targets,
                const InrLossDesc* loss, const InrOptDesc* opt, int n_images, int steps, int step0, float* loss_hist,
                float* final_logits, int32_t* status, void* workspace, int64_t workspace_bytes, void* stream) {
-    const KernelEntry* e = find_entry(model);
-    if (!e) return INR_EUNSUPPORTED;
-    if (!params || !opt_state || !targets || !opt || !workspace || steps < 0 || step0 < 0) return INR_EINVAL;
+    const KernelEntry* e;
+    Workspace w;
+    if (!params || !opt_state || !targets || !opt || steps < 0 || step0 < 0) return INR_EINVAL;
     if (opt->kind != INR_OPT_ADAM && opt->kind != INR_OPT_ADAMAX) return INR_EINVAL;
-    int rc = check_grid(grid, e, n_images);
+    int rc = check_loss(loss);
     if (rc) return rc;
-    if ((rc = check_loss(loss))) return rc;
-    const Workspace w = carve(e, grid->n_points, n_images, workspace);
-    if (workspace_bytes < w.bytes) return INR_EWORKSPACE;
-    if ((rc = set_lds(e))) return rc;
+    if (loss->kind == INR_LOSS_EXTERNAL) return INR_EINVAL;
+    if ((rc = prepare(model, grid, n_images, workspace, workspace_bytes, &e, &w))) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(loss_coef_kernel, dim3(n_images), dim3(256), 0, s, targets, (long long)grid->n_points, *loss, w.coef);
     hipLaunchKernelGGL(opt_init_kernel, dim3(n_images), dim3(64), 0, s, opt_state, e->P, *opt, step0);
     if (status) {
         if (hipMemsetAsync(status, 0, sizeof(int32_t) * n_images, s) != hipSuccess) return INR_ELAUNCH;
     }
+    if ((rc = launch_pack(e, w, params, n_images, s))) return rc;
     UpdArgs u{};
+    u.wimg = w.wimg;
+    u.img = e->img;
     u.params = params;
     u.opt_state = opt_state;
     u.slabs = w.slabs;
@@ -1031,13 +1093,13 @@ int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const
     u.clamp_hi1 = e->clamp_hi1;
     const dim3 ugrid((e->P + 1 + UPD_PARAMS - 1) / UPD_PARAMS, n_images);
     for (int it = 0; it < steps; ++it) {
-        if ((rc = launch_step(e, w, params, grid, targets, loss, n_images, nullptr, s))) return rc;
+        if ((rc = launch_step(e, w, true, grid, targets, loss->kind, n_images, nullptr, s))) return rc;
         u.t = step0 + it + 1;
         u.hist_idx = it;
         hipLaunchKernelGGL(icnn_update_kernel, ugrid, dim3(UPD_PARAMS, UPD_GROUPS), 0, s, u);
     }
     if (hipGetLastError() != hipSuccess) return INR_ELAUNCH;
-    if (final_logits) return inrfit_forward(model, params, grid, n_images, final_logits, stream);
+    if (final_logits) return launch_step(e, w, false, grid, nullptr, 0, n_images, final_logits, s);
     return INR_OK;
 }
 

@@ -197,8 +197,9 @@ def forward(spec: IcnnSpec, params: Tensor, grid: Grid) -> Tensor:
     assert params.shape[1] == spec.n_params, (params.shape, spec.n_params)
     logits = torch.empty(n_images, grid.n_points, dtype=torch.float32, device=params.device)
     md, gd = spec.desc(), grid.desc()
-    rc = L.load().inrfit_forward(C.byref(md), params.data_ptr(), C.byref(gd), n_images, logits.data_ptr(),
-                                 _stream_ptr(params.device))
+    ws = _workspace(spec, grid, n_images)
+    rc = L.load().inrfit_forward(C.byref(md), params.data_ptr(), C.byref(gd), n_images, logits.data_ptr(), ws.data_ptr(),
+                                 ws.numel() * 4, _stream_ptr(params.device))
     L.check(rc, "inrfit_forward")
     return logits
 

@@ -114,14 +114,14 @@ int inrfit_query(int* abi_version, int* max_hidden, int* lds_bytes);
 int inrfit_supported(const InrModelDesc* model);
 int64_t inrfit_param_count(const InrModelDesc* model);
 int64_t inrfit_opt_state_floats(const InrModelDesc* model);
-/* Scratch the step kernels need (per-workgroup gradient slabs, per-image loss coefficients). */
+/* Scratch every compute call needs (parameter images in LDS layout, per-workgroup gradient slabs, loss coefficients). */
 int64_t inrfit_workspace_bytes(const InrModelDesc* model, const InrGridDesc* grid, int n_images);
 
 /* logits[n_images][n_points] = f_theta(grid).  Replaces ConvexNet/ConvexNextNet.forward
  * (awesome/model/convex_net.py:26-35, 205-214) incl. the @pixelize reshapes, for n_images parameter sets at once
  * (the PriorCache axis, awesome/util/prior_cache.py:49-59). */
 int inrfit_forward(const InrModelDesc* model, const float* params, const InrGridDesc* grid, int n_images,
-                   float* logits, void* stream);
+                   float* logits, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* loss_out[n_images], grads[n_images][P] (same flat order as params) of the data term at `params`.
  * Replaces one forward + criterion + loss.backward() of the hot loop (awesome/model/path_connected_net.py:941-948;
