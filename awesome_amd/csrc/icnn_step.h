@@ -1,0 +1,662 @@
+// icnn_step.h - the fused forward + data term + backward kernel of the ICNN fit (gfx950 / CDNA4).
+// Included by inrfit.hip (single translation unit).  Design notes: DESIGN.md §4.1.
+//
+// Reference arithmetic being computed (jp-schneider/awesome, awesome/model/convex_net.py:205-214):
+//   z0 = relu(W_in x + b_in);  z1 = relu(W1 z0 + b1 + S1 x);  y = w_o.z1 + b_o + s_o.x
+// plus sigmoid, SE/BCE data term (awesome/measures/se.py:21-23, weighted_loss.py:67-92) and the full backward pass.
+//
+// Geometry.  h = 16*TM + HR.  The 16*TM "main" hidden units go through v_mfma_f32_16x16x4_f32; the HR (<= 4) leftover
+// units are handled on the VALU in the shadow of the MFMAs, so the matrix pipe does no padding work.
+//   * points sit on the MFMA column (lane & 15), hidden units on the accumulator rows: the D tile of one product is the
+//     B operand of the next one (k-step (tile, r) takes position 16*tile + 4*(lane>>4) + r from every lane group), so
+//     activations stay in registers from layer to layer and into the backward product;
+//   * the last k-group of the forward product carries the leftover hidden units (lane group 0) and the "ext" inputs
+//     (1, x_0.., lane groups 1-2): bias and skip weights are columns of the same LDS weight image, and their gradients
+//     fall out of the dW product;
+//   * dW = dZ1^T Z0ext contracts over points: both operands are staged once per 64-point chunk through LDS (point-major
+//     rows, float4 writes), every wave then owns TM/4 row tiles x all column tiles - the same code for all waves.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "inrfit.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// LLVM SchedGroupMask bits for __builtin_amdgcn_sched_group_barrier
+#define SG_VALU 0x2
+#define SG_MFMA 0x8
+#define SG_DS_READ 0x100
+#define SG_DS_WRITE 0x200
+
+namespace {
+
+constexpr int WG_THREADS = 256;
+constexpr int SP = 64;  // points per chunk (4 waves x 16)
+
+constexpr int round_up(int v, int m) { return (v + m - 1) / m * m; }
+// smallest s >= v with s % 8 == 4: float4-aligned rows whose 4-row step lands 16 banks away (conflict-free b32 column
+// reads by the two 16-lane groups of a half-wave, conflict-free b128 row writes by 8 consecutive rows)
+constexpr int stride_4mod8(int v) {
+    int s = round_up(v, 4);
+    while (s % 8 != 4) s += 4;
+    return s;
+}
+
+template <int H, int C>
+struct Cfg {
+    static constexpr int TM = H / 16;            // hidden tiles on the matrix pipe
+    static constexpr int HM = 16 * TM;           // hidden units on the matrix pipe
+    static constexpr int HR = H % 16;            // leftover hidden units (VALU)
+    static_assert(HR <= 4, "leftover hidden units must fit lane group 0 of one k-group (n_hidden % 16 <= 4)");
+    static_assert(TM >= 1 && C >= 1 && C <= 3, "unsupported shape");
+    static constexpr int NEXT = C + 1;           // ext inputs: 1, x_0..x_{C-1}
+    // position (padded index) of: hidden unit u -> u;  ext input e -> lane group 1 + e/2, k-step e%2 of k-group TM
+    static constexpr int ext_pos(int e) { return HM + 4 * (1 + e / 2) + (e % 2); }
+    static constexpr int NRL = HR > 2 ? HR : 2;  // k-steps of the last forward k-group
+    static constexpr int KG = TM + 1;            // forward k-groups (= column tiles of the dW product)
+    static constexpr int nr_in(int tk) { return tk < TM ? 4 : NRL; }
+    static constexpr int nr_out(int tk) { return tk < TM ? 4 : HR; }
+    static constexpr int PT = 16 * KG;           // padded table length
+    static constexpr int S = stride_4mod8(HM + 10);   // weight image row stride
+    static constexpr int SA = stride_4mod8(HM + 4);   // stage A row stride: dz1[0..HM) | leftover dz1 (HR) | pad
+    static constexpr int SB = stride_4mod8(HM + 10);  // stage B row stride: z0ext positions
+    static constexpr int RPW = (TM + 3) / 4;     // row tiles of the dW product per wave
+
+    // ---- LDS carve (floats).  [0, IMG_FLOATS) is the parameter image, kept in HBM in exactly this layout. ----------
+    static constexpr int OFF_W = 0;                              // W1ext [H][S]: row o, columns = positions
+    static constexpr int OFF_WCT = OFF_W + H * S + 16;           // [HR][PT]: W1[:, HM+u] transposed (leftover inputs)
+    static constexpr int OFF_WIN = OFF_WCT + HR * PT;            // [C][PT]
+    static constexpr int OFF_BIN = OFF_WIN + C * PT;
+    static constexpr int OFF_FLOOR = OFF_BIN + PT;               // relu floor: 0 for hidden, -inf for ext inputs
+    static constexpr int OFF_WO = OFF_FLOOR + PT;
+    static constexpr int OFF_SC = OFF_WO + PT;                   // b_o, s_o[0..C-1]
+    static constexpr int IMG_FLOATS = OFF_SC + 8;
+    static_assert(IMG_FLOATS % 4 == 0, "image must be float4-copyable");
+    static constexpr int OFF_STA = IMG_FLOATS;
+    static constexpr int OFF_STB = OFF_STA + SP * SA + 16;
+    static constexpr int LDS_FLOATS = OFF_STB + SP * SB + 16;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
+
+    // ---- flat parameter offsets (L = 1), include/inrfit.h ---------------------------------------------------------
+    static constexpr int P_WIN = 0;
+    static constexpr int P_BIN = H * C;
+    static constexpr int P_W1 = P_BIN + H;
+    static constexpr int P_B1 = P_W1 + H * H;
+    static constexpr int P_S1 = P_B1 + H;
+    static constexpr int P_WO = P_S1 + H * C;
+    static constexpr int P_BO = P_WO + H;
+    static constexpr int P_SO = P_BO + 1;
+    static constexpr int P = P_SO + C;
+};
+
+// run-time description of the parameter image (same numbers as Cfg<H,C>) for the untemplated kernels
+struct ImgMap {
+    int H, C, HM, S, PT, floats;
+    int off_wct, off_win, off_bin, off_floor, off_wo, off_sc;
+    int ext[4];
+    int p_bin, p_w1, p_b1, p_s1, p_wo, p_bo, p_so, P;
+};
+
+// image offset of flat parameter j (every parameter has one primary slot)
+__device__ __forceinline__ int image_offset(const ImgMap& m, int j) {
+    if (j < m.p_bin) {  // input.weight [H][C]
+        const int i = j / m.C, c = j - i * m.C;
+        return m.off_win + c * m.PT + i;
+    }
+    if (j < m.p_w1) return m.off_bin + (j - m.p_bin);
+    if (j < m.p_b1) {  // skip.0.ln.weight [H][H]
+        const int q = j - m.p_w1;
+        const int o = q / m.H, i = q - o * m.H;
+        return o * m.S + i;
+    }
+    if (j < m.p_s1) return (j - m.p_b1) * m.S + m.ext[0];
+    if (j < m.p_wo) {  // skip.0.skp.weight [H][C]
+        const int q = j - m.p_s1;
+        const int o = q / m.C, c = q - o * m.C;
+        return o * m.S + m.ext[1 + c];
+    }
+    if (j < m.p_bo) return m.off_wo + (j - m.p_wo);
+    return m.off_sc + (j - m.p_bo);  // b_o, s_o[c]
+}
+// second slot: W1[o][HM+u] is mirrored into the transposed leftover-column table; -1 if none
+__device__ __forceinline__ int image_offset2(const ImgMap& m, int j) {
+    if (j >= m.p_w1 && j < m.p_b1) {
+        const int q = j - m.p_w1;
+        const int o = q / m.H, i = q - o * m.H;
+        if (i >= m.HM) return m.off_wct + (i - m.HM) * m.PT + o;
+    }
+    return -1;
+}
+
+struct StepArgs {
+    const float* wimg;     // [n_images][IMG_FLOATS] parameter images
+    const float* targets;  // [n_images][N]            (TRAIN)
+    const float* coef;     // [n_images][2] c_fg, c_bg (TRAIN)
+    float* slabs;          // [n_images][wgs][PS]      (TRAIN)
+    float* logits;         // [n_images][N] or null
+    InrGridDesc grid;
+    long long N;
+    int n_images, wgs, PS, loss_kind;
+};
+
+__device__ __forceinline__ float sum_over_points(float v) {  // the 16 lanes sharing lane>>4
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+__device__ __forceinline__ float sum_over_groups(float v) {  // the 4 lanes sharing lane&15
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+#ifndef INR_SCHED_HINTS
+#define INR_SCHED_HINTS 1
+#endif
+#if INR_SCHED_HINTS
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
+#else
+#define SGB(mask, n)
+#endif
+
+template <int H, int C, bool TRAIN>
+__global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs a) {
+    using G = Cfg<H, C>;
+    constexpr int TM = G::TM, KG = G::KG, HM = G::HM, HR = G::HR, S = G::S, PT = G::PT, RPW = G::RPW, NEXT = G::NEXT;
+    constexpr int HRA = HR > 0 ? HR : 1;  // array extent (zero-length arrays are not allowed)
+    static_assert(TM % RPW == 0, "row tiles must split evenly over the waves that own rows");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Wimg = smem + G::OFF_W;
+    float* const WcT = smem + G::OFF_WCT;
+    float* const WinT = smem + G::OFF_WIN;
+    float* const binT = smem + G::OFF_BIN;
+    float* const floorT = smem + G::OFF_FLOOR;
+    float* const woT = smem + G::OFF_WO;
+    float* const stA = smem + G::OFF_STA;
+    float* const stB = smem + G::OFF_STB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int img = blockIdx.x / a.wgs;
+    const int wg = blockIdx.x - img * a.wgs;
+    const long long N = a.N;
+
+    // ---- copy the parameter image into LDS (all loads in flight at once) ------------------------------------------
+    {
+        const f32x4* __restrict__ src = (const f32x4*)(a.wimg + (size_t)img * G::IMG_FLOATS);
+        constexpr int NV4 = G::IMG_FLOATS / 4;
+        constexpr int NIT = (NV4 + WG_THREADS - 1) / WG_THREADS;
+        f32x4 tmp[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = tid + k * WG_THREADS;
+            if (i < NV4) tmp[k] = src[i];
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = tid + k * WG_THREADS;
+            if (i < NV4) ((f32x4*)smem)[i] = tmp[k];
+        }
+    }
+    float cfg_ = 0.f, cbg_ = 0.f;
+    if (TRAIN) {
+        cfg_ = a.coef[2 * img];
+        cbg_ = a.coef[2 * img + 1];
+    }
+    __syncthreads();
+    const float b_o = smem[G::OFF_SC];
+    float s_o[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) s_o[c] = smem[G::OFF_SC + 1 + c];
+    float wol[HRA];  // w_o of the leftover units
+#pragma unroll
+    for (int u = 0; u < HRA; ++u) wol[u] = HR > 0 ? woT[HM + u] : 0.f;
+
+    // per-lane LDS addresses
+    const float* const wf = Wimg + l15 * S + 4 * g;  // forward A operand: row 16t + l15, columns 16tk + 4g ..+3
+    const float* const wb = Wimg + l15;              // backward A operand: row o, column 16t + l15
+    const bool row_ok = wave * RPW < TM;             // this wave owns row tiles of the dW product
+    const int arow = 16 * wave * RPW + l15;          // first dW row tile of this wave (+ lane column)
+
+    // persistent gradient accumulators (TRAIN)
+    f32x4 dW[RPW][KG];     // dW1ext tiles: rows 16*(wave*RPW+j).., columns 16*b..             (MFMA)
+    f32x4 dL0[RPW];        // layer-0 gradient tiles: same rows, columns = ext slots of k-group TM (MFMA)
+    f32x4 dwo[TM];         // dw_o partial sums over this lane's points                          (VALU)
+    float dwol[HRA];       // ... leftover units (lane group 0 only)
+    float dWl[HRA][KG];    // leftover rows of dW1ext: column 16b + l15, partial over this lane group's points
+    float dL0l[HRA][NEXT]; // leftover rows of the layer-0 gradient (lane group 0 only)
+    float loss_acc = 0.f, dbo = 0.f, dso[C];
+    if (TRAIN) {
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            dL0[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < KG; ++b) dW[j][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int t = 0; t < TM; ++t) dwo[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < HRA; ++u) {
+            dwol[u] = 0.f;
+#pragma unroll
+            for (int b = 0; b < KG; ++b) dWl[u][b] = 0.f;
+#pragma unroll
+            for (int e = 0; e < NEXT; ++e) dL0l[u][e] = 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) dso[c] = 0.f;
+    }
+
+    const long long n_chunks = (N + SP - 1) / SP;
+    for (long long chunk = wg; chunk < n_chunks; chunk += a.wgs) {
+        // ---- coordinates (and target) of this lane's point ---------------------------------------------------
+        const long long p = chunk * SP + wave * 16 + l15;
+        const bool valid = p < N;
+        const long long pc = valid ? p : N - 1;
+        float x[C];
+        if (a.grid.mode == INR_GRID_SEPARABLE) {
+            const int row = (int)(pc / a.grid.width);
+            const int col = (int)(pc - (long long)row * a.grid.width);
+            x[0] = a.grid.xs[col];
+            x[1] = a.grid.ys[row];
+            if (C > 2) x[C - 1] = a.grid.ts ? a.grid.ts[img] : 0.f;
+        } else {
+            const float* cp = a.grid.coords + (size_t)img * a.grid.coords_image_stride;
+#pragma unroll
+            for (int c = 0; c < C; ++c) x[c] = cp[(size_t)c * N + pc];
+        }
+        float tg = 0.f;
+        if (TRAIN) tg = a.targets[(size_t)img * N + pc];
+
+        // layer 0 (VALU), one k-group at a time: z0[pos] = max(W_in[pos].x + b_in[pos], floor[pos]), B-operand layout
+        f32x4 z0[KG];
+        auto z0_tile = [&](int tk) -> f32x4 {
+            const int q = 16 * tk + 4 * g;
+            f32x4 v = *(const f32x4*)&binT[q];
+#pragma unroll
+            for (int c = 0; c < C; ++c) v += *(const f32x4*)&WinT[c * PT + q] * x[c];
+            const f32x4 fl = *(const f32x4*)&floorT[q];
+            f32x4 z;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[r] = fmaxf(v[r], fl[r]);
+            return z;
+        };
+
+        // ---- layer 1 (MFMA, software pipelined): acc[t] = W1ext . z0ext ----------------------------------------
+        f32x4 acc[TM];
+        float la[HRA];  // leftover units' pre-activation, partial over this lane group's positions
+#pragma unroll
+        for (int t = 0; t < TM; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < HRA; ++u) la[u] = 0.f;
+        f32x4 wq[2][TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) wq[0][t] = *(const f32x4*)(wf + t * 16 * S);
+        z0[0] = z0_tile(0);
+#pragma unroll
+        for (int tk = 0; tk < KG; ++tk) {
+            if (tk + 1 < KG) {
+#pragma unroll
+                for (int t = 0; t < TM; ++t) wq[(tk + 1) & 1][t] = *(const f32x4*)(wf + t * 16 * S + 16 * (tk + 1));
+                z0[tk + 1] = z0_tile(tk + 1);
+            }
+#pragma unroll
+            for (int u = 0; u < HR; ++u) {
+                const f32x4 wl = *(const f32x4*)(Wimg + (HM + u) * S + 16 * tk + 4 * g);
+#pragma unroll
+                for (int r = 0; r < G::nr_in(tk); ++r) la[u] = fmaf(wl[r], z0[tk][r], la[u]);
+            }
+#pragma unroll
+            for (int r = 0; r < G::nr_in(tk); ++r)
+#pragma unroll
+                for (int t = 0; t < TM; ++t) acc[t] = MFMA16(wq[tk & 1][t][r], z0[tk][r], acc[t]);
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                SGB(SG_DS_READ, 2);
+                SGB(SG_VALU, 3);
+                SGB(SG_MFMA, 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- output layer, sigmoid, data term ------------------------------------------------------------------
+        float ypart = 0.f;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const f32x4 wo = *(const f32x4*)&woT[16 * t + 4 * g];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[t][r] = fmaxf(acc[t][r], 0.f);  // z1
+                ypart = fmaf(wo[r], acc[t][r], ypart);
+            }
+        }
+        ypart = sum_over_groups(ypart);
+        float z1l[HRA];
+#pragma unroll
+        for (int u = 0; u < HR; ++u) {
+            z1l[u] = fmaxf(sum_over_groups(la[u]), 0.f);
+            ypart = fmaf(wol[u], z1l[u], ypart);
+        }
+        float y = ypart + b_o;
+#pragma unroll
+        for (int c = 0; c < C; ++c) y = fmaf(s_o[c], x[c], y);
+        if (a.logits != nullptr && valid && g == 0) a.logits[(size_t)img * N + p] = y;
+
+        if (TRAIN) {
+            const float pr = 1.f / (1.f + expf(-y));
+            const float cw = tg < 0.5f ? cfg_ : cbg_;
+            float l, dy;
+            if (a.loss_kind == INR_LOSS_SE) {
+                const float d = tg - pr;
+                l = d * d * cw;
+                dy = 2.f * (pr - tg) * pr * (1.f - pr) * cw;
+            } else if (a.loss_kind == INR_LOSS_EXTERNAL) {
+                l = 0.f;
+                dy = tg;  // `targets` carries dL/dlogit
+            } else {
+                const float lp = fmaxf(logf(pr), -100.f), lq = fmaxf(logf(1.f - pr), -100.f);
+                l = -(tg * lp + (1.f - tg) * lq) * cw;
+                const float pq = pr * (1.f - pr);
+                dy = (pr - tg) / fmaxf(pq, 1e-12f) * pq * cw;
+            }
+            if (!valid) {
+                l = 0.f;
+                dy = 0.f;
+            }
+            float dzl[HRA];  // dz1 of the leftover units (same value in all 4 lane groups)
+#pragma unroll
+            for (int u = 0; u < HRA; ++u) dzl[u] = 0.f;
+#pragma unroll
+            for (int u = 0; u < HR; ++u) dzl[u] = z1l[u] > 0.f ? dy * wol[u] : 0.f;
+            if (g == 0) {
+                loss_acc += l;
+                dbo += dy;
+#pragma unroll
+                for (int c = 0; c < C; ++c) dso[c] = fmaf(dy, x[c], dso[c]);
+#pragma unroll
+                for (int u = 0; u < HR; ++u) dwol[u] = fmaf(dy, z1l[u], dwol[u]);
+            }
+            const int pl = wave * 16 + l15;  // this lane's row in the stages
+            float* const sa = stA + pl * G::SA + 4 * g;
+            float* const sb = stB + pl * G::SB + 4 * g;
+            // dz1 of tile t (in place over acc), dw_o accumulation, staging of dz1 (A) and z0ext (B)
+            auto dz1_tile = [&](int t) {
+                const f32x4 wo = *(const f32x4*)&woT[16 * t + 4 * g];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z1 = acc[t][r];
+                    dwo[t][r] = fmaf(dy, z1, dwo[t][r]);
+                    acc[t][r] = z1 > 0.f ? dy * wo[r] : 0.f;
+                }
+                *(f32x4*)(sa + 16 * t) = acc[t];
+                *(f32x4*)(sb + 16 * t) = z0[t];
+            };
+            if (HR > 0 && g == 0) {
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < HR; ++u) v[u] = dzl[u];
+                *(f32x4*)(sa + HM) = v;
+            }
+            if (g < 3) *(f32x4*)(sb + HM) = z0[TM];
+
+            // ---- backward through layer 1 (MFMA, pipelined): dz0[t] = W1^T . dz1 ---------------------------------
+            f32x4 dz0[TM];
+            float dz0l[HRA];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) dz0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < HRA; ++u) dz0l[u] = 0.f;
+            constexpr int KS = 4 * TM + HR;  // k-steps over the hidden outputs
+            float bq[2][TM];
+            auto b_row = [&](int ks) -> const float* {  // LDS row of the A operand for k-step ks
+                const int tk = ks >> 2, r = ks & 3;
+                if (tk < TM) return wb + (16 * tk + 4 * g + r) * S;
+                return wb + (g == 0 ? (HM + r) * S : 0);  // leftover outputs live in lane group 0 (others: B = 0)
+            };
+            dz1_tile(0);
+            {
+                const float* br = b_row(0);
+#pragma unroll
+                for (int t = 0; t < TM; ++t) bq[0][t] = br[16 * t];
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int tk = ks >> 2, r = ks & 3;
+                if (ks + 1 < KS) {
+                    const float* br = b_row(ks + 1);
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) bq[(ks + 1) & 1][t] = br[16 * t];
+                }
+                if (r == 0 && tk + 1 < TM) dz1_tile(tk + 1);  // next tile's dz1, in the shadow of this tile's MFMAs
+                const float bop = tk < TM ? acc[tk < TM ? tk : 0][r] : (g == 0 ? dzl[r < HRA ? r : 0] : 0.f);
+                if (r == 0) {  // leftover hidden inputs: dz0l[u] += W1[:, HM+u] . dz1 over this lane's positions
+#pragma unroll
+                    for (int u = 0; u < HR; ++u) {
+                        const f32x4 wc = *(const f32x4*)(WcT + u * PT + 16 * tk + 4 * g);
+                        if (tk < TM) {
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) dz0l[u] = fmaf(wc[rr], acc[tk < TM ? tk : 0][rr], dz0l[u]);
+                        } else if (g == 0) {
+#pragma unroll
+                            for (int rr = 0; rr < HR; ++rr) dz0l[u] = fmaf(wc[rr], dzl[rr], dz0l[u]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < TM; ++t) dz0[t] = MFMA16(bq[ks & 1][t], bop, dz0[t]);
+#pragma unroll
+                for (int t = 0; t < TM; ++t) {
+                    SGB(SG_DS_READ, 1);
+                    SGB(SG_VALU, 2);
+                    SGB(SG_MFMA, 1);
+                }
+                if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            // relu mask of layer 0; leftover rows of the layer-0 gradient (lane group 0, VALU)
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dz0[t][r] = z0[t][r] > 0.f ? dz0[t][r] : 0.f;
+#pragma unroll
+            for (int u = 0; u < HR; ++u) {
+                const float d = sum_over_groups(dz0l[u]);
+                if (g == 0) {
+                    const float dm = z0[TM][u] > 0.f ? d : 0.f;  // position HM + u lives in lane group 0, k-step u
+                    dL0l[u][0] += dm;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) dL0l[u][1 + c] = fmaf(dm, x[c], dL0l[u][1 + c]);
+                }
+            }
+            __syncthreads();
+
+            // ---- dW1ext += dZ1^T Z0ext over the 64 staged points (MFMA, pipelined); leftover rows on the VALU ------
+            {
+                auto stage_pt = [&](int it) { const int s = (it + wave) & 15; return 16 * (s >> 2) + (s & 3) + 4 * g; };
+                float af[2][RPW], bf[2][KG];
+                {
+                    const int pt = stage_pt(0);
+#pragma unroll
+                    for (int j = 0; j < RPW; ++j) af[0][j] = stA[pt * G::SA + arow + 16 * j];
+#pragma unroll
+                    for (int b = 0; b < KG; ++b) bf[0][b] = stB[pt * G::SB + 16 * b + l15];
+                }
+#pragma unroll
+                for (int it = 0; it < SP / 4; ++it) {
+                    const int ptc = stage_pt(it);
+                    if (it + 1 < SP / 4) {
+                        const int pt = stage_pt(it + 1);
+#pragma unroll
+                        for (int j = 0; j < RPW; ++j) af[(it + 1) & 1][j] = stA[pt * G::SA + arow + 16 * j];
+#pragma unroll
+                        for (int b = 0; b < KG; ++b) bf[(it + 1) & 1][b] = stB[pt * G::SB + 16 * b + l15];
+                    }
+                    if (HR > 0 && (it & 3) == 0) {  // every wave takes a quarter of the k-steps for the leftover rows
+                        const f32x4 dl = *(const f32x4*)(stA + ptc * G::SA + HM);
+#pragma unroll
+                        for (int u = 0; u < HR; ++u)
+#pragma unroll
+                            for (int b = 0; b < KG; ++b) dWl[u][b] = fmaf(dl[u], bf[it & 1][b], dWl[u][b]);
+                    }
+                    if (row_ok) {
+#pragma unroll
+                        for (int j = 0; j < RPW; ++j)
+#pragma unroll
+                            for (int b = 0; b < KG; ++b) dW[j][b] = MFMA16(af[it & 1][j], bf[it & 1][b], dW[j][b]);
+                    }
+#pragma unroll
+                    for (int b = 0; b < KG; ++b) {
+                        SGB(SG_DS_READ, 2);
+                        SGB(SG_VALU, 2);
+                        SGB(SG_MFMA, RPW);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();
+            // ---- layer-0 gradients: restage dz0 over dz1, multiply with the ext columns of stage B ------------------
+#pragma unroll
+            for (int t = 0; t < TM; ++t) *(f32x4*)(sa + 16 * t) = dz0[t];
+            __syncthreads();
+            if (row_ok) {
+#pragma unroll
+                for (int it = 0; it < SP / 4; ++it) {
+                    const int pt = 16 * (it >> 2) + (it & 3) + 4 * g;
+                    const float bfe = stB[pt * G::SB + HM + l15];
+#pragma unroll
+                    for (int j = 0; j < RPW; ++j) dL0[j] = MFMA16(stA[pt * G::SA + arow + 16 * j], bfe, dL0[j]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    if (TRAIN) {
+        float* __restrict__ slab = a.slabs + ((size_t)img * a.wgs + wg) * a.PS;
+        // ---- dW1ext / layer-0 tiles of this wave ---------------------------------------------------------------------
+        if (row_ok) {
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                const int o0 = 16 * (wave * RPW + j) + 4 * g;  // first of this lane's 4 rows
+#pragma unroll
+                for (int b = 0; b < KG; ++b) {
+                    const int pos = 16 * b + l15;
+                    int off = -1, rs = 0;
+                    if (pos < H) {
+                        off = G::P_W1 + pos;
+                        rs = H;
+                    } else if (pos == G::ext_pos(0)) {
+                        off = G::P_B1;
+                        rs = 1;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < C; ++c)
+                            if (pos == G::ext_pos(1 + c)) {
+                                off = G::P_S1 + c;
+                                rs = C;
+                            }
+                    }
+                    if (off >= 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) slab[off + (o0 + r) * rs] = dW[j][b][r];
+                    }
+                }
+                {
+                    const int pos = HM + l15;
+                    int off = -1, rs = 0;
+                    if (pos == G::ext_pos(0)) {
+                        off = G::P_BIN;
+                        rs = 1;
+                    }
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        if (pos == G::ext_pos(1 + c)) {
+                            off = G::P_WIN + c;
+                            rs = C;
+                        }
+                    if (off >= 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) slab[off + (o0 + r) * rs] = dL0[j][r];
+                    }
+                }
+            }
+        }
+        // ---- everything that was summed per lane: reduce within the wave, then over the waves through LDS -------------
+        constexpr int SC_DWO = 0;                    // [PT]            dw_o by position
+        constexpr int SC_DWL = SC_DWO + PT;          // [HRA][PT]       leftover rows of dW1ext by column position
+        constexpr int SC_L0L = SC_DWL + HRA * PT;    // [HRA][4]        leftover rows of the layer-0 gradient
+        constexpr int SC_SC = SC_L0L + HRA * 4;      // [8]             loss, db_o, ds_o
+        constexpr int WSTR = SC_SC + 8;
+        static_assert(4 * WSTR <= SP * G::SA, "reduction scratch must fit stage A");
+        float* const scr = stA + wave * WSTR;
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = sum_over_points(dwo[t][r]);
+                if (l15 == 0) scr[SC_DWO + 16 * t + 4 * g + r] = v;
+            }
+#pragma unroll
+        for (int u = 0; u < HR; ++u) {
+            const float v = sum_over_points(dwol[u]);  // lane group 0 only
+            if (lane == 0) scr[SC_DWO + HM + u] = v;
+#pragma unroll
+            for (int b = 0; b < KG; ++b) {
+                const float w = sum_over_groups(dWl[u][b]);
+                if (g == 0) scr[SC_DWL + u * PT + 16 * b + l15] = w;
+            }
+#pragma unroll
+            for (int e = 0; e < NEXT; ++e) {
+                const float w = sum_over_points(dL0l[u][e]);  // lane group 0 only
+                if (lane == 0) scr[SC_L0L + u * 4 + e] = w;
+            }
+        }
+        {
+            float sc[2 + C];
+            sc[0] = loss_acc;
+            sc[1] = dbo;
+#pragma unroll
+            for (int c = 0; c < C; ++c) sc[2 + c] = dso[c];
+#pragma unroll
+            for (int k = 0; k < 2 + C; ++k) {
+                const float v = sum_over_points(sc[k]);  // lane group 0 only
+                if (lane == 0) scr[SC_SC + k] = v;
+            }
+        }
+        __syncthreads();
+        auto wsum = [&](int i) { return ((stA[i] + stA[WSTR + i]) + stA[2 * WSTR + i]) + stA[3 * WSTR + i]; };
+        for (int i = tid; i < H; i += WG_THREADS) slab[G::P_WO + i] = wsum(SC_DWO + i);
+        for (int i = tid; i < HR * PT; i += WG_THREADS) {
+            const int u = i / PT, pos = i - u * PT;
+            const float v = wsum(SC_DWL + i);
+            if (pos < H) slab[G::P_W1 + (HM + u) * H + pos] = v;
+            else if (pos == G::ext_pos(0)) slab[G::P_B1 + HM + u] = v;
+            else {
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (pos == G::ext_pos(1 + c)) slab[G::P_S1 + (HM + u) * C + c] = v;
+            }
+        }
+        if (tid < HR * NEXT) {
+            const int u = tid / NEXT, e = tid - u * NEXT;
+            const float v = wsum(SC_L0L + u * 4 + e);
+            if (e == 0) slab[G::P_BIN + HM + u] = v;
+            else slab[G::P_WIN + (HM + u) * C + (e - 1)] = v;
+        }
+        if (tid < 2 + C) {
+            const float v = wsum(SC_SC + tid);
+            if (tid == 0) slab[G::P] = v;  // loss partial
+            else if (tid == 1) slab[G::P_BO] = v;
+            else slab[G::P_SO + tid - 2] = v;
+        }
+    }
+}
+
+}  // namespace

@@ -20,558 +20,9 @@
 //   * dW1 = dZ1^T Z0ext contracts over points: the two operands are staged once through LDS (point-major rows,
 //     float4 writes, conflict-free strides), the 9x9 output tiles are split over the 4 waves;
 //   * fp32 everywhere (exact-f32 MFMA == fmaf chain), fixed-order reductions, no atomics: results are reproducible.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <math.h>
-
-#include "inrfit.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#include "icnn_step.h"
 
 namespace {
-
-constexpr int WG_THREADS = 256;
-constexpr int SP = 64;  // points staged per chunk (4 waves x 16)
-
-constexpr int round_up(int v, int m) { return (v + m - 1) / m * m; }
-// smallest s >= v with s % 8 == 4 (LDS strides: float4-aligned rows whose 4-row step lands 16 banks away)
-constexpr int stride_4mod8(int v) {
-    int s = round_up(v, 4);
-    while (s % 8 != 4) s += 4;
-    return s;
-}
-
-// Static geometry of the ICNN(h, C) kernel.  "Position" = padded index of a hidden unit or ext input inside the
-// 16-row MFMA tiles: hidden unit u sits at position u; the ext inputs (1, x_0..x_{C-1}) sit in free slots.
-// A k-step of the 16x16x4 MFMA is (tile tk, r): lane group g = lane>>4 supplies position 16*tk + 4*g + r.
-template <int H, int C>
-struct Cfg {
-    static constexpr int TL = H / 16;                       // full hidden tiles
-    static constexpr int REM = H % 16;                      // hidden units in the partial tile
-    static constexpr int MT = (H + 15) / 16;                // tiles over hidden units (M of forward, K of backward)
-    static constexpr int NEXT = C + 1;                      // ext inputs: 1, x_0..x_{C-1}
-    static constexpr int R_HID = REM == 0 ? 0 : (REM < 4 ? REM : 4);  // k-steps the partial tile needs for hidden units
-
-    // position of ext input e
-    static constexpr int ext_pos(int e) {
-        int n = 0;
-        if (REM > 0) {
-            // free slots of the partial tile inside the k-steps the hidden units already use: g ascending, r ascending
-            for (int g = 0; g < 4; ++g)
-                for (int r = 0; r < R_HID; ++r)
-                    if (4 * g + r >= REM) {
-                        if (n == e) return 16 * TL + 4 * g + r;
-                        ++n;
-                    }
-            // then new k-steps of the partial tile
-            for (int r = R_HID; r < 4; ++r)
-                for (int g = 0; g < 4; ++g)
-                    if (4 * g + r >= REM) {
-                        if (n == e) return 16 * TL + 4 * g + r;
-                        ++n;
-                    }
-            return -1;
-        }
-        // hidden tiles are full: open a new tile, fill k-step r = 0 first
-        return 16 * MT + 4 * (e % 4) + e / 4;
-    }
-    static constexpr int pos_max() {
-        int m = H - 1;
-        for (int e = 0; e < NEXT; ++e) m = ext_pos(e) > m ? ext_pos(e) : m;
-        return m;
-    }
-    static constexpr int POS_MAX = pos_max();
-    static_assert(ext_pos(NEXT - 1) >= 0, "no slot for the ext inputs: unsupported n_hidden % 16");
-    static constexpr int MTB = POS_MAX / 16 + 1;            // tiles over positions (K of forward, N of the dW product)
-    static constexpr int PT = MTB * 16;                     // padded table length
-    // valid k-steps (r = 0..nr-1) of k-group tk
-    static constexpr int nr_in(int tk) {                    // forward: hidden + ext inputs
-        int nr = 0;
-        for (int g = 0; g < 4; ++g)
-            for (int r = 0; r < 4; ++r) {
-                const int pos = 16 * tk + 4 * g + r;
-                bool used = pos < H;
-                for (int e = 0; e < NEXT; ++e) used = used || pos == ext_pos(e);
-                if (used && r + 1 > nr) nr = r + 1;
-            }
-        return nr;
-    }
-    static constexpr int nr_out(int tk) {                   // backward: hidden outputs only
-        return tk < TL ? 4 : R_HID;
-    }
-    static constexpr int S = stride_4mod8(POS_MAX + 1);     // weight image row stride (floats)
-    static constexpr int SA = stride_4mod8(16 * TL + round_up(REM, 4));  // stage A (dz1) row stride
-    static constexpr int SB = stride_4mod8(POS_MAX + 1);    // stage B (z0ext) row stride
-    static constexpr int A_G_MAX = REM == 0 ? 4 : (REM + 3) / 4;         // lane groups that write tile TL of stage A
-    static constexpr int B_G_MAX = (POS_MAX % 16) / 4 + 1;               // lane groups that write the last tile of stage B
-
-    // LDS carve (floats).  [0, IMG_FLOATS) is the "parameter image": it is kept in global memory in exactly this
-    // layout (written by pack_image_kernel / icnn_update_kernel) and copied verbatim at kernel start.
-    static constexpr int OFF_W = 0;                           // W1ext [H+1][S] (+16 zero floats: tail reads of the zero row)
-    static constexpr int OFF_WIN = OFF_W + (H + 1) * S + 16;  // [C][PT]
-    static constexpr int OFF_BIN = OFF_WIN + C * PT;
-    static constexpr int OFF_FLOOR = OFF_BIN + PT;
-    static constexpr int OFF_WO = OFF_FLOOR + PT;
-    static constexpr int OFF_SC = OFF_WO + PT;                // scalars: b_o, s_o[0..C-1]
-    static constexpr int IMG_FLOATS = OFF_SC + 8;
-    static_assert(IMG_FLOATS % 4 == 0, "image must be float4-copyable");
-    static constexpr int OFF_STA = IMG_FLOATS;
-    static constexpr int OFF_STB = OFF_STA + SP * SA + 16;
-    static constexpr int LDS_FLOATS = OFF_STB + SP * SB + 16;
-    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
-
-    // flat parameter offsets (L = 1), include/inrfit.h
-    static constexpr int P_WIN = 0;
-    static constexpr int P_BIN = H * C;
-    static constexpr int P_W1 = P_BIN + H;
-    static constexpr int P_B1 = P_W1 + H * H;
-    static constexpr int P_S1 = P_B1 + H;
-    static constexpr int P_WO = P_S1 + H * C;
-    static constexpr int P_BO = P_WO + H;
-    static constexpr int P_SO = P_BO + 1;
-    static constexpr int P = P_SO + C;
-
-    // dW product: MT x MTB output tiles, contiguous runs of the row-major enumeration per wave
-    static constexpr int NTILES = MT * MTB;
-    static constexpr int TPW = (NTILES + 3) / 4;
-    static constexpr int tile_begin(int w) { return w * TPW < NTILES ? w * TPW : NTILES; }
-    static constexpr int tile_end(int w) { return (w + 1) * TPW < NTILES ? (w + 1) * TPW : NTILES; }
-};
-
-// run-time description of the parameter image (same numbers as Cfg<H,C>), for the kernels that are not templated
-struct ImgMap {
-    int H, C, S, PT, floats;
-    int off_win, off_bin, off_floor, off_wo, off_sc;
-    int ext[4];
-    int p_bin, p_w1, p_b1, p_s1, p_wo, p_bo, p_so, P;
-};
-
-// image offset of flat parameter j
-__device__ __forceinline__ int image_offset(const ImgMap& m, int j) {
-    if (j < m.p_bin) {                       // input.weight [H][C]
-        const int i = j / m.C, c = j - i * m.C;
-        return m.off_win + c * m.PT + i;
-    }
-    if (j < m.p_w1) return m.off_bin + (j - m.p_bin);
-    if (j < m.p_b1) {                        // skip.0.ln.weight [H][H]
-        const int q = j - m.p_w1;
-        const int o = q / m.H, i = q - o * m.H;
-        return o * m.S + i;
-    }
-    if (j < m.p_s1) return (j - m.p_b1) * m.S + m.ext[0];
-    if (j < m.p_wo) {                        // skip.0.skp.weight [H][C]
-        const int q = j - m.p_s1;
-        const int o = q / m.C, c = q - o * m.C;
-        return o * m.S + m.ext[1 + c];
-    }
-    if (j < m.p_bo) return m.off_wo + (j - m.p_wo);
-    return m.off_sc + (j - m.p_bo);          // b_o, s_o[c]
-}
-
-struct StepArgs {
-    const float* wimg;     // [n_images][IMG_FLOATS] parameter images
-    const float* targets;  // [n_images][N]            (TRAIN)
-    const float* coef;     // [n_images][2] c_fg, c_bg (TRAIN)
-    float* slabs;          // [n_images][wgs][PS]      (TRAIN)
-    float* logits;         // [n_images][N] or null
-    InrGridDesc grid;
-    long long N;
-    int n_images, wgs, PS, loss_kind;
-};
-
-__device__ __forceinline__ float wave16_sum(float v) {  // sum over the 16 lanes that share lane>>4
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    return v;
-}
-
-template <int H, int C, int WAVE>
-struct DwPhase {
-    using G = Cfg<H, C>;
-    static constexpr int T0 = G::tile_begin(WAVE), T1 = G::tile_end(WAVE);
-    static constexpr int A0 = T0 / G::MTB, A1 = T1 > T0 ? (T1 - 1) / G::MTB : A0;  // row tiles touched
-    static constexpr bool b_used(int b) {
-        for (int t = T0; t < T1; ++t)
-            if (t % G::MTB == b) return true;
-        return false;
-    }
-
-    // dW[k] += sum over the 64 staged points of A-tile(a_k)^T . B-tile(b_k)
-    static __device__ __forceinline__ void run(f32x4 (&dW)[G::TPW], const float* __restrict__ stA,
-                                               const float* __restrict__ stB, int l15, int g) {
-        for (int s = 0; s < SP / 4; ++s) {
-            // k-step s: lane group g supplies staged point 16*(s/4) + (s%4) + 4*g
-            const int pt = 16 * (s >> 2) + (s & 3) + 4 * g;
-            const float* pa = stA + pt * G::SA + l15;
-            const float* pb = stB + pt * G::SB + l15;
-            float af[A1 - A0 + 1];
-            float bf[G::MTB];
-#pragma unroll
-            for (int a = A0; a <= A1; ++a) af[a - A0] = pa[16 * a];
-#pragma unroll
-            for (int b = 0; b < G::MTB; ++b)
-                if (b_used(b)) bf[b] = pb[16 * b];
-#pragma unroll
-            for (int t = T0; t < T1; ++t) dW[t - T0] = MFMA16(af[t / G::MTB - A0], bf[t % G::MTB], dW[t - T0]);
-        }
-    }
-
-    // layer-0 gradients: dL0[k] += sum over the staged points of dz0-tile(a)^T . z0ext-tile(b_ext), a = WAVE + 4k.
-    // Column ext_pos(0) of the result is db_in, columns ext_pos(1+c) are dW_in[:, c].
-    static constexpr int BE = G::ext_pos(0) / 16;
-    static constexpr int NL0 = (G::MT - WAVE + 3) / 4;  // row tiles a = WAVE, WAVE+4, ... < MT
-    static __device__ __forceinline__ void run_l0(f32x4 (&dL0)[3], const float* __restrict__ stA,
-                                                  const float* __restrict__ stB, int l15, int g) {
-        for (int s = 0; s < SP / 4; ++s) {
-            const int pt = 16 * (s >> 2) + (s & 3) + 4 * g;
-            const float* pa = stA + pt * G::SA + l15;
-            const float bfr = stB[pt * G::SB + 16 * BE + l15];
-#pragma unroll
-            for (int k = 0; k < NL0; ++k) dL0[k] = MFMA16(pa[16 * (WAVE + 4 * k)], bfr, dL0[k]);
-        }
-    }
-    static __device__ __forceinline__ void store_l0(const f32x4 (&dL0)[3], float* __restrict__ slab, int l15, int g) {
-        const int pos = 16 * BE + l15;
-        int off = -1, rs = 0;
-        if (pos == G::ext_pos(0)) {
-            off = G::P_BIN;
-            rs = 1;
-        }
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-            if (pos == G::ext_pos(1 + c)) {
-                off = G::P_WIN + c;
-                rs = C;
-            }
-#pragma unroll
-        for (int k = 0; k < NL0; ++k)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * (WAVE + 4 * k) + 4 * g + r;
-                if (off >= 0 && i < H) slab[off + i * rs] = dL0[k][r];
-            }
-    }
-
-    // write this wave's dW tiles into the gradient slab (flat parameter order)
-    static __device__ __forceinline__ void store(const f32x4 (&dW)[G::TPW], float* __restrict__ slab, int l15, int g) {
-#pragma unroll
-        for (int t = T0; t < T1; ++t) {
-            const int a = t / G::MTB, b = t % G::MTB;
-            const int pos = 16 * b + l15;  // input position (column)
-            int col_off = -1;              // offset of (row o = 0) for this column, stride per row in `rs`
-            int rs = 0;
-            if (pos < H) {
-                col_off = G::P_W1 + pos;
-                rs = H;
-            } else if (pos == G::ext_pos(0)) {
-                col_off = G::P_B1;
-                rs = 1;
-            } else {
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-                    if (pos == G::ext_pos(1 + c)) {
-                        col_off = G::P_S1 + c;
-                        rs = C;
-                    }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = 16 * a + 4 * g + r;
-                if (col_off >= 0 && o < H) slab[col_off + o * rs] = dW[t - T0][r];
-            }
-        }
-    }
-};
-
-template <int H, int C, bool TRAIN>
-__global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs a) {
-    using G = Cfg<H, C>;
-    constexpr int MT = G::MT, MTB = G::MTB, S = G::S, PT = G::PT;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const Wimg = smem + G::OFF_W;
-    float* const stA = smem + G::OFF_STA;
-    float* const stB = smem + G::OFF_STB;
-    float* const WinT = smem + G::OFF_WIN;
-    float* const binT = smem + G::OFF_BIN;
-    float* const floorT = smem + G::OFF_FLOOR;
-    float* const woT = smem + G::OFF_WO;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, g = lane >> 4;
-    const int img = blockIdx.x / a.wgs;
-    const int wg = blockIdx.x - img * a.wgs;
-    const long long N = a.N;
-
-    // ---- copy the parameter image into LDS (all loads in flight at once) ------------------------------------------
-    {
-        const f32x4* __restrict__ src = (const f32x4*)(a.wimg + (size_t)img * G::IMG_FLOATS);
-        constexpr int NV4 = G::IMG_FLOATS / 4;
-        constexpr int NIT = (NV4 + WG_THREADS - 1) / WG_THREADS;
-        f32x4 tmp[NIT];
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int i = tid + k * WG_THREADS;
-            if (i < NV4) tmp[k] = src[i];
-        }
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int i = tid + k * WG_THREADS;
-            if (i < NV4) ((f32x4*)smem)[i] = tmp[k];
-        }
-    }
-    float cfg_ = 0.f, cbg_ = 0.f;
-    if (TRAIN) {
-        cfg_ = a.coef[2 * img];
-        cbg_ = a.coef[2 * img + 1];
-    }
-    __syncthreads();
-    const float b_o = smem[G::OFF_SC];
-    float s_o[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) s_o[c] = smem[G::OFF_SC + 1 + c];
-
-    // per-lane LDS row offsets of the weight image: forward reads row (16t + l15), clamped to the zero row H
-    int frow[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        const int o = 16 * t + l15;
-        frow[t] = (o < H ? o : H) * S + 4 * g;
-    }
-
-    // persistent per-lane gradient accumulators (TRAIN)
-    f32x4 dW[G::TPW];   // this wave's tiles of dW1ext (MFMA accumulators)
-    f32x4 dL0[3];       // this wave's tiles of the layer-0 gradient product
-    f32x4 dwo[MT];      // dw_o partial sums of this lane's points (VALU)
-    float loss_acc = 0.f, dbo = 0.f, dso[C];
-    if (TRAIN) {
-#pragma unroll
-        for (int k = 0; k < G::TPW; ++k) dW[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) dL0[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < MT; ++t) dwo[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < C; ++c) dso[c] = 0.f;
-    }
-
-    const long long n_chunks = (N + SP - 1) / SP;
-    for (long long chunk = wg; chunk < n_chunks; chunk += a.wgs) {
-        // ---- coordinates of this lane's point ---------------------------------------------------------------
-        const long long p = chunk * SP + wave * 16 + l15;
-        const bool valid = p < N;
-        const long long pc = valid ? p : N - 1;
-        float x[C];
-        if (a.grid.mode == INR_GRID_SEPARABLE) {
-            const int row = (int)(pc / a.grid.width);
-            const int col = (int)(pc - (long long)row * a.grid.width);
-            x[0] = a.grid.xs[col];
-            x[1] = a.grid.ys[row];
-            if (C > 2) x[C - 1] = a.grid.ts ? a.grid.ts[img] : 0.f;
-        } else {
-            const float* cp = a.grid.coords + (size_t)img * a.grid.coords_image_stride;
-#pragma unroll
-            for (int c = 0; c < C; ++c) x[c] = cp[(size_t)c * N + pc];
-        }
-
-        // ---- layer 0 (VALU): z0[pos] = max(W_in[pos].x + b_in[pos], floor[pos]) in B-operand layout ----------
-        f32x4 z0[MTB];
-#pragma unroll
-        for (int t = 0; t < MTB; ++t) {
-            const int q = 16 * t + 4 * g;
-            f32x4 v = *(const f32x4*)&binT[q];
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const f32x4 w = *(const f32x4*)&WinT[c * PT + q];
-                v += w * x[c];
-            }
-            const f32x4 fl = *(const f32x4*)&floorT[q];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) z0[t][r] = fmaxf(v[r], fl[r]);
-        }
-
-        // ---- layer 1 (MFMA): acc[t] = W1ext . z0ext,  rows = hidden outputs, cols = points ---------------------
-        f32x4 acc[MT];
-#pragma unroll
-        for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int tk = 0; tk < MTB; ++tk) {
-#pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const f32x4 w = *(const f32x4*)&Wimg[frow[t] + 16 * tk];
-#pragma unroll
-                for (int r = 0; r < G::nr_in(tk); ++r) acc[t] = MFMA16(w[r], z0[tk][r], acc[t]);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads of later k-groups from piling up in registers
-        }
-
-        // ---- output layer, sigmoid, data term ------------------------------------------------------------------
-        float ypart = 0.f;
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const f32x4 wo = *(const f32x4*)&woT[16 * t + 4 * g];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[t][r] = fmaxf(acc[t][r], 0.f);  // z1
-                ypart = fmaf(wo[r], acc[t][r], ypart);
-            }
-        }
-        ypart += __shfl_xor(ypart, 16);
-        ypart += __shfl_xor(ypart, 32);
-        float y = ypart + b_o;
-#pragma unroll
-        for (int c = 0; c < C; ++c) y = fmaf(s_o[c], x[c], y);
-        if (a.logits != nullptr && valid && g == 0) a.logits[(size_t)img * N + p] = y;
-
-        if (TRAIN) {
-            const float tg = a.targets[(size_t)img * N + pc];
-            const float pr = 1.f / (1.f + expf(-y));
-            const float cw = tg < 0.5f ? cfg_ : cbg_;
-            float l, dy;
-            if (a.loss_kind == INR_LOSS_SE) {
-                const float d = tg - pr;
-                l = d * d * cw;
-                dy = 2.f * (pr - tg) * pr * (1.f - pr) * cw;
-            } else if (a.loss_kind == INR_LOSS_EXTERNAL) {
-                l = 0.f;
-                dy = tg;  // `targets` carries dL/dlogit
-            } else {
-                const float lp = fmaxf(logf(pr), -100.f), lq = fmaxf(logf(1.f - pr), -100.f);
-                l = -(tg * lp + (1.f - tg) * lq) * cw;
-                const float pq = pr * (1.f - pr);
-                dy = (pr - tg) / fmaxf(pq, 1e-12f) * pq * cw;
-            }
-            if (!valid) {
-                l = 0.f;
-                dy = 0.f;
-            }
-            if (g == 0) {
-                loss_acc += l;
-                dbo += dy;
-#pragma unroll
-                for (int c = 0; c < C; ++c) dso[c] = fmaf(dy, x[c], dso[c]);
-            }
-            // dw_o += dy z1 ;  dz1 = dy w_o [z1 > 0]   (in place over acc)
-#pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const f32x4 wo = *(const f32x4*)&woT[16 * t + 4 * g];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float z1 = acc[t][r];
-                    dwo[t][r] = fmaf(dy, z1, dwo[t][r]);
-                    acc[t][r] = z1 > 0.f ? dy * wo[r] : 0.f;
-                }
-            }
-            // ---- stage dz1 (A) and z0ext (B) point-major for the dW product ---------------------------------
-            {
-                const int pl = wave * 16 + l15;
-#pragma unroll
-                for (int t = 0; t < MT; ++t)
-                    if (t < G::TL || g < G::A_G_MAX) *(f32x4*)&stA[pl * G::SA + 16 * t + 4 * g] = acc[t];
-#pragma unroll
-                for (int t = 0; t < MTB; ++t)
-                    if (t < MTB - 1 || g < G::B_G_MAX) *(f32x4*)&stB[pl * G::SB + 16 * t + 4 * g] = z0[t];
-            }
-            // ---- backward through layer 1 (MFMA): dz0[t] = W1^T . dz1, rows = hidden inputs ----------------------
-            f32x4 dz0[MT];
-#pragma unroll
-            for (int t = 0; t < MT; ++t) dz0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int tk = 0; tk < MT; ++tk) {
-#pragma unroll
-                for (int r = 0; r < G::nr_out(tk); ++r) {
-                    const int o = 16 * tk + 4 * g + r;
-                    const float* wr = Wimg + (tk < G::TL ? o : (o < H ? o : H)) * S + l15;
-#pragma unroll
-                    for (int t = 0; t < MT; ++t) dz0[t] = MFMA16(wr[16 * t], acc[tk][r], dz0[t]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            // relu mask of layer 0
-#pragma unroll
-            for (int t = 0; t < MT; ++t) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool hid = (t < G::TL) || (4 * g + r < G::REM);
-                    dz0[t][r] = (hid && z0[t][r] > 0.f) ? dz0[t][r] : 0.f;
-                }
-            }
-            __syncthreads();
-            // ---- dW1ext += dZ1^T Z0ext over the 64 staged points, output tiles split over the waves --------------
-            if (wave == 0) DwPhase<H, C, 0>::run(dW, stA, stB, l15, g);
-            else if (wave == 1) DwPhase<H, C, 1>::run(dW, stA, stB, l15, g);
-            else if (wave == 2) DwPhase<H, C, 2>::run(dW, stA, stB, l15, g);
-            else DwPhase<H, C, 3>::run(dW, stA, stB, l15, g);
-            __syncthreads();
-            // ---- layer-0 gradients: restage dz0 over dz1, multiply with the ext columns (1, x, ..) of stage B -----
-            {
-                const int pl = wave * 16 + l15;
-#pragma unroll
-                for (int t = 0; t < MT; ++t)
-                    if (t < G::TL || g < G::A_G_MAX) *(f32x4*)&stA[pl * G::SA + 16 * t + 4 * g] = dz0[t];
-            }
-            __syncthreads();
-            if (wave == 0) DwPhase<H, C, 0>::run_l0(dL0, stA, stB, l15, g);
-            else if (wave == 1) DwPhase<H, C, 1>::run_l0(dL0, stA, stB, l15, g);
-            else if (wave == 2) DwPhase<H, C, 2>::run_l0(dL0, stA, stB, l15, g);
-            else DwPhase<H, C, 3>::run_l0(dL0, stA, stB, l15, g);
-            __syncthreads();
-        }
-    }
-
-    if (TRAIN) {
-        float* __restrict__ slab = a.slabs + ((size_t)img * a.wgs + wg) * a.PS;
-        if (wave == 0) { DwPhase<H, C, 0>::store(dW, slab, l15, g); DwPhase<H, C, 0>::store_l0(dL0, slab, l15, g); }
-        else if (wave == 1) { DwPhase<H, C, 1>::store(dW, slab, l15, g); DwPhase<H, C, 1>::store_l0(dL0, slab, l15, g); }
-        else if (wave == 2) { DwPhase<H, C, 2>::store(dW, slab, l15, g); DwPhase<H, C, 2>::store_l0(dL0, slab, l15, g); }
-        else { DwPhase<H, C, 3>::store(dW, slab, l15, g); DwPhase<H, C, 3>::store_l0(dL0, slab, l15, g); }
-
-        // dw_o and the scalars: reduce over the 16 point-lanes, then over the 4 waves through LDS (fixed order)
-        constexpr int VS = MT * 16;               // vector length (positions)
-        constexpr int WSTR = VS + 8;
-        float* const scr = stA;                   // [4 waves][WSTR]
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v0 = wave16_sum(dwo[t][r]);
-                if (l15 == 0) scr[wave * WSTR + 16 * t + 4 * g + r] = v0;
-            }
-        }
-        {
-            float sc[2 + C];
-            sc[0] = loss_acc;
-            sc[1] = dbo;
-#pragma unroll
-            for (int c = 0; c < C; ++c) sc[2 + c] = dso[c];
-#pragma unroll
-            for (int k = 0; k < 2 + C; ++k) {
-                const float v = wave16_sum(sc[k]);  // only lane group 0 contributed
-                if (lane == 0) scr[wave * WSTR + VS + k] = v;
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < H; i += WG_THREADS) {
-            float s0 = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) s0 += scr[w * WSTR + i];
-            slab[G::P_WO + i] = s0;
-        }
-        if (tid < 2 + C) {
-            float sum = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) sum += scr[w * WSTR + VS + tid];
-            if (tid == 0) slab[G::P] = sum;              // loss partial
-            else if (tid == 1) slab[G::P_BO] = sum;
-            else slab[G::P_SO + tid - 2] = sum;
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // slab reduction + optimizer step
@@ -680,6 +131,10 @@ __global__ __launch_bounds__(UPD_PARAMS * UPD_GROUPS) void icnn_update_kernel(co
     if (u.opt.clamp && ((j >= u.clamp_lo0 && j < u.clamp_hi0) || (j >= u.clamp_lo1 && j < u.clamp_hi1))) p = fmaxf(p, 0.f);
     u.params[(size_t)img * u.P + j] = p;
     u.wimg[(size_t)img * u.img.floats + image_offset(u.img, j)] = p;
+    {
+        const int j2 = image_offset2(u.img, j);
+        if (j2 >= 0) u.wimg[(size_t)img * u.img.floats + j2] = p;
+    }
     st[j] = m;
     st[u.P + j] = v;
 }
@@ -710,7 +165,10 @@ __global__ __launch_bounds__(256) void pack_params_kernel(const float* __restric
     const int img = blockIdx.y;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m.P) return;
-    wimg[(size_t)img * m.floats + image_offset(m, j)] = params[(size_t)img * m.P + j];
+    const float v = params[(size_t)img * m.P + j];
+    wimg[(size_t)img * m.floats + image_offset(m, j)] = v;
+    const int j2 = image_offset2(m, j);
+    if (j2 >= 0) wimg[(size_t)img * m.floats + j2] = v;
 }
 
 // per-image loss coefficients (c_fg, c_bg): 'mean' normalisation x UnariesWeightedLoss class weight
@@ -818,8 +276,8 @@ template <int H, int C>
 constexpr KernelEntry make_entry() {
     using G = Cfg<H, C>;
     ImgMap m{};
-    m.H = H; m.C = C; m.S = G::S; m.PT = G::PT; m.floats = G::IMG_FLOATS;
-    m.off_win = G::OFF_WIN; m.off_bin = G::OFF_BIN; m.off_floor = G::OFF_FLOOR; m.off_wo = G::OFF_WO; m.off_sc = G::OFF_SC;
+    m.H = H; m.C = C; m.HM = G::HM; m.S = G::S; m.PT = G::PT; m.floats = G::IMG_FLOATS;
+    m.off_wct = G::OFF_WCT; m.off_win = G::OFF_WIN; m.off_bin = G::OFF_BIN; m.off_floor = G::OFF_FLOOR; m.off_wo = G::OFF_WO; m.off_sc = G::OFF_SC;
     for (int e = 0; e < 4; ++e) m.ext[e] = e < G::NEXT ? G::ext_pos(e) : 0;
     m.p_bin = G::P_BIN; m.p_w1 = G::P_W1; m.p_b1 = G::P_B1; m.p_s1 = G::P_S1; m.p_wo = G::P_WO; m.p_bo = G::P_BO;
     m.p_so = G::P_SO; m.P = G::P;
