@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libinrfit.so")
+LIB_PATH = os.environ.get("INRFIT_LIB") or os.path.join(HERE, "csrc", "libinrfit.so")  # INRFIT_LIB: A/B builds (tools/)
 
 # enums (include/inrfit.h)
 INR_MODEL_ICNN = 1

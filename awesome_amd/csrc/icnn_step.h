@@ -66,15 +66,17 @@ struct Cfg {
     static constexpr int RPW = (TM + 3) / 4;     // row tiles of the dW product per wave
 
     // ---- LDS carve (floats).  [0, IMG_FLOATS) is the parameter image, kept in HBM in exactly this layout. ----------
-    static constexpr int OFF_W = 0;                              // W1ext [H][S]: row o, columns = positions
-    static constexpr int OFF_WCT = OFF_W + H * S + 16;           // [HR][PT]: W1[:, HM+u] transposed (leftover inputs)
-    static constexpr int OFF_WIN = OFF_WCT + HR * PT;            // [C][PT]
-    static constexpr int OFF_BIN = OFF_WIN + C * PT;
-    static constexpr int OFF_FLOOR = OFF_BIN + PT;               // relu floor: 0 for hidden, -inf for ext inputs
-    static constexpr int OFF_WO = OFF_FLOOR + PT;
-    static constexpr int OFF_SC = OFF_WO + PT;                   // b_o, s_o[0..C-1]
-    static constexpr int IMG_FLOATS = OFF_SC + 8;
-    static_assert(IMG_FLOATS % 4 == 0, "image must be float4-copyable");
+    // Small tables first (reachable with immediate offsets from one base), then the big weight image.
+    static constexpr int OFF_SC = 0;                             // b_o, s_o[0..C-1]
+    static constexpr int OFF_WINE = OFF_SC + 8;                  // [4][PT] layer-0 A operand: rows W_in[:,0..C-1], b_in, (0)
+    static constexpr int OFF_WIN = OFF_WINE + 4 * PT;            // [C][16] W_in of k-group TM's positions (leftovers + ext)
+    static constexpr int OFF_BIN = OFF_WIN + C * 16;             // [16]
+    static constexpr int OFF_FLOOR = OFF_BIN + 16;               // [16] relu floor: 0 for hidden, -inf for ext inputs
+    static constexpr int OFF_WO = OFF_FLOOR + 16;                // [PT]
+    static constexpr int OFF_WCT = OFF_WO + PT;                  // [HR][PT]: W1[:, HM+u] transposed (leftover inputs)
+    static constexpr int OFF_W = OFF_WCT + HR * PT;              // W1ext [H][S]: row o, columns = positions
+    static constexpr int IMG_FLOATS = OFF_W + H * S + 16;        // +16 zero floats: tail reads past the last row
+    static_assert(IMG_FLOATS % 4 == 0 && OFF_W % 4 == 0, "image must be float4-copyable / aligned");
     static constexpr int OFF_STA = IMG_FLOATS;
     static constexpr int OFF_STB = OFF_STA + SP * SA + 16;
     static constexpr int LDS_FLOATS = OFF_STB + SP * SB + 16;
@@ -96,40 +98,58 @@ struct Cfg {
 // run-time description of the parameter image (same numbers as Cfg<H,C>) for the untemplated kernels
 struct ImgMap {
     int H, C, HM, S, PT, floats;
-    int off_wct, off_win, off_bin, off_floor, off_wo, off_sc;
+    int off_sc, off_wine, off_win, off_bin, off_floor, off_wo, off_wct, off_w;
     int ext[4];
     int p_bin, p_w1, p_b1, p_s1, p_wo, p_bo, p_so, P;
 };
 
-// image offset of flat parameter j (every parameter has one primary slot)
-__device__ __forceinline__ int image_offset(const ImgMap& m, int j) {
-    if (j < m.p_bin) {  // input.weight [H][C]
+// Image slots of flat parameter j: every parameter has a primary slot; W_in/b_in of the leftover units and
+// W1[:, HM+u] are mirrored into a second table.  Returns the number of slots (1 or 2).
+__device__ __forceinline__ int image_slots(const ImgMap& m, int j, int (&slot)[2]) {
+    if (j < m.p_bin) {  // input.weight [H][C] -> layer-0 A operand rows 0..C-1 (+ k-group TM table for leftovers)
         const int i = j / m.C, c = j - i * m.C;
-        return m.off_win + c * m.PT + i;
+        slot[0] = m.off_wine + c * m.PT + i;
+        if (i >= m.HM) {
+            slot[1] = m.off_win + c * 16 + (i - m.HM);
+            return 2;
+        }
+        return 1;
     }
-    if (j < m.p_w1) return m.off_bin + (j - m.p_bin);
+    if (j < m.p_w1) {  // input.bias -> layer-0 A operand row C
+        const int i = j - m.p_bin;
+        slot[0] = m.off_wine + m.C * m.PT + i;
+        if (i >= m.HM) {
+            slot[1] = m.off_bin + (i - m.HM);
+            return 2;
+        }
+        return 1;
+    }
     if (j < m.p_b1) {  // skip.0.ln.weight [H][H]
         const int q = j - m.p_w1;
         const int o = q / m.H, i = q - o * m.H;
-        return o * m.S + i;
+        slot[0] = m.off_w + o * m.S + i;
+        if (i >= m.HM) {
+            slot[1] = m.off_wct + (i - m.HM) * m.PT + o;
+            return 2;
+        }
+        return 1;
     }
-    if (j < m.p_s1) return (j - m.p_b1) * m.S + m.ext[0];
+    if (j < m.p_s1) {
+        slot[0] = m.off_w + (j - m.p_b1) * m.S + m.ext[0];
+        return 1;
+    }
     if (j < m.p_wo) {  // skip.0.skp.weight [H][C]
         const int q = j - m.p_s1;
         const int o = q / m.C, c = q - o * m.C;
-        return o * m.S + m.ext[1 + c];
+        slot[0] = m.off_w + o * m.S + m.ext[1 + c];
+        return 1;
     }
-    if (j < m.p_bo) return m.off_wo + (j - m.p_wo);
-    return m.off_sc + (j - m.p_bo);  // b_o, s_o[c]
-}
-// second slot: W1[o][HM+u] is mirrored into the transposed leftover-column table; -1 if none
-__device__ __forceinline__ int image_offset2(const ImgMap& m, int j) {
-    if (j >= m.p_w1 && j < m.p_b1) {
-        const int q = j - m.p_w1;
-        const int o = q / m.H, i = q - o * m.H;
-        if (i >= m.HM) return m.off_wct + (i - m.HM) * m.PT + o;
+    if (j < m.p_bo) {
+        slot[0] = m.off_wo + (j - m.p_wo);
+        return 1;
     }
-    return -1;
+    slot[0] = m.off_sc + (j - m.p_bo);  // b_o, s_o[c]
+    return 1;
 }
 
 struct StepArgs {
@@ -143,16 +163,27 @@ struct StepArgs {
     int n_images, wgs, PS, loss_kind;
 };
 
-__device__ __forceinline__ float sum_over_points(float v) {  // the 16 lanes sharing lane>>4
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+// Cross-lane sums on the VALU (DPP / permlane swaps): no LDS round trip, no s_waitcnt.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float sum_over_points(float v) {  // the 16 lanes sharing lane>>4 (one DPP row)
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);  // row_half_mirror
+    v += dpp_f<0x140>(v);  // row_mirror
     return v;
 }
 __device__ __forceinline__ float sum_over_groups(float v) {  // the 4 lanes sharing lane&15
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);   // rows 0+1, rows 2+3
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);   // halves
+    }
     return v;
 }
 
@@ -164,6 +195,16 @@ __device__ __forceinline__ float sum_over_groups(float v) {  // the 4 lanes shar
 #else
 #define SGB(mask, n)
 #endif
+// Keep successive k-steps of MFMAs in program order (everything else may still move across): without it hipcc regroups
+// the products per accumulator, i.e. into dependent chains that pay the 40-cycle latency instead of the 32-cycle issue.
+#ifndef INR_MFMA_ORDER
+#define INR_MFMA_ORDER 1
+#endif
+#if INR_MFMA_ORDER
+#define MFMA_STEP_FENCE() __builtin_amdgcn_sched_barrier(0x7F6)
+#else
+#define MFMA_STEP_FENCE()
+#endif
 
 template <int H, int C, bool TRAIN>
 __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs a) {
@@ -174,6 +215,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Wimg = smem + G::OFF_W;
     float* const WcT = smem + G::OFF_WCT;
+    float* const WinE = smem + G::OFF_WINE;
     float* const WinT = smem + G::OFF_WIN;
     float* const binT = smem + G::OFF_BIN;
     float* const floorT = smem + G::OFF_FLOOR;
@@ -258,13 +300,13 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
     const long long n_chunks = (N + SP - 1) / SP;
     for (long long chunk = wg; chunk < n_chunks; chunk += a.wgs) {
         // ---- coordinates (and target) of this lane's point ---------------------------------------------------
-        const long long p = chunk * SP + wave * 16 + l15;
-        const bool valid = p < N;
-        const long long pc = valid ? p : N - 1;
+        const int p = (int)chunk * SP + wave * 16 + l15;   // points per image < 2^31 (checked on the host)
+        const bool valid = p < (int)N;
+        const int pc = valid ? p : (int)N - 1;
         float x[C];
         if (a.grid.mode == INR_GRID_SEPARABLE) {
-            const int row = (int)(pc / a.grid.width);
-            const int col = (int)(pc - (long long)row * a.grid.width);
+            const int row = pc / a.grid.width;
+            const int col = pc - row * a.grid.width;
             x[0] = a.grid.xs[col];
             x[1] = a.grid.ys[row];
             if (C > 2) x[C - 1] = a.grid.ts ? a.grid.ts[img] : 0.f;
@@ -276,19 +318,26 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
         float tg = 0.f;
         if (TRAIN) tg = a.targets[(size_t)img * N + pc];
 
-        // layer 0 (VALU), one k-group at a time: z0[pos] = max(W_in[pos].x + b_in[pos], floor[pos]), B-operand layout
+        // layer 0.  Main tiles on the matrix pipe: z0pre = [W_in | b_in] . (x, 1) is one k-step per tile (A rows from the
+        // WinE table, B = this point's (x_0.., 1) by lane group); its D tile is already the B operand layout.  The last
+        // k-group (leftover hidden units + ext inputs 1, x_c) is 16 positions of VALU work with per-position tables.
         f32x4 z0[KG];
+        const float xe = g < C ? x[g < C ? g : 0] : (g == C ? 1.f : 0.f);
         auto z0_tile = [&](int tk) -> f32x4 {
-            const int q = 16 * tk + 4 * g;
-            f32x4 v = *(const f32x4*)&binT[q];
+            f32x4 z = MFMA16(WinE[g * PT + 16 * tk + l15], xe, (f32x4{0.f, 0.f, 0.f, 0.f}));
 #pragma unroll
-            for (int c = 0; c < C; ++c) v += *(const f32x4*)&WinT[c * PT + q] * x[c];
-            const f32x4 fl = *(const f32x4*)&floorT[q];
-            f32x4 z;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) z[r] = fmaxf(v[r], fl[r]);
+            for (int r = 0; r < 4; ++r) z[r] = fmaxf(z[r], 0.f);
             return z;
         };
+        {
+            const int q = 4 * g;
+            f32x4 v = *(const f32x4*)&binT[q];
+#pragma unroll
+            for (int c = 0; c < C; ++c) v += *(const f32x4*)&WinT[c * 16 + q] * x[c];
+            const f32x4 fl = *(const f32x4*)&floorT[q];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z0[TM][r] = fmaxf(v[r], fl[r]);
+        }
 
         // ---- layer 1 (MFMA, software pipelined): acc[t] = W1ext . z0ext ----------------------------------------
         f32x4 acc[TM];
@@ -306,7 +355,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
             if (tk + 1 < KG) {
 #pragma unroll
                 for (int t = 0; t < TM; ++t) wq[(tk + 1) & 1][t] = *(const f32x4*)(wf + t * 16 * S + 16 * (tk + 1));
-                z0[tk + 1] = z0_tile(tk + 1);
+                if (tk + 1 < TM) z0[tk + 1] = z0_tile(tk + 1);
             }
 #pragma unroll
             for (int u = 0; u < HR; ++u) {
@@ -315,9 +364,11 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 for (int r = 0; r < G::nr_in(tk); ++r) la[u] = fmaf(wl[r], z0[tk][r], la[u]);
             }
 #pragma unroll
-            for (int r = 0; r < G::nr_in(tk); ++r)
+            for (int r = 0; r < G::nr_in(tk); ++r) {
 #pragma unroll
                 for (int t = 0; t < TM; ++t) acc[t] = MFMA16(wq[tk & 1][t][r], z0[tk][r], acc[t]);
+                MFMA_STEP_FENCE();
+            }
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
                 SGB(SG_DS_READ, 2);
@@ -452,6 +503,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 }
 #pragma unroll
                 for (int t = 0; t < TM; ++t) dz0[t] = MFMA16(bq[ks & 1][t], bop, dz0[t]);
+                MFMA_STEP_FENCE();
 #pragma unroll
                 for (int t = 0; t < TM; ++t) {
                     SGB(SG_DS_READ, 1);
@@ -510,6 +562,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                         for (int j = 0; j < RPW; ++j)
 #pragma unroll
                             for (int b = 0; b < KG; ++b) dW[j][b] = MFMA16(af[it & 1][j], bf[it & 1][b], dW[j][b]);
+                        MFMA_STEP_FENCE();
                     }
 #pragma unroll
                     for (int b = 0; b < KG; ++b) {

@@ -130,34 +130,32 @@ __global__ __launch_bounds__(UPD_PARAMS * UPD_GROUPS) void icnn_update_kernel(co
     }
     if (u.opt.clamp && ((j >= u.clamp_lo0 && j < u.clamp_hi0) || (j >= u.clamp_lo1 && j < u.clamp_hi1))) p = fmaxf(p, 0.f);
     u.params[(size_t)img * u.P + j] = p;
-    u.wimg[(size_t)img * u.img.floats + image_offset(u.img, j)] = p;
     {
-        const int j2 = image_offset2(u.img, j);
-        if (j2 >= 0) u.wimg[(size_t)img * u.img.floats + j2] = p;
+        int slot[2];
+        const int ns = image_slots(u.img, j, slot);
+        float* __restrict__ wi = u.wimg + (size_t)img * u.img.floats;
+        wi[slot[0]] = p;
+        if (ns > 1) wi[slot[1]] = p;
     }
     st[j] = m;
     st[u.P + j] = v;
 }
 
-// params -> parameter image (zeros, ext-input constants, then every parameter at its image offset)
-__global__ __launch_bounds__(256) void pack_image_kernel(const float* __restrict__ params, float* __restrict__ wimg,
-                                                         const ImgMap m) {
-    const int img = blockIdx.y;
-    float* __restrict__ dst = wimg + (size_t)img * m.floats;
-    const float* __restrict__ src = params + (size_t)img * m.P;
+// params -> parameter image: constant background (zeros, ext-input constants), then every parameter into its slot(s)
+__global__ __launch_bounds__(256) void pack_image_kernel(float* __restrict__ wimg, const ImgMap m) {
+    float* __restrict__ dst = wimg + (size_t)blockIdx.y * m.floats;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m.floats) return;
-    // which parameter (if any) lives at image offset i?  Invert image_offset by scanning is too slow; instead every
-    // thread first writes the constant background of its slot, and parameter threads overwrite afterwards (2nd launch).
     float v = 0.f;
-    if (i == m.off_bin + m.ext[0]) v = 1.f;                       // ext input "1": bias slot
+    const int e0 = m.ext[0] - m.HM;                                // k-group TM slot of the ext input "1"
+    if (i == m.off_bin + e0) v = 1.f;
+    if (i == m.off_floor + e0) v = -INFINITY;                      // no relu on ext inputs
     for (int c = 0; c < m.C; ++c) {
-        if (i == m.off_win + c * m.PT + m.ext[1 + c]) v = 1.f;    // ext input x_c
-        if (i == m.off_floor + m.ext[1 + c]) v = -INFINITY;       // no relu on ext inputs
+        const int ec = m.ext[1 + c] - m.HM;                        // ext input x_c
+        if (i == m.off_win + c * 16 + ec) v = 1.f;
+        if (i == m.off_floor + ec) v = -INFINITY;
     }
-    if (i == m.off_floor + m.ext[0]) v = -INFINITY;
     dst[i] = v;
-    (void)src;
 }
 
 __global__ __launch_bounds__(256) void pack_params_kernel(const float* __restrict__ params, float* __restrict__ wimg,
@@ -166,9 +164,11 @@ __global__ __launch_bounds__(256) void pack_params_kernel(const float* __restric
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m.P) return;
     const float v = params[(size_t)img * m.P + j];
-    wimg[(size_t)img * m.floats + image_offset(m, j)] = v;
-    const int j2 = image_offset2(m, j);
-    if (j2 >= 0) wimg[(size_t)img * m.floats + j2] = v;
+    int slot[2];
+    const int ns = image_slots(m, j, slot);
+    float* __restrict__ wi = wimg + (size_t)img * m.floats;
+    wi[slot[0]] = v;
+    if (ns > 1) wi[slot[1]] = v;
 }
 
 // per-image loss coefficients (c_fg, c_bg): 'mean' normalisation x UnariesWeightedLoss class weight
@@ -277,7 +277,8 @@ constexpr KernelEntry make_entry() {
     using G = Cfg<H, C>;
     ImgMap m{};
     m.H = H; m.C = C; m.HM = G::HM; m.S = G::S; m.PT = G::PT; m.floats = G::IMG_FLOATS;
-    m.off_wct = G::OFF_WCT; m.off_win = G::OFF_WIN; m.off_bin = G::OFF_BIN; m.off_floor = G::OFF_FLOOR; m.off_wo = G::OFF_WO; m.off_sc = G::OFF_SC;
+    m.off_sc = G::OFF_SC; m.off_wine = G::OFF_WINE; m.off_win = G::OFF_WIN; m.off_bin = G::OFF_BIN;
+    m.off_floor = G::OFF_FLOOR; m.off_wo = G::OFF_WO; m.off_wct = G::OFF_WCT; m.off_w = G::OFF_W;
     for (int e = 0; e < 4; ++e) m.ext[e] = e < G::NEXT ? G::ext_pos(e) : 0;
     m.p_bin = G::P_BIN; m.p_w1 = G::P_W1; m.p_b1 = G::P_B1; m.p_s1 = G::P_S1; m.p_wo = G::P_WO; m.p_bo = G::P_BO;
     m.p_so = G::P_SO; m.P = G::P;
@@ -317,7 +318,7 @@ int wgs_per_image(long long n_points, int n_images) {
 }
 
 int check_grid(const InrGridDesc* g, const KernelEntry* e, int n_images) {
-    if (!g || g->n_points <= 0 || n_images <= 0) return INR_EINVAL;
+    if (!g || g->n_points <= 0 || g->n_points > 0x7fffffffLL || n_images <= 0) return INR_EINVAL;
     if (g->mode == INR_GRID_SEPARABLE) {
         if (!g->xs || !g->ys || g->width <= 0 || g->height <= 0) return INR_EINVAL;
         if ((long long)g->width * g->height != g->n_points) return INR_EINVAL;
@@ -393,7 +394,7 @@ int64_t inrfit_workspace_bytes(const InrModelDesc* model, const InrGridDesc* gri
 }
 
 static int launch_pack(const KernelEntry* e, const Workspace& w, const float* params, int n_images, hipStream_t s) {
-    hipLaunchKernelGGL(pack_image_kernel, dim3((e->img.floats + 255) / 256, n_images), dim3(256), 0, s, params, w.wimg, e->img);
+    hipLaunchKernelGGL(pack_image_kernel, dim3((e->img.floats + 255) / 256, n_images), dim3(256), 0, s, w.wimg, e->img);
     hipLaunchKernelGGL(pack_params_kernel, dim3((e->P + 255) / 256, n_images), dim3(256), 0, s, params, w.wimg, e->img);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
