@@ -270,7 +270,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
 
     // persistent gradient accumulators (TRAIN)
     f32x4 dW[RPW][KG];     // dW1ext tiles: rows 16*(wave*RPW+j).., columns 16*b..             (MFMA)
-    f32x4 dL0[RPW];        // layer-0 gradient tiles: same rows, columns = ext slots of k-group TM (MFMA)
+    f32x4 dL0[TM];         // layer-0 gradient of this wave's own points: rows 16t.., columns = slots of k-group TM (MFMA)
     f32x4 dwo[TM];         // dw_o partial sums over this lane's points                          (VALU)
     float dwol[HRA];       // ... leftover units (lane group 0 only)
     float dWl[HRA][KG];    // leftover rows of dW1ext: column 16b + l15, partial over this lane group's points
@@ -278,13 +278,14 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
     float loss_acc = 0.f, dbo = 0.f, dso[C];
     if (TRAIN) {
 #pragma unroll
-        for (int j = 0; j < RPW; ++j) {
-            dL0[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < RPW; ++j)
 #pragma unroll
             for (int b = 0; b < KG; ++b) dW[j][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
 #pragma unroll
-        for (int t = 0; t < TM; ++t) dwo[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < TM; ++t) {
+            dwo[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dL0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int u = 0; u < HRA; ++u) {
             dwol[u] = 0.f;
@@ -297,26 +298,43 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
         for (int c = 0; c < C; ++c) dso[c] = 0.f;
     }
 
-    const long long n_chunks = (N + SP - 1) / SP;
-    for (long long chunk = wg; chunk < n_chunks; chunk += a.wgs) {
-        // ---- coordinates (and target) of this lane's point ---------------------------------------------------
-        const int p = (int)chunk * SP + wave * 16 + l15;   // points per image < 2^31 (checked on the host)
-        const bool valid = p < (int)N;
-        const int pc = valid ? p : (int)N - 1;
+    const int n_chunks = (int)((N + SP - 1) / SP);
+    // coordinates (and target) of this lane's point of a chunk; invalid points are clamped to the last valid one
+    struct PointIn {
         float x[C];
+        float tg;
+    };
+    auto load_point = [&](int chunk) -> PointIn {
+        PointIn q;
+        int pc = chunk * SP + wave * 16 + l15;   // points per image < 2^31 (checked on the host)
+        pc = pc < (int)N ? pc : (int)N - 1;
         if (a.grid.mode == INR_GRID_SEPARABLE) {
             const int row = pc / a.grid.width;
             const int col = pc - row * a.grid.width;
-            x[0] = a.grid.xs[col];
-            x[1] = a.grid.ys[row];
-            if (C > 2) x[C - 1] = a.grid.ts ? a.grid.ts[img] : 0.f;
+            q.x[0] = a.grid.xs[col];
+            q.x[1] = a.grid.ys[row];
+            if (C > 2) q.x[C - 1] = a.grid.ts ? a.grid.ts[img] : 0.f;
         } else {
             const float* cp = a.grid.coords + (size_t)img * a.grid.coords_image_stride;
 #pragma unroll
-            for (int c = 0; c < C; ++c) x[c] = cp[(size_t)c * N + pc];
+            for (int c = 0; c < C; ++c) q.x[c] = cp[(size_t)c * N + pc];
         }
-        float tg = 0.f;
-        if (TRAIN) tg = a.targets[(size_t)img * N + pc];
+        q.tg = TRAIN ? a.targets[(size_t)img * N + pc] : 0.f;
+        return q;
+    };
+    PointIn nxt = load_point(wg);
+    for (int chunk = wg; chunk < n_chunks; chunk += a.wgs) {
+        const int p = chunk * SP + wave * 16 + l15;
+        const bool valid = p < (int)N;
+        const PointIn cur = nxt;
+        {   // prefetch the next chunk's inputs: the global-load latency hides under this chunk's MFMAs
+            const int cn = chunk + a.wgs;
+            nxt = load_point(cn < n_chunks ? cn : chunk);
+        }
+        float x[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) x[c] = cur.x[c];
+        const float tg = cur.tg;
 
         // layer 0.  Main tiles on the matrix pipe: z0pre = [W_in | b_in] . (x, 1) is one k-step per tile (A rows from the
         // WinE table, B = this point's (x_0.., 1) by lane group); its D tile is already the B operand layout.  The last
@@ -458,7 +476,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
             }
             if (g < 3) *(f32x4*)(sb + HM) = z0[TM];
 
-            // ---- backward through layer 1 (MFMA, pipelined): dz0[t] = W1^T . dz1 ---------------------------------
+            // ---- backward through layer 1 (MFMA, pipelined): dZ0 = dZ1 . W1 ----------------------------------------
+            // Operands swapped w.r.t. the forward product (same registers): the D tile comes out transposed - rows =
+            // this wave's points 4g+r, columns = hidden unit 16t + l15 - which is the A operand of the layer-0
+            // gradient product dW_in = dZ0^T . (1, x), so that product needs no staging and no barrier.
             f32x4 dz0[TM];
             float dz0l[HRA];
 #pragma unroll
@@ -502,7 +523,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                     }
                 }
 #pragma unroll
-                for (int t = 0; t < TM; ++t) dz0[t] = MFMA16(bq[ks & 1][t], bop, dz0[t]);
+                for (int t = 0; t < TM; ++t) dz0[t] = MFMA16(bop, bq[ks & 1][t], dz0[t]);  // D = dZ0 with POINTS on the rows
                 MFMA_STEP_FENCE();
 #pragma unroll
                 for (int t = 0; t < TM; ++t) {
@@ -512,11 +533,26 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 }
                 if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
-            // relu mask of layer 0; leftover rows of the layer-0 gradient (lane group 0, VALU)
+            // relu mask of layer 0 in the same transposed layout: z0^T comes from the layer-0 product with swapped operands
+            // (TM more MFMAs); then dL0[t] += dZ0[:, tile t]^T . ext columns of this wave's own stage-B rows.
+            {
+                float bfe[4];
 #pragma unroll
-            for (int t = 0; t < TM; ++t)
+                for (int r = 0; r < 4; ++r) bfe[r] = stB[(wave * 16 + 4 * g + r) * G::SB + HM + l15];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dz0[t][r] = z0[t][r] > 0.f ? dz0[t][r] : 0.f;
+                for (int t = 0; t < TM; ++t) {
+                    const f32x4 z0p = MFMA16(xe, WinE[g * PT + 16 * t + l15], (f32x4{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dz0[t][r] = z0p[r] > 0.f ? dz0[t][r] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) dL0[t] = MFMA16(dz0[t][r], bfe[r], dL0[t]);
+                    MFMA_STEP_FENCE();
+                }
+            }
+            // leftover rows of the layer-0 gradient (lane group 0, VALU)
 #pragma unroll
             for (int u = 0; u < HR; ++u) {
                 const float d = sum_over_groups(dz0l[u]);
@@ -574,20 +610,6 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 }
             }
             __syncthreads();
-            // ---- layer-0 gradients: restage dz0 over dz1, multiply with the ext columns of stage B ------------------
-#pragma unroll
-            for (int t = 0; t < TM; ++t) *(f32x4*)(sa + 16 * t) = dz0[t];
-            __syncthreads();
-            if (row_ok) {
-#pragma unroll
-                for (int it = 0; it < SP / 4; ++it) {
-                    const int pt = 16 * (it >> 2) + (it & 3) + 4 * g;
-                    const float bfe = stB[pt * G::SB + HM + l15];
-#pragma unroll
-                    for (int j = 0; j < RPW; ++j) dL0[j] = MFMA16(stA[pt * G::SA + arow + 16 * j], bfe, dL0[j]);
-                }
-            }
-            __syncthreads();
         }
     }
 
@@ -621,24 +643,6 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                         for (int r = 0; r < 4; ++r) slab[off + (o0 + r) * rs] = dW[j][b][r];
                     }
                 }
-                {
-                    const int pos = HM + l15;
-                    int off = -1, rs = 0;
-                    if (pos == G::ext_pos(0)) {
-                        off = G::P_BIN;
-                        rs = 1;
-                    }
-#pragma unroll
-                    for (int c = 0; c < C; ++c)
-                        if (pos == G::ext_pos(1 + c)) {
-                            off = G::P_WIN + c;
-                            rs = C;
-                        }
-                    if (off >= 0) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) slab[off + (o0 + r) * rs] = dL0[j][r];
-                    }
-                }
             }
         }
         // ---- everything that was summed per lane: reduce within the wave, then over the waves through LDS -------------
@@ -646,7 +650,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
         constexpr int SC_DWL = SC_DWO + PT;          // [HRA][PT]       leftover rows of dW1ext by column position
         constexpr int SC_L0L = SC_DWL + HRA * PT;    // [HRA][4]        leftover rows of the layer-0 gradient
         constexpr int SC_SC = SC_L0L + HRA * 4;      // [8]             loss, db_o, ds_o
-        constexpr int WSTR = SC_SC + 8;
+        constexpr int SC_L0 = SC_SC + 8;             // [HM][4]         layer-0 gradient of the main units by ext input
+        constexpr int WSTR = SC_L0 + HM * 4;
         static_assert(4 * WSTR <= SP * G::SA, "reduction scratch must fit stage A");
         float* const scr = stA + wave * WSTR;
 #pragma unroll
@@ -669,6 +674,18 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
             for (int e = 0; e < NEXT; ++e) {
                 const float w = sum_over_points(dL0l[u][e]);  // lane group 0 only
                 if (lane == 0) scr[SC_L0L + u * 4 + e] = w;
+            }
+        }
+        {   // dL0 tiles: row 16t + 4g + r = hidden unit, column l15 = slot of k-group TM; keep the ext-input columns
+            int e = -1;
+#pragma unroll
+            for (int k = 0; k < NEXT; ++k)
+                if (HM + l15 == G::ext_pos(k)) e = k;
+            if (e >= 0) {
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) scr[SC_L0 + (16 * t + 4 * g + r) * 4 + e] = dL0[t][r];
             }
         }
         {
@@ -696,6 +713,12 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 for (int c = 0; c < C; ++c)
                     if (pos == G::ext_pos(1 + c)) slab[G::P_S1 + (HM + u) * C + c] = v;
             }
+        }
+        for (int i = tid; i < HM * NEXT; i += WG_THREADS) {
+            const int row = i / NEXT, e = i - row * NEXT;
+            const float v = wsum(SC_L0 + row * 4 + e);
+            if (e == 0) slab[G::P_BIN + row] = v;
+            else slab[G::P_WIN + row * C + (e - 1)] = v;
         }
         if (tid < HR * NEXT) {
             const int u = tid / NEXT, e = tid - u * NEXT;
