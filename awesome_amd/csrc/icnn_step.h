@@ -197,13 +197,40 @@ __device__ __forceinline__ float sum_over_groups(float v) {  // the 4 lanes shar
 #endif
 // Keep successive k-steps of MFMAs in program order (everything else may still move across): without it hipcc regroups
 // the products per accumulator, i.e. into dependent chains that pay the 40-cycle latency instead of the 32-cycle issue.
+#ifndef INR_FWD_FENCE
+#define INR_FWD_FENCE 0
+#endif
 #ifndef INR_MFMA_ORDER
 #define INR_MFMA_ORDER 1
 #endif
 #if INR_MFMA_ORDER
 #define MFMA_STEP_FENCE() __builtin_amdgcn_sched_barrier(0x7F6)
+// ... and one that LDS reads may not cross either: operand reads written ahead of a block of MFMAs stay ahead of it
+// (hipcc otherwise sinks each read to just before its use and waits for it there, one LDS latency per pair of MFMAs).
+#define OPERAND_FENCE() __builtin_amdgcn_sched_barrier(0x676)
 #else
 #define MFMA_STEP_FENCE()
+#define OPERAND_FENCE()
+#endif
+
+// Diagnostic build only (-DINR_STAMPS=1): per-phase cycle sums of workgroup 0 / wave 0, read back by tools/stamps.py.
+// Never enabled in the shipped library (stamps fence the schedule; read their SHARES, not the run time).
+#ifndef INR_STAMPS
+#define INR_STAMPS 0
+#endif
+#if INR_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP(k)                                                                                   \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        unsigned long long t_;                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        st_sum[k] += t_ - st_prev;                                                                 \
+        st_prev = t_;                                                                              \
+    } while (0)
+#else
+#define STAMP(k)
 #endif
 
 template <int H, int C, bool TRAIN>
@@ -323,7 +350,13 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
         return q;
     };
     PointIn nxt = load_point(wg);
+#if INR_STAMPS
+    unsigned long long st_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+    const unsigned long long st_begin = st_prev;
+#endif
     for (int chunk = wg; chunk < n_chunks; chunk += a.wgs) {
+        STAMP(0);
         const int p = chunk * SP + wave * 16 + l15;
         const bool valid = p < (int)N;
         const PointIn cur = nxt;
@@ -357,54 +390,71 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
             for (int r = 0; r < 4; ++r) z0[TM][r] = fmaxf(v[r], fl[r]);
         }
 
+        STAMP(1);
         // ---- layer 1 (MFMA, software pipelined): acc[t] = W1ext . z0ext ----------------------------------------
+        // Every LDS operand of k-group tk+1 is requested while k-group tk multiplies (double-buffered registers), so no
+        // wait sits between a read and its use inside the stream of MFMAs.
         f32x4 acc[TM];
         float la[HRA];  // leftover units' pre-activation, partial over this lane group's positions
 #pragma unroll
-        for (int t = 0; t < TM; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
         for (int u = 0; u < HRA; ++u) la[u] = 0.f;
-        f32x4 wq[2][TM];
+        f32x4 wq[2][TM];    // A operands of the main units: rows 16t + l15, 4 k-steps each
+        f32x4 wlq[2][HRA];  // same columns of the leftover units' rows
+        float winq[2];      // layer-0 A operand of the next z0 tile
+        f32x4 wo[TM];       // w_o of this lane's positions (requested during the last k-group)
 #pragma unroll
         for (int t = 0; t < TM; ++t) wq[0][t] = *(const f32x4*)(wf + t * 16 * S);
+#pragma unroll
+        for (int u = 0; u < HR; ++u) wlq[0][u] = *(const f32x4*)(Wimg + (HM + u) * S + 4 * g);
         z0[0] = z0_tile(0);
+        winq[1] = WinE[g * PT + 16 * (TM > 1 ? 1 : 0) + l15];
 #pragma unroll
         for (int tk = 0; tk < KG; ++tk) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int cur = tk & 1, nx = cur ^ 1;
             if (tk + 1 < KG) {
 #pragma unroll
-                for (int t = 0; t < TM; ++t) wq[(tk + 1) & 1][t] = *(const f32x4*)(wf + t * 16 * S + 16 * (tk + 1));
-                if (tk + 1 < TM) z0[tk + 1] = z0_tile(tk + 1);
-            }
+                for (int t = 0; t < TM; ++t) wq[nx][t] = *(const f32x4*)(wf + t * 16 * S + 16 * (tk + 1));
 #pragma unroll
-            for (int u = 0; u < HR; ++u) {
-                const f32x4 wl = *(const f32x4*)(Wimg + (HM + u) * S + 16 * tk + 4 * g);
+                for (int u = 0; u < HR; ++u) wlq[nx][u] = *(const f32x4*)(Wimg + (HM + u) * S + 16 * (tk + 1) + 4 * g);
+                if (tk + 2 < TM) winq[cur] = WinE[g * PT + 16 * (tk + 2) + l15];
+            } else {
 #pragma unroll
-                for (int r = 0; r < G::nr_in(tk); ++r) la[u] = fmaf(wl[r], z0[tk][r], la[u]);
+                for (int t = 0; t < TM; ++t) wo[t] = *(const f32x4*)&woT[16 * t + 4 * g];
             }
+#if INR_FWD_FENCE
+            OPERAND_FENCE();
+#endif
+            f32x4 zn = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (tk + 1 < TM) zn = MFMA16(winq[nx], xe, (f32x4{0.f, 0.f, 0.f, 0.f}));  // pre-activation of z0[tk+1]
 #pragma unroll
             for (int r = 0; r < G::nr_in(tk); ++r) {
 #pragma unroll
-                for (int t = 0; t < TM; ++t) acc[t] = MFMA16(wq[tk & 1][t][r], z0[tk][r], acc[t]);
+                for (int t = 0; t < TM; ++t)
+                    acc[t] = MFMA16(wq[cur][t][r], z0[tk][r], (tk == 0 && r == 0) ? (f32x4{0.f, 0.f, 0.f, 0.f}) : acc[t]);
                 MFMA_STEP_FENCE();
             }
 #pragma unroll
-            for (int t = 0; t < TM; ++t) {
-                SGB(SG_DS_READ, 2);
-                SGB(SG_VALU, 3);
-                SGB(SG_MFMA, 4);
+            for (int u = 0; u < HR; ++u)
+#pragma unroll
+                for (int r = 0; r < G::nr_in(tk); ++r) la[u] = fmaf(wlq[cur][u][r], z0[tk][r], la[u]);
+            if (tk + 1 < TM) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z0[tk + 1][r] = fmaxf(zn[r], 0.f);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
 
+        STAMP(2);
         // ---- output layer, sigmoid, data term ------------------------------------------------------------------
         float ypart = 0.f;
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
-            const f32x4 wo = *(const f32x4*)&woT[16 * t + 4 * g];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 acc[t][r] = fmaxf(acc[t][r], 0.f);  // z1
-                ypart = fmaf(wo[r], acc[t][r], ypart);
+                ypart = fmaf(wo[t][r], acc[t][r], ypart);
             }
         }
         ypart = sum_over_groups(ypart);
@@ -458,12 +508,11 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
             float* const sb = stB + pl * G::SB + 4 * g;
             // dz1 of tile t (in place over acc), dw_o accumulation, staging of dz1 (A) and z0ext (B)
             auto dz1_tile = [&](int t) {
-                const f32x4 wo = *(const f32x4*)&woT[16 * t + 4 * g];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float z1 = acc[t][r];
                     dwo[t][r] = fmaf(dy, z1, dwo[t][r]);
-                    acc[t][r] = z1 > 0.f ? dy * wo[r] : 0.f;
+                    acc[t][r] = z1 > 0.f ? dy * wo[t][r] : 0.f;
                 }
                 *(f32x4*)(sa + 16 * t) = acc[t];
                 *(f32x4*)(sb + 16 * t) = z0[t];
@@ -476,6 +525,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
             }
             if (g < 3) *(f32x4*)(sb + HM) = z0[TM];
 
+            STAMP(3);
             // ---- backward through layer 1 (MFMA, pipelined): dZ0 = dZ1 . W1 ----------------------------------------
             // Operands swapped w.r.t. the forward product (same registers): the D tile comes out transposed - rows =
             // this wave's points 4g+r, columns = hidden unit 16t + l15 - which is the A operand of the layer-0
@@ -483,21 +533,22 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
             f32x4 dz0[TM];
             float dz0l[HRA];
 #pragma unroll
-            for (int t = 0; t < TM; ++t) dz0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
             for (int u = 0; u < HRA; ++u) dz0l[u] = 0.f;
             constexpr int KS = 4 * TM + HR;  // k-steps over the hidden outputs
-            float bq[2][TM];
-            auto b_row = [&](int ks) -> const float* {  // LDS row of the A operand for k-step ks
+            float bq[2][TM];      // B operands (weights): row o of this k-step, columns 16t + l15
+            f32x4 wcq[2][HRA];    // leftover input columns W1[o][HM+u] at this lane's positions of a tile
+            auto b_row = [&](int ks) -> const float* {  // LDS row of the weight operand for k-step ks
                 const int tk = ks >> 2, r = ks & 3;
                 if (tk < TM) return wb + (16 * tk + 4 * g + r) * S;
-                return wb + (g == 0 ? (HM + r) * S : 0);  // leftover outputs live in lane group 0 (others: B = 0)
+                return wb + (g == 0 ? (HM + r) * S : 0);  // leftover outputs live in lane group 0 (others: A = 0)
             };
             dz1_tile(0);
             {
                 const float* br = b_row(0);
 #pragma unroll
                 for (int t = 0; t < TM; ++t) bq[0][t] = br[16 * t];
+#pragma unroll
+                for (int u = 0; u < HR; ++u) wcq[0][u] = *(const f32x4*)(WcT + u * PT + 4 * g);
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -507,44 +558,50 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
 #pragma unroll
                     for (int t = 0; t < TM; ++t) bq[(ks + 1) & 1][t] = br[16 * t];
                 }
-                if (r == 0 && tk + 1 < TM) dz1_tile(tk + 1);  // next tile's dz1, in the shadow of this tile's MFMAs
+                if (r == 0 && (tk + 1) * 4 < KS) {
+#pragma unroll
+                    for (int u = 0; u < HR; ++u) wcq[(tk + 1) & 1][u] = *(const f32x4*)(WcT + u * PT + 16 * (tk + 1) + 4 * g);
+                }
+                OPERAND_FENCE();
                 const float bop = tk < TM ? acc[tk < TM ? tk : 0][r] : (g == 0 ? dzl[r < HRA ? r : 0] : 0.f);
-                if (r == 0) {  // leftover hidden inputs: dz0l[u] += W1[:, HM+u] . dz1 over this lane's positions
+#pragma unroll
+                for (int t = 0; t < TM; ++t)  // D = dZ0 with POINTS on the rows
+                    dz0[t] = MFMA16(bop, bq[ks & 1][t], ks == 0 ? (f32x4{0.f, 0.f, 0.f, 0.f}) : dz0[t]);
+                MFMA_STEP_FENCE();
+                if (r == 1 && tk + 1 < TM) dz1_tile(tk + 1);  // next tile's dz1 + staging, in the shadow of the MFMAs
+                if (r == 3 || ks == KS - 1) {  // leftover hidden inputs: dz0l[u] += W1[:, HM+u] . dz1 over this tile
 #pragma unroll
                     for (int u = 0; u < HR; ++u) {
-                        const f32x4 wc = *(const f32x4*)(WcT + u * PT + 16 * tk + 4 * g);
                         if (tk < TM) {
 #pragma unroll
-                            for (int rr = 0; rr < 4; ++rr) dz0l[u] = fmaf(wc[rr], acc[tk < TM ? tk : 0][rr], dz0l[u]);
+                            for (int rr = 0; rr < 4; ++rr)
+                                dz0l[u] = fmaf(wcq[tk & 1][u][rr], acc[tk < TM ? tk : 0][rr], dz0l[u]);
                         } else if (g == 0) {
 #pragma unroll
-                            for (int rr = 0; rr < HR; ++rr) dz0l[u] = fmaf(wc[rr], dzl[rr], dz0l[u]);
+                            for (int rr = 0; rr < HR; ++rr) dz0l[u] = fmaf(wcq[tk & 1][u][rr], dzl[rr], dz0l[u]);
                         }
                     }
                 }
-#pragma unroll
-                for (int t = 0; t < TM; ++t) dz0[t] = MFMA16(bop, bq[ks & 1][t], dz0[t]);  // D = dZ0 with POINTS on the rows
-                MFMA_STEP_FENCE();
-#pragma unroll
-                for (int t = 0; t < TM; ++t) {
-                    SGB(SG_DS_READ, 1);
-                    SGB(SG_VALU, 2);
-                    SGB(SG_MFMA, 1);
-                }
-                if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+            STAMP(4);
             // relu mask of layer 0 in the same transposed layout: z0^T comes from the layer-0 product with swapped operands
             // (TM more MFMAs); then dL0[t] += dZ0[:, tile t]^T . ext columns of this wave's own stage-B rows.
             {
                 float bfe[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bfe[r] = stB[(wave * 16 + 4 * g + r) * G::SB + HM + l15];
+                float wie[TM];
 #pragma unroll
-                for (int t = 0; t < TM; ++t) {
-                    const f32x4 z0p = MFMA16(xe, WinE[g * PT + 16 * t + l15], (f32x4{0.f, 0.f, 0.f, 0.f}));
+                for (int t = 0; t < TM; ++t) wie[t] = WinE[g * PT + 16 * t + l15];
+                OPERAND_FENCE();
+                f32x4 z0p[TM];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dz0[t][r] = z0p[r] > 0.f ? dz0[t][r] : 0.f;
-                }
+                for (int t = 0; t < TM; ++t) z0p[t] = MFMA16(xe, wie[t], (f32x4{0.f, 0.f, 0.f, 0.f}));
+                MFMA_STEP_FENCE();
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dz0[t][r] = z0p[t][r] > 0.f ? dz0[t][r] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -563,7 +620,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                     for (int c = 0; c < C; ++c) dL0l[u][1 + c] = fmaf(dm, x[c], dL0l[u][1 + c]);
                 }
             }
+            STAMP(5);
             __syncthreads();
+            STAMP(6);
 
             // ---- dW1ext += dZ1^T Z0ext over the 64 staged points (MFMA, pipelined); leftover rows on the VALU ------
             {
@@ -609,9 +668,15 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            STAMP(7);
             __syncthreads();
+            STAMP(8);
         }
     }
+#if INR_STAMPS
+    unsigned long long st_loop_end;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_loop_end)::"memory");
+#endif
 
     if (TRAIN) {
         float* __restrict__ slab = a.slabs + ((size_t)img * a.wgs + wg) * a.PS;
@@ -733,6 +798,16 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
             else slab[G::P_SO + tid - 2] = v;
         }
     }
+#if INR_STAMPS
+    if (TRAIN && blockIdx.x == 0 && tid == 0) {
+        unsigned long long t_end;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end)::"memory");
+        for (int k = 0; k < 9; ++k) g_stamps[k] = st_sum[k];
+        g_stamps[9] = st_begin;     // (absolute) loop start
+        g_stamps[10] = st_loop_end - st_begin;
+        g_stamps[11] = t_end - st_loop_end;   // epilogue
+    }
+#endif
 }
 
 }  // namespace

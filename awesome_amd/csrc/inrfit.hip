@@ -570,6 +570,12 @@ int inrfit_miou(const float* out, const float* tgt, int n_images, int64_t n_poin
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 
+#if INR_STAMPS
+int inrfit_debug_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -4;
+}
+#endif
+
 const char* inrfit_strerror(int code) {
     switch (code) {
         case INR_OK: return "ok";
