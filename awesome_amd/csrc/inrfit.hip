@@ -39,7 +39,10 @@ struct UpdArgs {
     int32_t* status;      // [n_images] or null
     InrOptDesc opt;
     int P, PS, wgs, n_images;
-    int t;                // 1-based optimizer step index (bias correction)
+    int t;                // 1-based optimizer step index
+    double bc1;           // 1 - beta1^t
+    float bc2_sqrt;       // sqrt(1 - beta2^t)
+    float one_minus_b1, one_minus_b2;
     int hist_idx, hist_stride;
     int mode;             // 0 = optimizer step, 1 = write reduced grads + loss only
     int clamp_lo0, clamp_hi0, clamp_lo1, clamp_hi1;  // flat ranges projected onto >= 0
@@ -48,19 +51,25 @@ struct UpdArgs {
 constexpr int UPD_PARAMS = 64;   // parameters per block (one 256-B line per slab row)
 constexpr int UPD_GROUPS = 16;   // slab groups summed in parallel, then combined in fixed order
 
-__global__ __launch_bounds__(UPD_PARAMS * UPD_GROUPS) void icnn_update_kernel(const UpdArgs u) {
+// block = (16 lanes x float4 = 64 parameters) x 16 slab groups
+__global__ __launch_bounds__(UPD_PARAMS / 4 * UPD_GROUPS) void icnn_update_kernel(const UpdArgs u) {
     const int img = blockIdx.y;
-    const int jl = threadIdx.x, grp = threadIdx.y;
-    const int j = blockIdx.x * UPD_PARAMS + jl;
+    const int tx = threadIdx.x, grp = threadIdx.y;
     __shared__ float red[UPD_GROUPS][UPD_PARAMS];
-    float part = 0.f;
-    if (j <= u.P) {
-        const float* __restrict__ sl = u.slabs + (size_t)img * u.wgs * u.PS + j;
-        for (int w = grp; w < u.wgs; w += UPD_GROUPS) part += sl[(size_t)w * u.PS];
+    {
+        const int j4 = blockIdx.x * UPD_PARAMS + 4 * tx;
+        f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (j4 < u.PS) {
+            const float* __restrict__ sl = u.slabs + (size_t)img * u.wgs * u.PS + j4;
+#pragma unroll 4
+            for (int w = grp; w < u.wgs; w += UPD_GROUPS) part += *(const f32x4*)(sl + (size_t)w * u.PS);
+        }
+        *(f32x4*)&red[grp][4 * tx] = part;
     }
-    red[grp][jl] = part;
     __syncthreads();
-    if (grp != 0 || j > u.P) return;
+    const int jl = grp * (UPD_PARAMS / 4) + tx;  // the first 64 threads finish one parameter each
+    const int j = blockIdx.x * UPD_PARAMS + jl;
+    if (jl >= UPD_PARAMS || j > u.P) return;
     float gsum = 0.f;
 #pragma unroll
     for (int k = 0; k < UPD_GROUPS; ++k) gsum += red[k][jl];  // fixed order: reproducible
@@ -109,17 +118,15 @@ __global__ __launch_bounds__(UPD_PARAMS * UPD_GROUPS) void icnn_update_kernel(co
     float m = st[j], v = st[u.P + j];
     float grad = gsum;
     if (u.opt.weight_decay != 0.f) grad = __fadd_rn(grad, __fmul_rn(u.opt.weight_decay, p));
-    const double b1 = (double)u.opt.beta1, b2 = (double)u.opt.beta2;
-    const double bc1 = 1.0 - pow(b1, (double)u.t);
-    const float w1 = (float)(1.0 - b1);
+    const double bc1 = u.bc1;  // 1 - beta1^t, computed on the host in double like torch does
+    const float w1 = u.one_minus_b1;
     // exp_avg.lerp_(grad, 1 - beta1)
     m = __fadd_rn(m, __fmul_rn(w1, __fsub_rn(grad, m)));
     if (u.opt.kind == INR_OPT_ADAM) {
-        const double bc2 = 1.0 - pow(b2, (double)u.t);
-        const float bc2_sqrt = (float)sqrt(bc2);
+        const float bc2_sqrt = u.bc2_sqrt;
         const float step_size = (float)((double)lr / bc1);
         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
-        v = __fadd_rn(__fmul_rn(v, u.opt.beta2), __fmul_rn(__fmul_rn((float)(1.0 - b2), grad), grad));
+        v = __fadd_rn(__fmul_rn(v, u.opt.beta2), __fmul_rn(__fmul_rn(u.one_minus_b2, grad), grad));
         const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), u.opt.eps);
         p = __fadd_rn(p, __fdiv_rn(__fmul_rn(-step_size, m), denom));
     } else {
@@ -450,7 +457,7 @@ static void launch_reduce(const KernelEntry* e, const Workspace& w, int n_images
     u.n_images = n_images;
     u.mode = 1;
     hipLaunchKernelGGL(icnn_update_kernel, dim3((e->P + 1 + UPD_PARAMS - 1) / UPD_PARAMS, n_images),
-                       dim3(UPD_PARAMS, UPD_GROUPS), 0, s, u);
+                       dim3(UPD_PARAMS / 4, UPD_GROUPS), 0, s, u);
 }
 
 int inrfit_forward(const InrModelDesc* model, const float* params, const InrGridDesc* grid, int n_images, float* logits,
@@ -545,6 +552,8 @@ int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const
     u.wgs = w.wgs;
     u.n_images = n_images;
     u.hist_stride = steps;
+    u.one_minus_b1 = (float)(1.0 - (double)opt->beta1);
+    u.one_minus_b2 = (float)(1.0 - (double)opt->beta2);
     u.mode = 0;
     u.clamp_lo0 = e->clamp_lo0;
     u.clamp_hi0 = e->clamp_hi0;
@@ -554,8 +563,10 @@ int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const
     for (int it = 0; it < steps; ++it) {
         if ((rc = launch_step(e, w, true, grid, targets, loss->kind, n_images, nullptr, s))) return rc;
         u.t = step0 + it + 1;
+        u.bc1 = 1.0 - pow((double)opt->beta1, (double)u.t);
+        u.bc2_sqrt = (float)sqrt(1.0 - pow((double)opt->beta2, (double)u.t));
         u.hist_idx = it;
-        hipLaunchKernelGGL(icnn_update_kernel, ugrid, dim3(UPD_PARAMS, UPD_GROUPS), 0, s, u);
+        hipLaunchKernelGGL(icnn_update_kernel, ugrid, dim3(UPD_PARAMS / 4, UPD_GROUPS), 0, s, u);
     }
     if (hipGetLastError() != hipSuccess) return INR_ELAUNCH;
     if (final_logits) return launch_step(e, w, false, grid, nullptr, 0, n_images, final_logits, s);
