@@ -197,6 +197,14 @@ __device__ __forceinline__ float sum_over_groups(float v) {  // the 4 lanes shar
 #endif
 // Keep successive k-steps of MFMAs in program order (everything else may still move across): without it hipcc regroups
 // the products per accumulator, i.e. into dependent chains that pay the 40-cycle latency instead of the 32-cycle issue.
+#ifndef INR_NT_SLAB
+#define INR_NT_SLAB 0
+#endif
+#if INR_NT_SLAB
+#define SLAB_ST(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#else
+#define SLAB_ST(ptr, v) (*(ptr) = (v))
+#endif
 #ifndef INR_FWD_FENCE
 #define INR_FWD_FENCE 0
 #endif
@@ -705,7 +713,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                     }
                     if (off >= 0) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) slab[off + (o0 + r) * rs] = dW[j][b][r];
+                        for (int r = 0; r < 4; ++r) SLAB_ST(&slab[off + (o0 + r) * rs], dW[j][b][r]);
                     }
                 }
             }
