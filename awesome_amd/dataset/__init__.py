@@ -1,1 +1,1 @@
-from .synthetic import convex_blob_mask, convex_blob_unaries, disc_unaries  # noqa: F401
+from .synthetic import SyntheticUnariesDataset, convex_blob_mask, convex_blob_unaries, disc_unaries  # noqa: F401

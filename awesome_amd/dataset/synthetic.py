@@ -56,3 +56,28 @@ def disc_unaries(h: int, w: int, cy: float, cx: float, r: float) -> torch.Tensor
     yy, xx = np.mgrid[0:h, 0:w]
     disc = ((yy - cy) ** 2 + (xx - cx) ** 2) <= r * r
     return torch.from_numpy(1.0 - disc.astype(np.float32))
+
+
+class SyntheticUnariesDataset:
+    """Minimal stand-in for the reference's prior datasets on the hot path: item i is `(grid_desc, unaries_i)` where
+    unaries follow the reference convention (fg = 0).  `kind`: 'disc' (C1) or 'blob' (C2/C3, seed = index + seed0)."""
+
+    def __init__(self, n_images: int = 1, size: int = 256, kind: str = "blob", seed0: int = 0, **kwargs):
+        self.n_images, self.size, self.kind, self.seed0 = int(n_images), int(size), kind, int(seed0)
+
+    def __len__(self) -> int:
+        return self.n_images
+
+    def unaries(self, i: int) -> torch.Tensor:
+        if self.kind == "disc":
+            s = self.size
+            return disc_unaries(s, s, s / 2, s / 2, 15.0 * s / 64.0)
+        if self.kind == "blob":
+            return convex_blob_unaries(self.size, self.seed0 + i)
+        raise ValueError(f"unknown kind {self.kind}")
+
+    def __getitem__(self, i: int):
+        return (self.size, self.size), self.unaries(i)
+
+    def batch(self, indices) -> torch.Tensor:
+        return torch.stack([self.unaries(int(i)).reshape(-1) for i in indices])

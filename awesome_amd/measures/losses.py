@@ -1,0 +1,140 @@
+"""Loss / metric objects with the reference's call contract `(output, target, **kwargs)`, usable as
+`loss_type:` in a config.  Called on tensors they run as torch ops on whatever device the tensors live on; handed to
+the fused fitter (awesome_amd.fitter) they are translated into the kernel's InrLossDesc by `criterion_to_desc`, so the
+E-step loop never leaves the device.  MIOU on GPU tensors is the HIP counting kernel."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from .. import icnn as K
+
+
+class SE:
+    """awesome/measures/se.py:21-23 - squared error with sum/mean/none reduction."""
+
+    def __init__(self, reduction: str = "mean", name: Optional[str] = None, **kwargs):
+        if reduction not in ("sum", "mean", "none"):
+            raise ValueError(f"Value {reduction} for reduction is invalid.")
+        self.reduction, self.name = reduction, name
+
+    def __call__(self, output: torch.Tensor, target: torch.Tensor, **kwargs) -> torch.Tensor:
+        se = (target - output) ** 2
+        return se if self.reduction == "none" else getattr(torch, self.reduction)(se)
+
+    def get_name(self) -> str:
+        return self.name or (self.reduction[0].upper() + "SE")
+
+
+class UnariesWeightedLoss:
+    """awesome/measures/unaries_weighted_loss.py:9-69 (+ weighted_loss.py:67-92): criterion with reduction none,
+    per-class weight on target < 0.5 from the fg/bg count ratio, then mean."""
+
+    def __init__(self, criterion=None, mode: str = "none", ratio: float = 1.0, reduction: str = "mean", name=None, **kwargs):
+        if criterion is None:
+            raise ValueError("criterion must be specified")
+        if mode not in ("none", "equal", "ratio", "sssdms"):
+            raise ValueError(f"Mode {mode} is not supported")
+        self.criterion, self.mode, self.ratio, self.reduction, self.name = criterion, mode, ratio, reduction, name
+        if hasattr(criterion, "reduction"):
+            criterion.reduction = "none"
+
+    def _weight(self, target: torch.Tensor) -> torch.Tensor:
+        fg = (target < 0.5).sum()
+        bg = (target >= 0.5).sum()
+        cc = bg.float() / fg.float()
+        if self.mode == "ratio":
+            wv = (cc - 1) * self.ratio + 1
+        elif self.mode == "sssdms":
+            wv = torch.round(cc / 10) + 1
+        else:
+            wv = cc
+        return torch.where(target < 0.5, wv, torch.ones_like(target))
+
+    def __call__(self, output: torch.Tensor, target: torch.Tensor, **kwargs) -> torch.Tensor:
+        loss = self.criterion(output, target)
+        if self.mode != "none":
+            loss = loss * self._weight(target)
+        return loss if self.reduction == "none" else getattr(torch, self.reduction)(loss)
+
+    def get_name(self) -> str:
+        return self.name or type(self).__name__
+
+
+class MIOU:
+    """awesome/measures/miou.py:29-48 with average='binary'."""
+
+    def __init__(self, invert: bool = False, average: str = "binary", name: Optional[str] = None, **kwargs):
+        if average != "binary":
+            raise ValueError("only average='binary' (the mode the reference runner uses) is implemented")
+        self.invert, self.name = invert, name
+
+    def __call__(self, output: torch.Tensor, target: torch.Tensor, **kwargs) -> torch.Tensor:
+        if output.is_cuda:
+            return K.miou(output.reshape(1, -1).float(), target.reshape(1, -1).float(), 0.5, 0.5, self.invert)[0]
+        o, t = output.reshape(-1).float(), target.reshape(-1).float()
+        if self.invert:
+            o, t = 1.0 - o, 1.0 - t
+        if bool(torch.all(t == 0)):
+            return torch.tensor(0.0)
+        ob, tb = o == 1.0, t == 1.0
+        return (ob & tb).sum().float() / (ob | tb).sum().float()
+
+    def get_name(self) -> str:
+        return self.name or "MIOU"
+
+
+class AwesomeImageLoss:
+    """awesome/measures/awesome_image_loss.py:34-53: crit(seg,t) + alpha*crit(prior,t) [+ penalty]."""
+
+    def __init__(self, criterion=None, prior_criterion=None, alpha=1.0, beta=100.0, gamma=0.1, name=None, **kwargs):
+        self.criterion = criterion or torch.nn.BCELoss()
+        self.prior_criterion = prior_criterion or torch.nn.BCELoss()
+        self.alpha, self.beta, self.gamma, self.name = alpha, beta, gamma, name
+        self.extra_penalty = False  # toggled by the runner (awesome/run/awesome_runner.py:351-371)
+
+    def __call__(self, output: torch.Tensor, target: torch.Tensor, **kwargs) -> torch.Tensor:
+        c = output.shape[1] // 2
+        seg, prior = output[:, :c], output[:, c:]
+        loss = self.criterion(seg, target) + self.alpha * self.prior_criterion(prior, target)
+        if self.extra_penalty:
+            loss = self.gamma * loss + self.beta * torch.mean((prior - (seg > 0.5).float()) ** 2)
+        return loss
+
+    def get_name(self) -> str:
+        return self.name or type(self).__name__
+
+
+class FBMSJointLoss:
+    """awesome/measures/fbms_joint_loss.py:35-59: alpha*crit(seg,t) + clip(beta*SE(prior, seg))."""
+
+    def __init__(self, criterion=None, penalty_criterion=None, alpha=1.0, beta=1.0, clip_penalty=True, name=None, **kwargs):
+        self.criterion = criterion or UnariesWeightedLoss(torch.nn.BCELoss(), mode="sssdms")
+        self.penalty_criterion = penalty_criterion or SE("mean")
+        self.alpha, self.beta, self.clip_penalty, self.name = alpha, beta, clip_penalty, name
+
+    def __call__(self, output: torch.Tensor, target: torch.Tensor, **kwargs) -> torch.Tensor:
+        c = output.shape[1] // 2
+        seg, prior = output[:, :c], output[:, c:]
+        seg_loss = self.alpha * self.criterion(seg, target)
+        pen = self.beta * self.penalty_criterion(prior, seg)
+        if self.clip_penalty and bool(pen > seg_loss):
+            pen = pen * (seg_loss / pen).detach()
+        return seg_loss + pen
+
+    def get_name(self) -> str:
+        return self.name or type(self).__name__
+
+
+def criterion_to_desc(criterion) -> Tuple[str, str, float]:
+    """(loss kind, weight mode, ratio) for the fused kernel, or raise if the criterion has no fused form."""
+    mode, ratio, inner = "none", 1.0, criterion
+    if isinstance(criterion, UnariesWeightedLoss):
+        mode, ratio, inner = criterion.mode, criterion.ratio, criterion.criterion
+    if isinstance(inner, SE):
+        return "se", mode, ratio
+    if isinstance(inner, torch.nn.BCELoss):
+        return "bce", mode, ratio
+    raise TypeError(f"{type(criterion).__name__} has no fused kernel form (supported: SE, BCELoss, UnariesWeightedLoss of those)")

@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""scripts/run.py - config entrypoint for the MI355X hot path, with the reference's surface:
+
+    python scripts/run.py --config-path config/c2_blob256.yaml [--num-epochs N --seed S --device cuda:0 ...]
+
+Mirrors jp-schneider/awesome scripts/run.py:29-79 (argparse + YAML -> config -> runner.build() -> runner.train()).
+The YAML uses the reference's schema (`AwesomeConfig:` root or flat; `__class__` keys ignored) for the fields on the
+hot path: prior_model_type / prior_model_args (dotted type strings, resolved like awesome/util/reflection.py's
+dynamic_import; `awesome.model.convex_net.*` names map to the drop-in modules), dataset_type / dataset_args,
+loss_type / loss_args, agent_args.pretrain_args (num_epochs, lr, reuse_state...), seed, device, output_folder.
+Everything else the reference runner does (tensorboard, plots, UNet joint training) is out of scope.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import yaml  # noqa: E402
+
+ALIASES = {
+    "awesome.model.convex_net.ConvexNextNet": "awesome_amd.model.ConvexNextNet",
+    "awesome.model.convex_net.ConvexNet": "awesome_amd.model.ConvexNet",
+    "awesome.measures.se.SE": "awesome_amd.measures.SE",
+    "awesome.measures.unaries_weighted_loss.UnariesWeightedLoss": "awesome_amd.measures.UnariesWeightedLoss",
+}
+
+
+def dynamic_import(path: str):
+    path = ALIASES.get(path, path)
+    mod, _, name = path.rpartition(".")
+    return getattr(importlib.import_module(mod), name)
+
+
+def strip_class_tags(obj):
+    if isinstance(obj, dict):
+        return {k: strip_class_tags(v) for k, v in obj.items() if k != "__class__"}
+    if isinstance(obj, list):
+        return [strip_class_tags(v) for v in obj]
+    return obj
+
+
+def build_criterion(loss_type, loss_args):
+    import torch
+    if loss_type is None:
+        return None
+    args = dict(loss_args or {})
+    crit = args.get("criterion")
+    if isinstance(crit, dict):  # nested {"type": ..., "args": {...}}
+        args["criterion"] = build_criterion(crit.get("type"), crit.get("args"))
+    elif isinstance(crit, str):
+        args["criterion"] = torch.nn.BCELoss() if crit.endswith("BCELoss") else dynamic_import(crit)()
+    if loss_type.endswith("BCELoss"):
+        return torch.nn.BCELoss()
+    return dynamic_import(loss_type)(**args)
+
+
+def get_config():
+    ap = argparse.ArgumentParser(description="MI355X INR prior fit (awesome-compatible config entrypoint)")
+    ap.add_argument("--config-path", type=str, required=True)
+    ap.add_argument("--num-epochs", type=int, default=None)
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--device", type=str, default=None)
+    ap.add_argument("--output-folder", type=str, default=None)
+    ap.add_argument("--name-experiment", type=str, default=None)
+    args = ap.parse_args()
+    with open(args.config_path) as f:
+        cfg = yaml.safe_load(f)
+    cfg = strip_class_tags(cfg.get("AwesomeConfig", cfg))
+    for k in ("num_epochs", "seed", "device", "output_folder", "name_experiment"):
+        v = getattr(args, k)
+        if v is not None:
+            cfg[k] = v
+    return cfg
+
+
+def main(cfg):
+    import torch
+    import awesome_amd as A
+    from awesome_amd.fitter import BatchedPriorFitter
+    from awesome_amd import parallel
+
+    rank, world, local = parallel.init()
+    device = torch.device(cfg.get("device", "cuda"))
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise SystemExit("this entrypoint drives the MI355X path; no CPU fallback exists (use the reference for CPU runs)")
+    if device.index is None:
+        device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    seed = int(cfg.get("seed", 42))
+    torch.manual_seed(seed)
+
+    model_type = dynamic_import(cfg.get("prior_model_type", "awesome_amd.model.ConvexNextNet"))
+    model_args = dict(cfg.get("prior_model_args") or {})
+    dataset = dynamic_import(cfg.get("dataset_type", "awesome_amd.dataset.SyntheticUnariesDataset"))(**(cfg.get("dataset_args") or {}))
+    pre = dict((cfg.get("agent_args") or {}).get("pretrain_args") or {})
+    num_epochs = int(cfg.get("num_epochs", pre.get("num_epochs", 2000)))
+    criterion = build_criterion(cfg.get("loss_type"), cfg.get("loss_args"))
+    opt_type = cfg.get("optimizer_type", "torch.optim.Adamax").rsplit(".", 1)[-1].lower()
+    opt_args = dict(cfg.get("optimizer_args") or {})
+    fitter = BatchedPriorFitter(lambda: model_type(**model_args), num_epochs=num_epochs, lr=float(opt_args.get("lr", pre.get("lr", 1e-3))),
+                                optimizer=opt_type, weight_decay=float(opt_args.get("weight_decay", 0.0)), criterion=criterion,
+                                plateau=pre.get("plateau", None if pre.get("use_plateau", True) else False),
+                                proper_prior_fit_threshold=float(pre.get("proper_prior_fit_threshold", 0.5)),
+                                proper_prior_fit_retrys=int(pre.get("proper_prior_fit_retrys", 1)),
+                                reuse_state=bool(pre.get("reuse_state", False)),
+                                reuse_state_epochs=int(pre.get("reuse_state_epochs", 200)))
+    mine = list(parallel.shard_range(len(dataset), rank, world))
+    size = dataset.size
+    grid = A.Grid.linspace(size, size, device)
+    unaries = dataset.batch(mine).to(device)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rep = fitter.fit_batch(grid, unaries)
+    torch.cuda.synchronize()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, device)
+    iou_all = parallel.gather_per_image(rep.iou, len(dataset), rank, world)
+    if rank == 0:
+        out_dir = os.path.join(cfg.get("output_folder", "runs"), cfg.get("name_experiment", "inr_fit"))
+        os.makedirs(out_dir, exist_ok=True)
+        torch.save(fitter.prior_cache_state(rep, indices=mine, model_args=model_args), os.path.join(out_dir, "prior_cache_epoch_0.pth"))
+        summary = {"images": len(dataset), "ranks": world, "epochs": num_epochs, "seconds": round(dt, 4),
+                   "fits_per_s": round(len(dataset) / dt, 4), "ForegroundBinaryMIOU_vs_unaries": round(float(iou_all.mean()), 5),
+                   "retries": rep.retries, "output": out_dir}
+        with open(os.path.join(out_dir, "summary.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+        print(json.dumps(summary))
+    parallel.barrier()
+
+
+if __name__ == "__main__":
+    main(get_config())

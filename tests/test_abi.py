@@ -1,0 +1,56 @@
+"""The C-ABI library loads and exports every symbol include/inrfit.h declares (no compute calls: CPU only)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "inrfit.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(inrfit_\w+)\s*\(", src)))
+
+
+def test_header_declares_the_path():
+    names = _declared_functions()
+    for must in ["inrfit_forward", "inrfit_loss_grad", "inrfit_backward", "inrfit_fit", "inrfit_miou", "inrfit_query",
+                 "inrfit_workspace_bytes", "inrfit_strerror"]:
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from awesome_amd import build
+    path = build.build(force=False, verbose=False)  # cross-compiles for gfx950 without a GPU
+    lib = ctypes.CDLL(path)
+    for name in _declared_functions():
+        assert hasattr(lib, name), f"{name} declared in inrfit.h but not exported"
+
+
+def test_binding_matches_header_and_abi_version():
+    from awesome_amd import _lib
+    assert set(_lib.EXPORTS) == set(_declared_functions())
+    lib = _lib.load()
+    ver, maxh, lds = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.inrfit_query(ctypes.byref(ver), ctypes.byref(maxh), ctypes.byref(lds)) == 0
+    assert ver.value == _lib.INRFIT_ABI_VERSION and maxh.value >= 130 and 0 < lds.value <= 160 * 1024
+    md = _lib.InrModelDesc(_lib.INR_MODEL_ICNN, 130, 2, 1)
+    assert lib.inrfit_param_count(ctypes.byref(md)) == 17813
+    assert lib.inrfit_supported(ctypes.byref(md)) == 1
+    md2 = _lib.InrModelDesc(_lib.INR_MODEL_ICNN, 77, 2, 1)
+    assert lib.inrfit_supported(ctypes.byref(md2)) == 0
+    assert lib.inrfit_strerror(-2).decode().startswith("model shape")
+
+
+def test_argument_errors_are_reported_not_crashed():
+    """Null pointers / unsupported shapes return negative codes before anything touches a device."""
+    from awesome_amd import _lib
+    lib = _lib.load()
+    md = _lib.InrModelDesc(_lib.INR_MODEL_ICNN, 77, 2, 1)
+    gd = _lib.InrGridDesc(0, 4, 4, 16, None, None, None, None, 0)
+    assert lib.inrfit_workspace_bytes(ctypes.byref(md), ctypes.byref(gd), 1) == -2  # unsupported shape
+    md = _lib.InrModelDesc(_lib.INR_MODEL_ICNN, 130, 2, 1)
+    assert lib.inrfit_forward(ctypes.byref(md), None, ctypes.byref(gd), 1, None, None, 0, None) == -1  # invalid
+    assert lib.inrfit_workspace_bytes(ctypes.byref(md), ctypes.byref(gd), 0) == -1

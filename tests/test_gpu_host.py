@@ -1,0 +1,101 @@
+"""GPU tests of the host layer: drop-in modules (autograd bridge), BatchedPriorFitter (gate/retry/warm start), run.py."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import inr_oracle as O  # noqa: E402  (checker only)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_module_forward_backward_like_reference_loop(dev, golden_dir):
+    """The stock loop (zero_grad, forward, criterion, backward, Adam.step, enforce_convexity) driven through the drop-in
+    module reproduces the reference trajectory (golden adam10 weights)."""
+    from awesome_amd.model import ConvexNextNet
+    from awesome_amd.measures import SE, UnariesWeightedLoss
+    z = np.load(os.path.join(golden_dir, "icnn_convexnext_h130_c2_l1.npz"))
+    model = ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=1)
+    model.load_state_dict(O.load_npz_state(z, "sd0."))
+    model.to(dev)
+    grid = torch.from_numpy(z["grid"]).to(dev)
+    un = torch.from_numpy(z["unaries"]).to(dev)
+    crit = UnariesWeightedLoss(SE("mean"))
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    losses = []
+    for _ in range(10):
+        opt.zero_grad()
+        out = torch.sigmoid(model(grid))
+        assert out.shape == un.shape
+        loss = crit(out, un)
+        loss.backward()
+        opt.step()
+        model.enforce_convexity()
+        losses.append(float(loss.detach()))
+    np.testing.assert_allclose(np.asarray(losses, np.float32), z["adam.losses"], rtol=2e-5)
+    sd = model.state_dict()
+    for k in sd:
+        np.testing.assert_allclose(sd[k].cpu().numpy(), z["adam10." + k], rtol=2e-4, atol=5e-6, err_msg=k)
+    # (N, C) rows in, (N, 1) out
+    rows = grid[0].reshape(2, -1).t().contiguous()
+    assert model(rows).shape == (rows.shape[0], 1)
+
+
+def test_fitter_gate_retry_and_cache_layout(dev):
+    import awesome_amd as A
+    from awesome_amd.dataset import SyntheticUnariesDataset
+    from awesome_amd.fitter import BatchedPriorFitter
+    from awesome_amd.model import ConvexNextNet
+    torch.manual_seed(0)
+    ds = SyntheticUnariesDataset(n_images=3, size=64, kind="blob")
+    un = ds.batch([0, 1, 2]).to(dev)
+    un[2] = 1.0  # an image without foreground is skipped like the reference does
+    f = BatchedPriorFitter(lambda: ConvexNextNet(n_hidden=130), num_epochs=300, lr=2e-3, optimizer="adam", plateau=False)
+    rep = f.fit_batch(A.Grid.linspace(64, 64, dev), un)
+    assert rep.skipped == [False, False, True]
+    assert float(rep.iou[0]) > 0.9 and float(rep.iou[1]) > 0.9
+    state = f.prior_cache_state(rep, indices=[10, 11, 12], model_args={"n_hidden": 130})
+    assert set(state) == {"model_type", "model_args", "store_device", "cache"} and set(state["cache"]) == {"10", "11"}
+    assert list(state["cache"]["10"].keys()) == list(ConvexNextNet().state_dict().keys())
+    # an impossible threshold forces the retry path: parameters are re-initialised and refitted once
+    f2 = BatchedPriorFitter(lambda: ConvexNextNet(n_hidden=130), num_epochs=20, lr=2e-3, optimizer="adam", plateau=False,
+                            proper_prior_fit_threshold=1.1, proper_prior_fit_retrys=1)
+    rep2 = f2.fit_batch(A.Grid.linspace(64, 64, dev), un[:2].contiguous())
+    assert rep2.retries == [1, 1]
+
+
+def test_fitter_warm_start_chain(dev):
+    import awesome_amd as A
+    from awesome_amd.dataset import convex_blob_unaries
+    from awesome_amd.fitter import BatchedPriorFitter
+    from awesome_amd.model import ConvexNextNet
+    torch.manual_seed(0)
+    base = convex_blob_unaries(64, 1)
+    frames = torch.stack([torch.roll(base, shifts=2 * k, dims=1).reshape(-1) for k in range(3)] * 2).to(dev)  # 2 sequences
+    f = BatchedPriorFitter(lambda: ConvexNextNet(n_hidden=130), num_epochs=300, lr=2e-3, optimizer="adam", plateau=False,
+                           reuse_state=True, reuse_state_epochs=60)
+    rep = f.fit_sequences(A.Grid.linspace(64, 64, dev), frames, seq_ids=[0, 0, 0, 1, 1, 1])
+    assert float(rep.iou.min()) > 0.85   # 60 warm epochs are enough when starting from the previous frame
+
+
+def test_run_py_config_entrypoint(tmp_path):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run.py"), "--config-path",
+                          os.path.join(ROOT, "config", "c1_disc64.yaml"), "--output-folder", str(tmp_path)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    summary = json.loads(out.stdout.strip().splitlines()[-1])
+    assert summary["images"] == 1 and summary["ForegroundBinaryMIOU_vs_unaries"] > 0.98
+    cache = torch.load(os.path.join(summary["output"], "prior_cache_epoch_0.pth"))
+    assert "0" in cache["cache"] and "skip.0.ln.weight" in cache["cache"]["0"]

@@ -1,0 +1,109 @@
+"""Host-side logic that needs no GPU: parameter packing, drop-in module surface, loss objects, synthetic data, sharding."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import awesome_amd as A
+from awesome_amd import parallel
+from awesome_amd.dataset import SyntheticUnariesDataset, convex_blob_mask
+from awesome_amd.measures import MIOU, SE, AwesomeImageLoss, UnariesWeightedLoss, criterion_to_desc
+from awesome_amd.model import ConvexNet, ConvexNextNet
+from oracle import inr_oracle as O
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_pack_unpack_roundtrip_and_layout():
+    spec = A.IcnnSpec(130, 2, 1)
+    assert spec.n_params == 17813
+    torch.manual_seed(0)
+    sd = {k: torch.randn(shp) for k, shp in spec.keys_shapes()}
+    flat = A.pack_state_dict(spec, sd)
+    assert flat.shape == (17813,)
+    back = A.unpack_params(spec, flat)
+    assert all(torch.equal(back[k], sd[k]) for k in sd)
+    assert float(flat[0]) == float(sd["input.weight"][0, 0]) and float(flat[-1]) == float(sd["out.skp.weight"][0, -1])
+    # ConvexNet key names map onto the same vector
+    sd_cn = {A.icnn.CONVEXNET_KEYMAP_INV[k]: v for k, v in sd.items()}
+    assert torch.equal(A.pack_state_dict(spec, sd_cn), flat)
+
+
+def test_dropin_modules_match_reference_init_and_keys(golden_dir):
+    """Seeded construction reproduces the reference module's initial weights bit for bit (fixture: fit_disc64 sd0)."""
+    z = _load(golden_dir, "fit_disc64.npz")
+    torch.manual_seed(0)
+    m = ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=1)
+    sd = m.state_dict()
+    ref = O.load_npz_state(z, "sd0.")
+    assert list(sd.keys()) == list(ref.keys())
+    for k in ref:
+        assert torch.equal(sd[k], ref[k]), k
+    z = _load(golden_dir, "icnn_convexnet_h130_c2.npz")
+    assert list(ConvexNet().state_dict().keys()) == list(O.load_npz_state(z, "sd0.").keys())
+    # enforce_convexity clamps exactly the reference's weights
+    with torch.no_grad():
+        for p in m.parameters():
+            p.fill_(-1.0)
+    m.enforce_convexity()
+    sd = m.state_dict()
+    assert float(sd["skip.0.ln.weight"].min()) == 0.0 and float(sd["out.ln.weight"].min()) == 0.0
+    assert float(sd["skip.0.skp.weight"].max()) == -1.0 and float(sd["input.weight"].max()) == -1.0
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 2, 4, 4))  # CPU tensors are refused: there is no CPU fallback
+
+
+def test_loss_objects_match_reference(golden_dir):
+    z = _load(golden_dir, "losses.npz")
+    out, tgt = torch.from_numpy(z["output"]), torch.from_numpy(z["target"])
+    for mode in ["none", "equal", "ratio", "sssdms"]:
+        for kind, crit in [("se", SE("mean")), ("bce", torch.nn.BCELoss())]:
+            l = UnariesWeightedLoss(crit, mode=mode, ratio=0.35)
+            assert float(l(out, tgt)) == pytest.approx(float(z[f"uwl.{kind}.{mode}"]), rel=1e-6)
+            assert criterion_to_desc(l) == (kind, mode, 0.35)
+    out2, tb = torch.from_numpy(z["output2"]), torch.from_numpy(z["target_bin"])
+    ail = AwesomeImageLoss(alpha=0.7, beta=100.0, gamma=0.1)
+    assert float(ail(out2, tb)) == pytest.approx(float(z["ail.plain"]), rel=1e-6)
+    ail.extra_penalty = True
+    assert float(ail(out2, tb)) == pytest.approx(float(z["ail.penalty"]), rel=1e-6)
+    with pytest.raises(TypeError):
+        criterion_to_desc(ail)
+
+
+def test_miou_object_cpu_matches_reference(golden_dir):
+    z = _load(golden_dir, "miou.npz")
+    m = MIOU(invert=True)
+    for i in range(int(z["n"])):
+        assert float(m(torch.from_numpy(z[f"o{i}"]), torch.from_numpy(z[f"t{i}"]))) == pytest.approx(float(z[f"iou{i}"]), abs=1e-7)
+
+
+def test_synthetic_blob_is_convex_and_deterministic():
+    a, b = convex_blob_mask(256, 3), convex_blob_mask(256, 3)
+    assert np.array_equal(a, b) and 2000 < a.sum() < 30000
+    ys, xs = np.nonzero(a)   # convex: every row/column run of the mask is contiguous
+    for r in np.unique(ys):
+        cols = xs[ys == r]
+        assert cols.max() - cols.min() + 1 == len(cols)
+    ds = SyntheticUnariesDataset(n_images=3, size=64, kind="blob")
+    assert ds.batch([0, 1, 2]).shape == (3, 64 * 64)
+
+
+def test_grid_descriptors_match_reference_grid(golden_dir):
+    z = _load(golden_dir, "grid.npz")
+    g = A.Grid.linspace(7, 5, "cpu")
+    assert np.array_equal(g.xs.numpy(), z["g_7x5"][0, 0]) and np.array_equal(g.ys.numpy(), z["g_7x5"][1, :, 0])
+    g = A.Grid.howto(8, 4, "cpu")
+    ref = O.howto_grid(4, 8)
+    assert torch.equal(g.xs, ref[0, 0, 0]) and torch.equal(g.ys, ref[0, 1, :, 0])
+    e = A.Grid.from_image_grid(torch.zeros(2, 3, 4, 5))
+    assert e.n_points == 20 and e.image_stride == 60
+
+
+def test_sharding_rules():
+    assert [list(parallel.shard_range(10, r, 4)) for r in range(4)] == [[0, 1, 2], [3, 4, 5], [6, 7], [8, 9]]
+    assert sum(len(parallel.shard_range(512, r, 8)) for r in range(8)) == 512
+    owners = [parallel.shard_sequences([30, 5, 12, 12, 7], r, 2) for r in range(2)]
+    assert sorted(owners[0] + owners[1]) == [0, 1, 2, 3, 4] and not set(owners[0]) & set(owners[1])
