@@ -40,6 +40,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-steps", type=int, default=60)
     ap.add_argument("--kernel-iters", type=int, default=200, help="step-kernel launches for the roofline timing")
+    ap.add_argument("--throughput-images", type=int, default=64,
+                    help="also time ONE full fit of this many images per GPU (BASELINE configs[2] = 512/8) and report it "
+                         "under 'throughput_mode' (0 = skip); never part of `value`")
     return ap.parse_args()
 
 
@@ -132,6 +135,29 @@ def main():
                 "kernel": "icnn_step_kernel<130,2,train>", "kernel_us": round(kernel_ms * 1e3, 2),
                 "flop_per_launch": flop_per_launch}
 
+    # ---- throughput mode (extra, not `value`): configs[2]'s per-GPU share, one complete E-step fit of a batch ---------
+    thr = None
+    if args.throughput_images > 0:
+        TB = args.throughput_images
+        tseeds = [1000 + rank * TB + i for i in range(TB)]
+        tun = torch.stack([convex_blob_unaries(S, s).reshape(-1) for s in tseeds]).to(dev)
+        tinit = init[:1].repeat(TB, 1).contiguous()   # same seeded init for every image (weights are per image on device)
+        A.fit(spec, tinit.clone(), grid, tun, 20, lr=2e-3, record_loss=False, want_logits=False)  # warm
+        barrier()
+        t1 = time.perf_counter()
+        tres = A.fit(spec, tinit.clone(), grid, tun, E, lr=2e-3, loss="se", optimizer="adam", clamp=True, record_loss=False,
+                     want_logits=True)
+        barrier()
+        tdt = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([tdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tdt = float(tt.item())
+        tiou = A.miou((torch.sigmoid(tres.logits) > 0.5).float(), (tun > 0.5).float(), invert=True)
+        thr = {"images_per_gpu": TB, "fits_per_s": round(TB * world / tdt, 4), "seconds": round(tdt, 3),
+               "us_per_optimizer_step_per_image": round(tdt / E / TB * 1e6, 2), "miou_vs_unaries": round(float(tiou.mean()), 5),
+               "note": "one complete E-step fit of the batch; all images step together (BASELINE configs[2] per-GPU share)"}
+
     out = None
     if rank == 0:
         fits = args.steps * B * world
@@ -147,6 +173,8 @@ def main():
             "us_per_optimizer_step": round(elapsed / args.steps / E * 1e6, 2),
             "roofline": roofline,
         }
+        if thr is not None:
+            out["throughput_mode"] = thr
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, init[0].cpu(), unaries[0].cpu(), spec)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
