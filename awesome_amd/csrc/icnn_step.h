@@ -20,6 +20,8 @@
 #include <stdint.h>
 #include <math.h>
 
+#include <type_traits>
+
 #include "inrfit.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -95,16 +97,18 @@ struct Cfg {
     static constexpr int P = P_SO + C;
 };
 
-// run-time description of the parameter image (same numbers as Cfg<H,C>) for the untemplated kernels
+// run-time description of the parameter image (same numbers as Cfg<H,C> / Cfg2<H,C>) for the untemplated kernels
 struct ImgMap {
-    int H, C, HM, S, PT, floats;
-    int off_sc, off_wine, off_win, off_bin, off_floor, off_wo, off_wct, off_w;
+    int H, C, L, HM, S, PT, floats;
+    int off_sc, off_wine, off_win, off_bin, off_floor, off_wo;
+    int off_wct[2], off_w[2];   // per hidden layer
     int ext[4];
-    int p_bin, p_w1, p_b1, p_s1, p_wo, p_bo, p_so, P;
+    int p_bin, p_wo, p_bo, p_so, P;
+    int p_w[2], p_b[2], p_s[2]; // flat offsets of skip.k.ln.weight / ln.bias / skp.weight
 };
 
 // Image slots of flat parameter j: every parameter has a primary slot; W_in/b_in of the leftover units and
-// W1[:, HM+u] are mirrored into a second table.  Returns the number of slots (1 or 2).
+// W_k[:, HM+u] are mirrored into a second table.  Returns the number of slots (1 or 2).
 __device__ __forceinline__ int image_slots(const ImgMap& m, int j, int (&slot)[2]) {
     if (j < m.p_bin) {  // input.weight [H][C] -> layer-0 A operand rows 0..C-1 (+ k-group TM table for leftovers)
         const int i = j / m.C, c = j - i * m.C;
@@ -115,7 +119,7 @@ __device__ __forceinline__ int image_slots(const ImgMap& m, int j, int (&slot)[2
         }
         return 1;
     }
-    if (j < m.p_w1) {  // input.bias -> layer-0 A operand row C
+    if (j < m.p_w[0]) {  // input.bias -> layer-0 A operand row C
         const int i = j - m.p_bin;
         slot[0] = m.off_wine + m.C * m.PT + i;
         if (i >= m.HM) {
@@ -124,25 +128,27 @@ __device__ __forceinline__ int image_slots(const ImgMap& m, int j, int (&slot)[2
         }
         return 1;
     }
-    if (j < m.p_b1) {  // skip.0.ln.weight [H][H]
-        const int q = j - m.p_w1;
-        const int o = q / m.H, i = q - o * m.H;
-        slot[0] = m.off_w + o * m.S + i;
-        if (i >= m.HM) {
-            slot[1] = m.off_wct + (i - m.HM) * m.PT + o;
-            return 2;
+    for (int k = 0; k < m.L; ++k) {
+        if (j < m.p_b[k]) {  // skip.k.ln.weight [H][H]
+            const int q = j - m.p_w[k];
+            const int o = q / m.H, i = q - o * m.H;
+            slot[0] = m.off_w[k] + o * m.S + i;
+            if (i >= m.HM) {
+                slot[1] = m.off_wct[k] + (i - m.HM) * m.PT + o;
+                return 2;
+            }
+            return 1;
         }
-        return 1;
-    }
-    if (j < m.p_s1) {
-        slot[0] = m.off_w + (j - m.p_b1) * m.S + m.ext[0];
-        return 1;
-    }
-    if (j < m.p_wo) {  // skip.0.skp.weight [H][C]
-        const int q = j - m.p_s1;
-        const int o = q / m.C, c = q - o * m.C;
-        slot[0] = m.off_w + o * m.S + m.ext[1 + c];
-        return 1;
+        if (j < m.p_s[k]) {  // skip.k.ln.bias
+            slot[0] = m.off_w[k] + (j - m.p_b[k]) * m.S + m.ext[0];
+            return 1;
+        }
+        if (j < m.p_s[k] + m.H * m.C) {  // skip.k.skp.weight [H][C]
+            const int q = j - m.p_s[k];
+            const int o = q / m.C, c = q - o * m.C;
+            slot[0] = m.off_w[k] + o * m.S + m.ext[1 + c];
+            return 1;
+        }
     }
     if (j < m.p_bo) {
         slot[0] = m.off_wo + (j - m.p_wo);

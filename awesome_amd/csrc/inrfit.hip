@@ -21,6 +21,7 @@
 //     float4 writes, conflict-free strides), the 9x9 output tiles are split over the 4 waves;
 //   * fp32 everywhere (exact-f32 MFMA == fmaf chain), fixed-order reductions, no atomics: results are reproducible.
 #include "icnn_step.h"
+#include "icnn_step2.h"
 
 namespace {
 
@@ -45,7 +46,7 @@ struct UpdArgs {
     float one_minus_b1, one_minus_b2;
     int hist_idx, hist_stride;
     int mode;             // 0 = optimizer step, 1 = write reduced grads + loss only
-    int clamp_lo0, clamp_hi0, clamp_lo1, clamp_hi1;  // flat ranges projected onto >= 0
+    int clamp_lo[3], clamp_hi[3];  // flat ranges projected onto >= 0 (ln.weight of every hidden layer, out.ln.weight)
 };
 
 constexpr int UPD_PARAMS = 64;   // parameters per block (one 256-B line per slab row)
@@ -135,7 +136,12 @@ __global__ __launch_bounds__(UPD_PARAMS / 4 * UPD_GROUPS) void icnn_update_kerne
         const float clr = (float)((double)lr / bc1);
         p = __fadd_rn(p, __fdiv_rn(__fmul_rn(-clr, m), v));
     }
-    if (u.opt.clamp && ((j >= u.clamp_lo0 && j < u.clamp_hi0) || (j >= u.clamp_lo1 && j < u.clamp_hi1))) p = fmaxf(p, 0.f);
+    if (u.opt.clamp) {
+        bool in = false;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) in = in || (j >= u.clamp_lo[k] && j < u.clamp_hi[k]);
+        if (in) p = fmaxf(p, 0.f);
+    }
     u.params[(size_t)img * u.P + j] = p;
     {
         int slot[2];
@@ -270,38 +276,50 @@ __global__ __launch_bounds__(256) void miou_kernel(const float* __restrict__ out
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 struct KernelEntry {
-    int h, c;
+    int h, c, l;
     void (*train)(const StepArgs);
     void (*fwd)(const StepArgs);
     int lds_bytes;
     int P;
-    int clamp_lo0, clamp_hi0, clamp_lo1, clamp_hi1;
     ImgMap img;
 };
 
 template <int H, int C>
-constexpr KernelEntry make_entry() {
+KernelEntry make_entry() {
     using G = Cfg<H, C>;
     ImgMap m{};
-    m.H = H; m.C = C; m.HM = G::HM; m.S = G::S; m.PT = G::PT; m.floats = G::IMG_FLOATS;
+    m.H = H; m.C = C; m.L = 1; m.HM = G::HM; m.S = G::S; m.PT = G::PT; m.floats = G::IMG_FLOATS;
     m.off_sc = G::OFF_SC; m.off_wine = G::OFF_WINE; m.off_win = G::OFF_WIN; m.off_bin = G::OFF_BIN;
-    m.off_floor = G::OFF_FLOOR; m.off_wo = G::OFF_WO; m.off_wct = G::OFF_WCT; m.off_w = G::OFF_W;
+    m.off_floor = G::OFF_FLOOR; m.off_wo = G::OFF_WO; m.off_wct[0] = G::OFF_WCT; m.off_w[0] = G::OFF_W;
     for (int e = 0; e < 4; ++e) m.ext[e] = e < G::NEXT ? G::ext_pos(e) : 0;
-    m.p_bin = G::P_BIN; m.p_w1 = G::P_W1; m.p_b1 = G::P_B1; m.p_s1 = G::P_S1; m.p_wo = G::P_WO; m.p_bo = G::P_BO;
+    m.p_bin = G::P_BIN; m.p_w[0] = G::P_W1; m.p_b[0] = G::P_B1; m.p_s[0] = G::P_S1; m.p_wo = G::P_WO; m.p_bo = G::P_BO;
     m.p_so = G::P_SO; m.P = G::P;
-    return KernelEntry{H, C, icnn_step_kernel<H, C, true>, icnn_step_kernel<H, C, false>, G::LDS_BYTES, G::P,
-                       G::P_W1, G::P_W1 + H * H, G::P_WO, G::P_WO + H, m};
+    return KernelEntry{H, C, 1, icnn_step_kernel<H, C, true>, icnn_step_kernel<H, C, false>, G::LDS_BYTES, G::P, m};
+}
+
+template <int H, int C>
+KernelEntry make_entry2() {
+    using G = Cfg2<H, C>;
+    ImgMap m{};
+    m.H = H; m.C = C; m.L = 2; m.HM = G::HM; m.S = G::S; m.PT = G::PT; m.floats = G::IMG_FLOATS;
+    m.off_sc = G::OFF_SC; m.off_wine = G::OFF_WINE; m.off_win = G::OFF_WIN; m.off_bin = G::OFF_BIN;
+    m.off_floor = G::OFF_FLOOR; m.off_wo = G::OFF_WO; m.off_wct[0] = G::OFF_WCT0; m.off_wct[1] = G::OFF_WCT1;
+    m.off_w[0] = G::OFF_W0; m.off_w[1] = G::OFF_W1;
+    for (int e = 0; e < 4; ++e) m.ext[e] = e < G::NEXT ? G::ext_pos(e) : 0;
+    m.p_bin = G::P_BIN; m.p_w[0] = G::P_W1; m.p_b[0] = G::P_B1; m.p_s[0] = G::P_S1; m.p_w[1] = G::P_W2; m.p_b[1] = G::P_B2;
+    m.p_s[1] = G::P_S2; m.p_wo = G::P_WO; m.p_bo = G::P_BO; m.p_so = G::P_SO; m.P = G::P;
+    return KernelEntry{H, C, 2, icnn2_step_kernel<H, C, true>, icnn2_step_kernel<H, C, false>, G::LDS_BYTES, G::P, m};
 }
 
 const KernelEntry kEntries[] = {
-    make_entry<130, 2>(), make_entry<130, 3>(), make_entry<64, 2>(), make_entry<64, 3>(),
-    make_entry<32, 2>(),  make_entry<32, 3>(),
+    make_entry<130, 2>(),  make_entry<130, 3>(),  make_entry<64, 2>(),  make_entry<64, 3>(),  make_entry<32, 2>(),
+    make_entry<32, 3>(),   make_entry2<130, 2>(), make_entry2<130, 3>(), make_entry2<64, 2>(), make_entry2<64, 3>(),
 };
 
 const KernelEntry* find_entry(const InrModelDesc* m) {
-    if (!m || m->kind != INR_MODEL_ICNN || m->n_layers != 1) return nullptr;
+    if (!m || m->kind != INR_MODEL_ICNN) return nullptr;
     for (const auto& e : kEntries)
-        if (e.h == m->n_hidden && e.c == m->in_features) return &e;
+        if (e.h == m->n_hidden && e.c == m->in_features && e.l == m->n_layers) return &e;
     return nullptr;
 }
 
@@ -555,10 +573,13 @@ int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const
     u.one_minus_b1 = (float)(1.0 - (double)opt->beta1);
     u.one_minus_b2 = (float)(1.0 - (double)opt->beta2);
     u.mode = 0;
-    u.clamp_lo0 = e->clamp_lo0;
-    u.clamp_hi0 = e->clamp_hi0;
-    u.clamp_lo1 = e->clamp_lo1;
-    u.clamp_hi1 = e->clamp_hi1;
+    for (int k = 0; k < 3; ++k) u.clamp_lo[k] = u.clamp_hi[k] = 0;
+    for (int k = 0; k < e->img.L; ++k) {
+        u.clamp_lo[k] = e->img.p_w[k];
+        u.clamp_hi[k] = e->img.p_w[k] + e->img.H * e->img.H;
+    }
+    u.clamp_lo[2] = e->img.p_wo;
+    u.clamp_hi[2] = e->img.p_wo + e->img.H;
     const dim3 ugrid((e->P + 1 + UPD_PARAMS - 1) / UPD_PARAMS, n_images);
     for (int it = 0; it < steps; ++it) {
         if ((rc = launch_step(e, w, true, grid, targets, loss->kind, n_images, nullptr, s))) return rc;

@@ -173,7 +173,7 @@ def _check_dev(t: Tensor, name: str) -> Tensor:
 
 def _check_spec(spec: IcnnSpec) -> None:
     if not spec.supported():
-        raise L.InrfitError(f"no compiled kernel for {spec} (built: n_hidden in {{32,64,130}}, in_features in {{2,3}}, L=1)")
+        raise L.InrfitError(f"no compiled kernel for {spec} (built: n_hidden in {{32,64,130}} x in_features in {{2,3}} for L=1; n_hidden in {{64,130}} for L=2)")
 
 
 def _workspace(spec: IcnnSpec, grid: Grid, n_images: int) -> Tensor:

@@ -27,7 +27,8 @@ def _spec_from_sd(amd, p):
     return amd.IcnnSpec(n_hidden=h, in_features=c, n_layers=O.icnn_num_layers(p))
 
 
-L1_CASES = ["convexnet_h130_c2", "convexnext_h130_c2_l1", "convexnext_h130_c3_l1", "convexnext_h32_c2_l1"]
+L1_CASES = ["convexnet_h130_c2", "convexnext_h130_c2_l1", "convexnext_h130_c3_l1", "convexnext_h32_c2_l1",
+            "convexnext_h130_c2_l2", "convexnext_h64_c3_l2"]   # all golden model shapes, one and two hidden skip layers
 
 
 @pytest.mark.parametrize("name", L1_CASES)
