@@ -340,30 +340,38 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
 
         // ---- layer 0: all z0ext tiles up front (TM products + relu on the matrix pipe, last k-group on the VALU) --------
         const float xe = g < C ? x[g < C ? g : 0] : (g == C ? 1.f : 0.f);
-        f32x4 z0[KG];
-        {
+        // z0 main tiles are cheap to rebuild (TM single-k-step products + relu), so they are NOT kept across the backward
+        // pass: they are recomputed when layer 1's dW operands are staged.
+        auto z0_main = [&](f32x4 (&z)[KG]) {
             float wie[TM];
 #pragma unroll
             for (int t = 0; t < TM; ++t) wie[t] = WinE[g * PT + 16 * t + l15];
+            OPERAND_FENCE();
 #pragma unroll
-            for (int t = 0; t < TM; ++t) z0[t] = MFMA16(wie[t], xe, (f32x4{0.f, 0.f, 0.f, 0.f}));
+            for (int t = 0; t < TM; ++t) z[t] = MFMA16(wie[t], xe, (f32x4{0.f, 0.f, 0.f, 0.f}));
+            MFMA_STEP_FENCE();
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[t][r] = fmaxf(z[t][r], 0.f);
+        };
+        f32x4 z0last;  // last k-group of z0ext: leftover hidden units (lane group 0) + ext inputs (lane groups 1-2)
+        {
             const int q = 4 * g;
             f32x4 v = *(const f32x4*)&binT[q];
 #pragma unroll
             for (int c = 0; c < C; ++c) v += *(const f32x4*)&WinT[c * 16 + q] * x[c];
             const f32x4 fl = *(const f32x4*)&floorT[q];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z0[TM][r] = fmaxf(v[r], fl[r]);
-#pragma unroll
-            for (int t = 0; t < TM; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) z0[t][r] = fmaxf(z0[t][r], 0.f);
+            for (int r = 0; r < 4; ++r) z0last[r] = fmaxf(v[r], fl[r]);
         }
         // ---- layer 1 (needs only the W1 image; the W2 re-fetch of the previous chunk may still be in flight) -------------
         f32x4 z1[KG];
         float la[HRA], z1l[HRA];
         {
-            f32x4 acc[TM];
+            f32x4 z0[KG], acc[TM];
+            z0_main(z0);
+            z0[TM] = z0last;
             gemm_fwd(W0, z0, acc, la);
 #pragma unroll
             for (int t = 0; t < TM; ++t)
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
         for (int u = 0; u < HR; ++u) z1l[u] = fmaxf(sum_over_groups(la[u]), 0.f);
         // last k-group of z1ext: lane group 0 = leftover units, lane groups 1-2 = the same ext inputs as in z0ext
 #pragma unroll
-        for (int r = 0; r < 4; ++r) z1[TM][r] = g == 0 ? (r < HR ? z1l[r < HRA ? r : 0] : 0.f) : z0[TM][r];
+        for (int r = 0; r < 4; ++r) z1[TM][r] = g == 0 ? (r < HR ? z1l[r < HRA ? r : 0] : 0.f) : z0last[r];
         __syncthreads();  // (A) W2 image complete in LDS (re-fetch waited for by every wave's vmcnt(0) at this barrier)
 
         // ---- layer 2 ---------------------------------------------------------------------------------------------------
@@ -462,6 +470,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
                 const float d = sum_over_groups(dz1l[u]);
                 dz1l[u] = z1l[u] > 0.f ? d : 0.f;
             }
+            __syncthreads();  // (B) every wave is done with the W2 image: its region becomes the stage
+            stage(acc2, dz2l, z1);  // staged early so that dz2 and z1 leave the register file before the next product
             // ---- backward through layer 1 (W1 image), transposed output; layer-0 gradient wave-locally ----------------------
             {
                 f32x4 dz0[TM];
@@ -503,19 +513,22 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
                 for (int u = 0; u < HR; ++u) {
                     const float d = sum_over_groups(dz0l[u]);
                     if (g == 0) {
-                        const float dm = z0[TM][u] > 0.f ? d : 0.f;
+                        const float dm = z0last[u] > 0.f ? d : 0.f;
                         dL0l[u][0] += dm;
 #pragma unroll
                         for (int c = 0; c < C; ++c) dL0l[u][1 + c] = fmaf(dm, x[c], dL0l[u][1 + c]);
                     }
                 }
             }
-            __syncthreads();  // (B) every wave is done with the W2 image: its region becomes the stage
-            stage(acc2, dz2l, z1);
             __syncthreads();  // (C)
             dw_phase(dWb, dWlb);
             __syncthreads();  // (D)
-            stage(dz1, dz1l, z0);
+            {
+                f32x4 z0[KG];
+                z0_main(z0);
+                z0[TM] = z0last;
+                stage(dz1, dz1l, z0);
+            }
             __syncthreads();  // (E)
             dw_phase(dWa, dWla);
             __syncthreads();  // (F)

@@ -15,16 +15,18 @@ def main():
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--fit-steps", type=int, default=0)
+    ap.add_argument("--layers", type=int, default=1)
+    ap.add_argument("--features", type=int, default=2)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    spec = A.IcnnSpec(130, 2, 1)
+    spec = A.IcnnSpec(130, a.features, a.layers)
     torch.manual_seed(0)
-    p0 = ConvexNextNet().flat_parameters().to(dev)
+    p0 = ConvexNextNet(in_features=a.features, n_hidden_layers=a.layers).flat_parameters().to(dev)
     for S in a.sizes:
         for B in a.images:
             un = torch.stack([convex_blob_unaries(S, s).reshape(-1) for s in range(B)]).to(dev)
             params = p0[None].repeat(B, 1).contiguous()
-            grid = A.Grid.linspace(S, S, dev)
+            grid = A.Grid.linspace(S, S, dev, torch.full((B,), 0.3, device=dev) if a.features == 3 else None)
             ws = A.icnn.step_only(spec, params, grid, un, 10)
             torch.cuda.synchronize()
             best = 1e9
@@ -33,7 +35,8 @@ def main():
                 e0.record(); A.icnn.step_only(spec, params, grid, un, a.iters, workspace=ws); e1.record()
                 torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1) / a.iters * 1e3)
-            flop = 3 * 35104 * S * S * B
+            h, c, L = 130, a.features, a.layers
+            flop = 3 * (2 * h * c + 2 * h + L * (2 * h * h + 2 * h * c + 2 * h) + 2 * h + 2 * c + 1) * S * S * B   # ~3 x forward flops
             line = f"size {S:4d} images {B:3d}: step kernel {best:9.2f} us  {flop / best / 1e6:7.2f} TFLOP/s ({flop / best / 1e6 / 157.3:.3f} of peak)"
             if a.fit_steps:
                 pr = params.clone()
