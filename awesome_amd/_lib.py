@@ -58,7 +58,7 @@ EXPORTS = {
                                    C.POINTER(InrLossDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                    C.c_void_p]),
     "inrfit_backward": (C.c_int, [C.POINTER(InrModelDesc), C.c_void_p, C.POINTER(InrGridDesc), C.c_void_p, C.c_int,
-                                  C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "inrfit_step_only": (C.c_int, [C.POINTER(InrModelDesc), C.c_void_p, C.POINTER(InrGridDesc), C.c_void_p,
                                    C.POINTER(InrLossDesc), C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "inrfit_fit": (C.c_int, [C.POINTER(InrModelDesc), C.c_void_p, C.c_void_p, C.POINTER(InrGridDesc), C.c_void_p,

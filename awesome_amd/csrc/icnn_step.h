@@ -164,6 +164,7 @@ struct StepArgs {
     const float* coef;     // [n_images][2] c_fg, c_bg (TRAIN)
     float* slabs;          // [n_images][wgs][PS]      (TRAIN)
     float* logits;         // [n_images][N] or null
+    float* dcoords;        // [n_images][C][N] dL/dcoords (DX kernels only)
     InrGridDesc grid;
     long long N;
     int n_images, wgs, PS, loss_kind;
@@ -247,8 +248,10 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP(k)
 #endif
 
-template <int H, int C, bool TRAIN>
+// DX: additionally write dL/d(coordinates) (needed when the ICNN sits behind a learned deformation of the grid).
+template <int H, int C, bool TRAIN, bool DX = false>
 __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs a) {
+    static_assert(!DX || TRAIN, "coordinate gradients are a by-product of the backward pass");
     using G = Cfg<H, C>;
     constexpr int TM = G::TM, KG = G::KG, HM = G::HM, HR = G::HR, S = G::S, PT = G::PT, RPW = G::RPW, NEXT = G::NEXT;
     constexpr int HRA = HR > 0 ? HR : 1;  // array extent (zero-length arrays are not allowed)
@@ -545,6 +548,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
             // this wave's points 4g+r, columns = hidden unit 16t + l15 - which is the A operand of the layer-0
             // gradient product dW_in = dZ0^T . (1, x), so that product needs no staging and no barrier.
             f32x4 dz0[TM];
+            f32x4 dzx = f32x4{0.f, 0.f, 0.f, 0.f};  // DX: same product for the columns of k-group TM (skip-path inputs)
+            float bqx[2] = {0.f, 0.f};
             float dz0l[HRA];
 #pragma unroll
             for (int u = 0; u < HRA; ++u) dz0l[u] = 0.f;
@@ -561,6 +566,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 const float* br = b_row(0);
 #pragma unroll
                 for (int t = 0; t < TM; ++t) bq[0][t] = br[16 * t];
+                if (DX) bqx[0] = br[16 * TM];
 #pragma unroll
                 for (int u = 0; u < HR; ++u) wcq[0][u] = *(const f32x4*)(WcT + u * PT + 4 * g);
             }
@@ -571,6 +577,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                     const float* br = b_row(ks + 1);
 #pragma unroll
                     for (int t = 0; t < TM; ++t) bq[(ks + 1) & 1][t] = br[16 * t];
+                    if (DX) bqx[(ks + 1) & 1] = br[16 * TM];
                 }
                 if (r == 0 && (tk + 1) * 4 < KS) {
 #pragma unroll
@@ -581,6 +588,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
 #pragma unroll
                 for (int t = 0; t < TM; ++t)  // D = dZ0 with POINTS on the rows
                     dz0[t] = MFMA16(bop, bq[ks & 1][t], ks == 0 ? (f32x4{0.f, 0.f, 0.f, 0.f}) : dz0[t]);
+                if (DX) dzx = MFMA16(bop, bqx[ks & 1], dzx);
                 MFMA_STEP_FENCE();
                 if (r == 1 && tk + 1 < TM) dz1_tile(tk + 1);  // next tile's dz1 + staging, in the shadow of the MFMAs
                 if (r == 3 || ks == KS - 1) {  // leftover hidden inputs: dz0l[u] += W1[:, HM+u] . dz1 over this tile
@@ -624,14 +632,49 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 }
             }
             // leftover rows of the layer-0 gradient (lane group 0, VALU)
+            float hx[C];  // DX: the contributions that live per point on lane l15: s_o dy + W_in[HM+u] dz0l[u]
+#pragma unroll
+            for (int c = 0; c < C; ++c) hx[c] = s_o[c] * dy;
 #pragma unroll
             for (int u = 0; u < HR; ++u) {
                 const float d = sum_over_groups(dz0l[u]);
+                // position HM + u lives in lane group 0, k-step u (DX needs it in every lane group)
+                const float z0u = DX ? __shfl(z0[TM][u], l15) : z0[TM][u];
+                const float dm = z0u > 0.f ? d : 0.f;
+                if (DX) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) hx[c] = fmaf(WinT[c * 16 + u], dm, hx[c]);
+                }
                 if (g == 0) {
-                    const float dm = z0[TM][u] > 0.f ? d : 0.f;  // position HM + u lives in lane group 0, k-step u
                     dL0l[u][0] += dm;
 #pragma unroll
                     for (int c = 0; c < C; ++c) dL0l[u][1 + c] = fmaf(dm, x[c], dL0l[u][1 + c]);
+                }
+            }
+            if (DX) {
+                // dL/dx_c of point 4g + r: sum over hidden units (lanes l15, tiles t) of W_in[.,c] dz0, plus the skip
+                // path (column ext_pos(1+c) of the transposed product dzx), plus the per-point terms of that point.
+                float part[4][C];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) part[r][c] = (l15 == G::ext_pos(1 + c) - HM) ? dzx[r] : 0.f;
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const float w = WinE[c * PT + 16 * t + l15];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) part[r][c] = fmaf(w, dz0[t][r], part[r][c]);
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pp = chunk * SP + wave * 16 + 4 * g + r;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const float v = sum_over_points(part[r][c]) + __shfl(hx[c], 4 * g + r);
+                        if (l15 == 0 && pp < (int)N) a.dcoords[((size_t)img * C + c) * N + pp] = v;
+                    }
                 }
             }
             STAMP(5);

@@ -54,8 +54,9 @@ struct Cfg2 {
     static constexpr int P = P_SO + C;
 };
 
-template <int H, int C, bool TRAIN>
+template <int H, int C, bool TRAIN, bool DX = false>
 __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArgs a) {
+    static_assert(!DX || TRAIN, "coordinate gradients are a by-product of the backward pass");
     using G = Cfg2<H, C>;
     constexpr int TM = G::TM, KG = G::KG, HM = G::HM, HR = G::HR, S = G::S, PT = G::PT, RPW = G::RPW, NEXT = G::NEXT;
     constexpr int HRA = HR > 0 ? HR : 1;
@@ -184,8 +185,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
     // B-operand layout, feeds the next backward product); SWAP = true: transposed (rows = points), feeds the layer-0
     // gradient product.  outl[u]: leftover hidden inputs (partial over this lane group's positions).
     auto gemm_bwd = [&](auto swap_tag, const float* Wl, const float* WcTl, const f32x4 (&dz)[TM], const float (&dzl)[HRA],
-                        f32x4 (&out)[TM], float (&outl)[HRA]) {
+                        f32x4 (&out)[TM], float (&outl)[HRA], f32x4& outx) {
         constexpr bool SWAP = decltype(swap_tag)::value;
+        float bqx[2] = {0.f, 0.f};  // DX: the columns of k-group TM (skip-path inputs) as one more output tile
+        outx = f32x4{0.f, 0.f, 0.f, 0.f};
         constexpr int KS = 4 * TM + HR;
         const float* const wb = Wl + l15;
 #pragma unroll
@@ -201,6 +204,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
             const float* br = b_row(0);
 #pragma unroll
             for (int t = 0; t < TM; ++t) bq[0][t] = br[16 * t];
+            if (DX) bqx[0] = br[16 * TM];
 #pragma unroll
             for (int u = 0; u < HR; ++u) wcq[0][u] = *(const f32x4*)(WcTl + u * PT + 4 * g);
         }
@@ -211,6 +215,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
                 const float* br = b_row(ks + 1);
 #pragma unroll
                 for (int t = 0; t < TM; ++t) bq[(ks + 1) & 1][t] = br[16 * t];
+                if (DX) bqx[(ks + 1) & 1] = br[16 * TM];
             }
             if (r == 0 && (tk + 1) * 4 < KS) {
 #pragma unroll
@@ -223,6 +228,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
                 const f32x4 c0 = ks == 0 ? (f32x4{0.f, 0.f, 0.f, 0.f}) : out[t];
                 out[t] = SWAP ? MFMA16(bop, bq[ks & 1][t], c0) : MFMA16(bq[ks & 1][t], bop, c0);
             }
+            if (DX) outx = SWAP ? MFMA16(bop, bqx[ks & 1], outx) : MFMA16(bqx[ks & 1], bop, outx);
             MFMA_STEP_FENCE();
             if (r == 3 || ks == KS - 1) {
 #pragma unroll
@@ -460,7 +466,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
             // ---- backward through layer 2 (W2 image): dz1 in the B-operand layout, masked by z1 -----------------------------
             f32x4 dz1[TM];
             float dz1l[HRA];
-            gemm_bwd(std::false_type{}, W1, smem + G::OFF_WCT1, acc2, dz2l, dz1, dz1l);
+            f32x4 dzx2;  // DX: skip-path input gradient of layer 2 (rows = slots of k-group TM, columns = points)
+            gemm_bwd(std::false_type{}, W1, smem + G::OFF_WCT1, acc2, dz2l, dz1, dz1l, dzx2);
 #pragma unroll
             for (int t = 0; t < TM; ++t)
 #pragma unroll
@@ -476,7 +483,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
             {
                 f32x4 dz0[TM];
                 float dz0l[HRA];
-                gemm_bwd(std::true_type{}, W0, smem + G::OFF_WCT0, dz1, dz1l, dz0, dz0l);
+                f32x4 dzx1;  // DX: skip-path input gradient of layer 1 (rows = points, columns = slots of k-group TM)
+                gemm_bwd(std::true_type{}, W0, smem + G::OFF_WCT0, dz1, dz1l, dz0, dz0l, dzx1);
                 float wie[TM];
 #pragma unroll
                 for (int t = 0; t < TM; ++t) wie[t] = WinE[g * PT + 16 * t + l15];
@@ -509,14 +517,54 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
                     for (int t = 0; t < TM; ++t) dL0[t] = MFMA16(dz0[t][r], bfe[r], dL0[t]);
                     MFMA_STEP_FENCE();
                 }
+                float hx[C];  // DX: per-point terms on lane l15: s_o dy + layer-2 skip path + W_in[HM+u] dz0l[u]
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    hx[c] = s_o[c] * dy;
+                    if (DX) {  // layer-2 skip term: row ext_pos(1+c) - HM = 4*gc + rc of the (rows = slots) tile dzx2
+                        constexpr int dummy = 0;
+                        (void)dummy;
+                        const int slot = G::ext_pos(1 + c) - HM;
+                        hx[c] += sum_over_groups(g == (slot >> 2) ? dzx2[slot & 3] : 0.f);
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < HR; ++u) {
                     const float d = sum_over_groups(dz0l[u]);
+                    const float z0u = DX ? __shfl(z0last[u], l15) : z0last[u];
+                    const float dm = z0u > 0.f ? d : 0.f;
+                    if (DX) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) hx[c] = fmaf(WinT[c * 16 + u], dm, hx[c]);
+                    }
                     if (g == 0) {
-                        const float dm = z0last[u] > 0.f ? d : 0.f;
                         dL0l[u][0] += dm;
 #pragma unroll
                         for (int c = 0; c < C; ++c) dL0l[u][1 + c] = fmaf(dm, x[c], dL0l[u][1 + c]);
+                    }
+                }
+                if (DX) {
+                    float part[4][C];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < C; ++c) part[r][c] = (l15 == G::ext_pos(1 + c) - HM) ? dzx1[r] : 0.f;
+#pragma unroll
+                    for (int t = 0; t < TM; ++t)
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            const float w = WinE[c * PT + 16 * t + l15];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) part[r][c] = fmaf(w, dz0[t][r], part[r][c]);
+                        }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int pp = chunk * SP + wave * 16 + 4 * g + r;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            const float v = sum_over_points(part[r][c]) + __shfl(hx[c], 4 * g + r);
+                            if (l15 == 0 && pp < (int)N) a.dcoords[((size_t)img * C + c) * N + pp] = v;
+                        }
                     }
                 }
             }
@@ -644,7 +692,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
         auto wsum = [&](int i) { return ((stA[i] + stA[WSTR + i]) + stA[2 * WSTR + i]) + stA[3 * WSTR + i]; };
         for (int i = tid; i < H; i += WG_THREADS) slab[G::P_WO + i] = wsum(SC_DWO + i);
         for (int i = tid; i < 2 * HR * PT; i += WG_THREADS) {
-            const int layer = i / (HR * PT), q = i - layer * (HR * PT);
+            const int layer = i / (HRA * PT), q = i - layer * (HRA * PT);  // (loop is empty when HR == 0)
             const int u = q / PT, pos = q - u * PT;
             const float v = wsum((layer ? SC_DWLB : SC_DWLA) + q);
             const int p_w = layer ? G::P_W2 : G::P_W1, p_b = layer ? G::P_B2 : G::P_B1, p_s = layer ? G::P_S2 : G::P_S1;

@@ -278,6 +278,7 @@ __global__ __launch_bounds__(256) void miou_kernel(const float* __restrict__ out
 struct KernelEntry {
     int h, c, l;
     void (*train)(const StepArgs);
+    void (*train_dx)(const StepArgs);  // also writes dL/dcoords
     void (*fwd)(const StepArgs);
     int lds_bytes;
     int P;
@@ -294,7 +295,8 @@ KernelEntry make_entry() {
     for (int e = 0; e < 4; ++e) m.ext[e] = e < G::NEXT ? G::ext_pos(e) : 0;
     m.p_bin = G::P_BIN; m.p_w[0] = G::P_W1; m.p_b[0] = G::P_B1; m.p_s[0] = G::P_S1; m.p_wo = G::P_WO; m.p_bo = G::P_BO;
     m.p_so = G::P_SO; m.P = G::P;
-    return KernelEntry{H, C, 1, icnn_step_kernel<H, C, true>, icnn_step_kernel<H, C, false>, G::LDS_BYTES, G::P, m};
+    return KernelEntry{H, C, 1, icnn_step_kernel<H, C, true>, icnn_step_kernel<H, C, true, true>, icnn_step_kernel<H, C, false>,
+                       G::LDS_BYTES, G::P, m};
 }
 
 template <int H, int C>
@@ -308,7 +310,8 @@ KernelEntry make_entry2() {
     for (int e = 0; e < 4; ++e) m.ext[e] = e < G::NEXT ? G::ext_pos(e) : 0;
     m.p_bin = G::P_BIN; m.p_w[0] = G::P_W1; m.p_b[0] = G::P_B1; m.p_s[0] = G::P_S1; m.p_w[1] = G::P_W2; m.p_b[1] = G::P_B2;
     m.p_s[1] = G::P_S2; m.p_wo = G::P_WO; m.p_bo = G::P_BO; m.p_so = G::P_SO; m.P = G::P;
-    return KernelEntry{H, C, 2, icnn2_step_kernel<H, C, true>, icnn2_step_kernel<H, C, false>, G::LDS_BYTES, G::P, m};
+    return KernelEntry{H, C, 2, icnn2_step_kernel<H, C, true>, icnn2_step_kernel<H, C, true, true>,
+                       icnn2_step_kernel<H, C, false>, G::LDS_BYTES, G::P, m};
 }
 
 const KernelEntry kEntries[] = {
@@ -361,6 +364,8 @@ int set_lds(const KernelEntry* e) {
     if (hipFuncSetAttribute((const void*)e->train, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes) != hipSuccess)
         return INR_ELAUNCH;
     if (hipFuncSetAttribute((const void*)e->fwd, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes) != hipSuccess)
+        return INR_ELAUNCH;
+    if (hipFuncSetAttribute((const void*)e->train_dx, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes) != hipSuccess)
         return INR_ELAUNCH;
     return INR_OK;
 }
@@ -425,8 +430,9 @@ static int launch_pack(const KernelEntry* e, const Workspace& w, const float* pa
 }
 
 static int launch_step(const KernelEntry* e, const Workspace& w, bool train, const InrGridDesc* grid, const float* targets,
-                       int loss_kind, int n_images, float* logits, hipStream_t s) {
+                       int loss_kind, int n_images, float* logits, hipStream_t s, float* dcoords = nullptr) {
     StepArgs a{};
+    a.dcoords = dcoords;
     a.wimg = w.wimg;
     a.targets = targets;
     a.coef = w.coef;
@@ -438,7 +444,8 @@ static int launch_step(const KernelEntry* e, const Workspace& w, bool train, con
     a.wgs = w.wgs;
     a.PS = w.PS;
     a.loss_kind = loss_kind;
-    hipLaunchKernelGGL(train ? e->train : e->fwd, dim3((unsigned)(n_images * w.wgs)), dim3(WG_THREADS), e->lds_bytes, s, a);
+    hipLaunchKernelGGL(train ? (dcoords ? e->train_dx : e->train) : e->fwd, dim3((unsigned)(n_images * w.wgs)), dim3(WG_THREADS),
+                       e->lds_bytes, s, a);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 
@@ -508,7 +515,7 @@ int inrfit_loss_grad(const InrModelDesc* model, const float* params, const InrGr
 }
 
 int inrfit_backward(const InrModelDesc* model, const float* params, const InrGridDesc* grid, const float* dlogits,
-                    int n_images, float* grads, void* workspace, int64_t workspace_bytes, void* stream) {
+                    int n_images, float* grads, float* dcoords, void* workspace, int64_t workspace_bytes, void* stream) {
     const KernelEntry* e;
     Workspace w;
     if (!params || !dlogits || !grads) return INR_EINVAL;
@@ -516,7 +523,7 @@ int inrfit_backward(const InrModelDesc* model, const float* params, const InrGri
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     if ((rc = launch_pack(e, w, params, n_images, s))) return rc;
-    if ((rc = launch_step(e, w, true, grid, dlogits, INR_LOSS_EXTERNAL, n_images, nullptr, s))) return rc;
+    if ((rc = launch_step(e, w, true, grid, dlogits, INR_LOSS_EXTERNAL, n_images, nullptr, s, dcoords))) return rc;
     launch_reduce(e, w, n_images, grads, w.coef /* scratch: the loss slot is unused in this mode */, s);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }

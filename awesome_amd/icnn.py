@@ -230,8 +230,9 @@ def loss_grad(spec: IcnnSpec, params: Tensor, grid: Grid, targets: Tensor, loss:
     return loss_out, grads
 
 
-def backward(spec: IcnnSpec, params: Tensor, grid: Grid, dlogits: Tensor) -> Tensor:
-    """Vector-Jacobian product: grads [n_images, P] = dlogits [n_images, N] . d logits / d params (forward recomputed)."""
+def backward(spec: IcnnSpec, params: Tensor, grid: Grid, dlogits: Tensor, want_dcoords: bool = False):
+    """Vector-Jacobian product: grads [n_images, P] = dlogits [n_images, N] . d logits / d params (forward recomputed).
+    want_dcoords: also return dL/dcoords [n_images, C, N]."""
     _check_spec(spec)
     params = _check_dev(params, "params")
     dlogits = _check_dev(dlogits, "dlogits")
@@ -242,11 +243,13 @@ def backward(spec: IcnnSpec, params: Tensor, grid: Grid, dlogits: Tensor) -> Ten
     assert dlogits.shape[1] == grid.n_points
     ws = _workspace(spec, grid, n_images)
     grads = torch.empty_like(params)
+    dco = torch.empty(n_images, spec.in_features, grid.n_points, dtype=torch.float32, device=params.device) if want_dcoords else None
     md, gd = spec.desc(), grid.desc()
     rc = L.load().inrfit_backward(C.byref(md), params.data_ptr(), C.byref(gd), dlogits.data_ptr(), n_images,
-                                  grads.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream_ptr(params.device))
+                                  grads.data_ptr(), dco.data_ptr() if dco is not None else None, ws.data_ptr(),
+                                  ws.numel() * 4, _stream_ptr(params.device))
     L.check(rc, "inrfit_backward")
-    return grads
+    return (grads, dco) if want_dcoords else grads
 
 
 def step_only(spec: IcnnSpec, params: Tensor, grid: Grid, targets: Tensor, iters: int, loss: str = "se",

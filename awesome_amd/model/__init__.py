@@ -1,1 +1,2 @@
 from .convex_net import ConvexNet, ConvexNextNet  # noqa: F401
+from .diffeomorphism_net import ConvexDiffeomorphismNet, NormalBlock, NormalizingFlow1D, WNLinear, WNScale  # noqa: F401

@@ -29,16 +29,19 @@ class _IcnnFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dlogits: torch.Tensor):
-        if ctx.needs_input_grad[0]:
-            raise NotImplementedError("gradient w.r.t. the coordinates is not wired yet (needed only below a flow)")
         (flat,) = ctx.saved_tensors
-        g = K.backward(ctx.spec, flat, ctx.grid, dlogits.contiguous()[None])[0]
+        dco = None
+        if ctx.needs_input_grad[0]:   # the ICNN sits behind a learned deformation: also return dL/dcoords (C, N)
+            g, dco = K.backward(ctx.spec, flat, ctx.grid, dlogits.contiguous()[None], want_dcoords=True)
+            g, dco = g[0], dco[0]
+        else:
+            g = K.backward(ctx.spec, flat, ctx.grid, dlogits.contiguous()[None])[0]
         outs, off = [], 0
         for shp in ctx.shapes:
             n = math.prod(shp)
             outs.append(g[off:off + n].reshape(shp))
             off += n
-        return (None, None, *outs)
+        return (dco, None, *outs)
 
 
 def _kaiming_uniform_reset(linear: nn.Linear, activation: str) -> None:

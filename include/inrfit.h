@@ -132,9 +132,12 @@ int inrfit_loss_grad(const InrModelDesc* model, const float* params, const InrGr
 
 /* grads[n_images][P] = sum_p dlogits[image][p] * d logit_p / d params: the vector-Jacobian product of the forward
  * (forward is recomputed, nothing is saved).  Replaces autograd's backward through ConvexNextNet.forward for an
- * arbitrary downstream criterion (AwesomeImageLoss, FBMSJointLoss, ... - awesome/agent/torch_agent.py:478-491). */
+ * arbitrary downstream criterion (AwesomeImageLoss, FBMSJointLoss, ... - awesome/agent/torch_agent.py:478-491).
+ * dcoords (optional, may be NULL) [n_images][C][n_points]: dlogits[p] * d logit_p / d coords_p - the gradient that flows
+ * on into a learned deformation of the grid (ConvexDiffeomorphismNet.forward, awesome/model/convex_diffeomorphism_net.py:
+ * 173-178: ICNN(flow(Ax+b))). */
 int inrfit_backward(const InrModelDesc* model, const float* params, const InrGridDesc* grid, const float* dlogits,
-                    int n_images, float* grads, void* workspace, int64_t workspace_bytes, void* stream);
+                    int n_images, float* grads, float* dcoords, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* `steps` full-batch optimisation steps of n_images independent fits, entirely on device:
  *   E x { forward, loss, backward, Adam/Adamax step, clamp, plateau.step(loss) }
