@@ -130,8 +130,15 @@ def main():
     kernel_ms = e0.elapsed_time(e1) / args.kernel_iters
     flop_per_launch = STEP_FLOP_PER_POINT * N * B
     achieved = flop_per_launch / (kernel_ms * 1e-3) / 1e12
+    # HBM bytes per launch of this kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes of
+    # this same command; profiles/r01_c_pmc_traffic.json) - only quoted for the configuration it was measured on
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+    if B == 1 and S == 256 and os.path.exists(tf):
+        with open(tf) as f:
+            traffic = json.load(f).get("traffic_bytes_per_launch")
     roofline = {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": traffic,
                 "kernel": "icnn_step_kernel<130,2,train>", "kernel_us": round(kernel_ms * 1e3, 2),
                 "flop_per_launch": flop_per_launch}
 
