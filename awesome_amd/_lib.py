@@ -33,6 +33,10 @@ class InrGridDesc(C.Structure):
                 ("coords_image_stride", C.c_int64)]
 
 
+class InrFlowDesc(C.Structure):
+    _fields_ = [("width", C.c_int32), ("num_coupling", C.c_int32)]
+
+
 class InrLossDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("weight_mode", C.c_int32), ("ratio", C.c_float), ("c_fg", C.c_float),
                 ("c_bg", C.c_float)]
@@ -61,6 +65,19 @@ EXPORTS = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "inrfit_step_only": (C.c_int, [C.POINTER(InrModelDesc), C.c_void_p, C.POINTER(InrGridDesc), C.c_void_p,
                                    C.POINTER(InrLossDesc), C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_flow_param_count": (C.c_int64, [C.POINTER(InrFlowDesc)]),
+    "inrfit_cdn_workspace_bytes": (C.c_int64, [C.POINTER(InrModelDesc), C.POINTER(InrFlowDesc), C.POINTER(InrGridDesc), C.c_int]),
+    "inrfit_flow_forward": (C.c_int, [C.POINTER(InrFlowDesc), C.c_void_p, C.POINTER(InrGridDesc), C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_cdn_forward": (C.c_int, [C.POINTER(InrModelDesc), C.POINTER(InrFlowDesc), C.c_void_p, C.c_void_p,
+                                     C.POINTER(InrGridDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_cdn_loss_grad": (C.c_int, [C.POINTER(InrModelDesc), C.POINTER(InrFlowDesc), C.c_void_p, C.c_void_p,
+                                       C.POINTER(InrGridDesc), C.c_void_p, C.POINTER(InrLossDesc), C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_cdn_fit": (C.c_int, [C.POINTER(InrModelDesc), C.POINTER(InrFlowDesc), C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.POINTER(InrGridDesc), C.c_void_p, C.POINTER(InrLossDesc),
+                                 C.POINTER(InrOptDesc), C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "inrfit_fit": (C.c_int, [C.POINTER(InrModelDesc), C.c_void_p, C.c_void_p, C.POINTER(InrGridDesc), C.c_void_p,
                              C.POINTER(InrLossDesc), C.POINTER(InrOptDesc), C.c_int, C.c_int, C.c_int, C.c_void_p,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

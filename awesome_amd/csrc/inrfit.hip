@@ -22,6 +22,7 @@
 //   * fp32 everywhere (exact-f32 MFMA == fmaf chain), fixed-order reductions, no atomics: results are reproducible.
 #include "icnn_step.h"
 #include "icnn_step2.h"
+#include "flow.h"
 
 namespace {
 
@@ -598,6 +599,283 @@ int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const
     }
     if (hipGetLastError() != hipSuccess) return INR_ELAUNCH;
     if (final_logits) return launch_step(e, w, false, grid, nullptr, 0, n_images, final_logits, s);
+    return INR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// path-connected prior: ICNN(flow(Ax + b))
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct CdnWs {
+    Workspace icnn;       // ICNN workspace (explicit grid = deformed coordinates)
+    float *xd, *dxd, *FE, *ps, *slab1, *slab2;
+    int blocks1, chunks, Wp, S1;
+    FlowMap fm;
+    long long bytes;
+    InrGridDesc dgrid;    // the deformed grid handed to the ICNN kernels
+};
+
+long long align256(long long b) { return (b + 255) / 256 * 256; }
+
+bool flow_ok(const InrFlowDesc* f) {
+    return f && f->width >= 1 && f->width <= 256 &&
+           (f->num_coupling == 2 || f->num_coupling == 4 || f->num_coupling == 6 || f->num_coupling == 8);
+}
+
+CdnWs carve_cdn(const KernelEntry* e, const InrFlowDesc* f, const InrGridDesc* grid, int n_images, void* base) {
+    CdnWs w;
+    const long long N = grid->n_points;
+    w.fm = make_flow_map(f->width, f->num_coupling);
+    w.blocks1 = (int)((N + 255) / 256);
+    w.Wp = (f->width + 63) / 64 * 64;
+    w.chunks = 16;
+    while (w.chunks > 1 && N / w.chunks < 256) w.chunks /= 2;
+    w.S1 = 3 * f->num_coupling + 6;
+    char* b = (char*)base;
+    long long off = 0;
+    auto take = [&](long long bytes) { float* p = (float*)(b + off); off += align256(bytes); return p; };
+    w.xd = take((long long)n_images * 2 * N * 4);
+    w.dxd = take((long long)n_images * 2 * N * 4);
+    w.FE = take((long long)n_images * w.fm.FE * 4);
+    w.ps = take((long long)n_images * f->num_coupling * 3 * N * 4);
+    w.slab1 = take((long long)n_images * w.blocks1 * w.S1 * 4);
+    w.slab2 = take((long long)n_images * w.chunks * f->num_coupling * 2 * 3 * w.Wp * 4);
+    w.dgrid = *grid;
+    w.dgrid.mode = INR_GRID_EXPLICIT;
+    w.dgrid.coords = w.xd;
+    w.dgrid.coords_image_stride = 2 * N;
+    if (e) {
+        w.icnn = carve(e, N, n_images, b + off);
+        off += align256(w.icnn.bytes);
+    }
+    w.bytes = off;
+    return w;
+}
+
+void launch_flow_update(const CdnWs& w, const InrFlowDesc* f, int n_images, int mode, float* FP, float* opt, float* grads_out,
+                        const InrOptDesc* od, float wd_g, int t, const float* lr_hdr, long long hdr_stride, hipStream_t s) {
+    FlowUpdArgs u{};
+    u.FP = FP;
+    u.FE = w.FE;
+    u.opt = opt;
+    u.grads_out = grads_out;
+    u.slab1 = w.slab1;
+    u.slab2 = w.slab2;
+    u.lr_hdr = lr_hdr;
+    u.hdr_stride = hdr_stride;
+    if (od) u.opt_desc = *od;
+    u.m = w.fm;
+    u.blocks1 = w.blocks1;
+    u.S1 = w.S1;
+    u.chunks = w.chunks;
+    u.Wp = w.Wp;
+    u.t = t;
+    if (od && t > 0) {
+        u.bc1 = 1.0 - pow((double)od->beta1, (double)t);
+        u.bc2_sqrt = (float)sqrt(1.0 - pow((double)od->beta2, (double)t));
+        u.one_minus_b1 = (float)(1.0 - (double)od->beta1);
+        u.one_minus_b2 = (float)(1.0 - (double)od->beta2);
+    }
+    u.wd_g = wd_g;
+    u.mode = mode;
+    hipLaunchKernelGGL(flow_update_kernel, dim3(2 * f->num_coupling + 1, n_images), dim3(256), 0, s, u);
+}
+
+void launch_flow_fwd(const CdnWs& w, const InrGridDesc* grid, int n_images, float* out, hipStream_t s) {
+    FlowFwdArgs a{};
+    a.FE = w.FE;
+    a.xd = out;
+    a.grid = *grid;
+    a.N = grid->n_points;
+    a.m = w.fm;
+    hipLaunchKernelGGL(flow_fwd_kernel, dim3(w.blocks1, n_images), dim3(256), 0, s, a);
+}
+
+void launch_flow_bwd(const CdnWs& w, const InrFlowDesc* f, const InrGridDesc* grid, int n_images, hipStream_t s) {
+    FlowBwdArgs a{};
+    a.FE = w.FE;
+    a.dxd = w.dxd;
+    a.ps = w.ps;
+    a.slab1 = w.slab1;
+    a.grid = *grid;
+    a.N = grid->n_points;
+    a.m = w.fm;
+    a.S1 = w.S1;
+    const dim3 g1(w.blocks1, n_images), b1(256);
+    switch (f->num_coupling) {
+        case 2: hipLaunchKernelGGL(flow_bwd_points_kernel<2>, g1, b1, 0, s, a); break;
+        case 4: hipLaunchKernelGGL(flow_bwd_points_kernel<4>, g1, b1, 0, s, a); break;
+        case 6: hipLaunchKernelGGL(flow_bwd_points_kernel<6>, g1, b1, 0, s, a); break;
+        default: hipLaunchKernelGGL(flow_bwd_points_kernel<8>, g1, b1, 0, s, a); break;
+    }
+    FlowUnitsArgs ua{};
+    ua.FE = w.FE;
+    ua.ps = w.ps;
+    ua.slab2 = w.slab2;
+    ua.N = grid->n_points;
+    ua.m = w.fm;
+    ua.chunks = w.chunks;
+    ua.Wp = w.Wp;
+    hipLaunchKernelGGL(flow_bwd_units_kernel, dim3(w.chunks, 2 * f->num_coupling * (w.Wp / 64), n_images), dim3(256), 0, s, ua);
+}
+
+int check_cdn(const InrModelDesc* model, const InrFlowDesc* flow, const InrGridDesc* grid, int n_images, void* workspace,
+              int64_t workspace_bytes, bool need_icnn, const KernelEntry** e_out, CdnWs* w_out) {
+    if (!flow_ok(flow)) return INR_EUNSUPPORTED;
+    const KernelEntry* e = nullptr;
+    if (need_icnn) {
+        e = find_entry(model);
+        if (!e) return INR_EUNSUPPORTED;
+        if (e->c != 2) return INR_EUNSUPPORTED;   // the reference flow is 2-D only (diffeomorphism_net.py:288)
+    }
+    if (!workspace || !grid || grid->n_points <= 0 || grid->n_points > 0x7fffffffLL || n_images <= 0) return INR_EINVAL;
+    if (grid->mode == INR_GRID_SEPARABLE) {
+        if (!grid->xs || !grid->ys || (long long)grid->width * grid->height != grid->n_points) return INR_EINVAL;
+    } else if (grid->mode == INR_GRID_EXPLICIT) {
+        if (!grid->coords) return INR_EINVAL;
+    } else {
+        return INR_EINVAL;
+    }
+    *w_out = carve_cdn(e, flow, grid, n_images, workspace);
+    if (workspace_bytes < w_out->bytes) return INR_EWORKSPACE;
+    if (e) {
+        const int rc = set_lds(e);
+        if (rc) return rc;
+    }
+    *e_out = e;
+    return INR_OK;
+}
+
+}  // namespace
+
+int64_t inrfit_flow_param_count(const InrFlowDesc* flow) {
+    if (!flow_ok(flow)) return INR_EUNSUPPORTED;
+    return make_flow_map(flow->width, flow->num_coupling).FP;
+}
+
+int64_t inrfit_cdn_workspace_bytes(const InrModelDesc* model, const InrFlowDesc* flow, const InrGridDesc* grid, int n_images) {
+    if (!flow_ok(flow)) return INR_EUNSUPPORTED;
+    if (!grid || grid->n_points <= 0 || n_images <= 0) return INR_EINVAL;
+    const KernelEntry* e = model ? find_entry(model) : nullptr;
+    if (model && !e) return INR_EUNSUPPORTED;
+    return carve_cdn(e, flow, grid, n_images, nullptr).bytes;
+}
+
+int inrfit_flow_forward(const InrFlowDesc* flow, const float* flow_params, const InrGridDesc* grid, int n_images,
+                        float* out_coords, void* workspace, int64_t workspace_bytes, void* stream) {
+    const KernelEntry* e;
+    CdnWs w;
+    if (!flow_params || !out_coords) return INR_EINVAL;
+    int rc = check_cdn(nullptr, flow, grid, n_images, workspace, workspace_bytes, false, &e, &w);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    launch_flow_update(w, flow, n_images, 2, (float*)flow_params, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0, s);
+    launch_flow_fwd(w, grid, n_images, out_coords, s);
+    return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
+}
+
+int inrfit_cdn_forward(const InrModelDesc* model, const InrFlowDesc* flow, const float* icnn_params, const float* flow_params,
+                       const InrGridDesc* grid, int n_images, float* logits, void* workspace, int64_t workspace_bytes,
+                       void* stream) {
+    const KernelEntry* e;
+    CdnWs w;
+    if (!icnn_params || !flow_params || !logits) return INR_EINVAL;
+    int rc = check_cdn(model, flow, grid, n_images, workspace, workspace_bytes, true, &e, &w);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    launch_flow_update(w, flow, n_images, 2, (float*)flow_params, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0, s);
+    launch_flow_fwd(w, grid, n_images, w.xd, s);
+    if ((rc = launch_pack(e, w.icnn, icnn_params, n_images, s))) return rc;
+    return launch_step(e, w.icnn, false, &w.dgrid, nullptr, 0, n_images, logits, s);
+}
+
+int inrfit_cdn_loss_grad(const InrModelDesc* model, const InrFlowDesc* flow, const float* icnn_params,
+                         const float* flow_params, const InrGridDesc* grid, const float* targets, const InrLossDesc* loss,
+                         int n_images, float* loss_out, float* icnn_grads, float* flow_grads, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
+    const KernelEntry* e;
+    CdnWs w;
+    if (!icnn_params || !flow_params || !targets || !loss_out || !icnn_grads || !flow_grads) return INR_EINVAL;
+    int rc = check_loss(loss);
+    if (rc) return rc;
+    if ((rc = check_cdn(model, flow, grid, n_images, workspace, workspace_bytes, true, &e, &w))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    launch_flow_update(w, flow, n_images, 2, (float*)flow_params, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0, s);
+    launch_flow_fwd(w, grid, n_images, w.xd, s);
+    hipLaunchKernelGGL(loss_coef_kernel, dim3(n_images), dim3(256), 0, s, targets, (long long)grid->n_points, *loss, w.icnn.coef);
+    if ((rc = launch_pack(e, w.icnn, icnn_params, n_images, s))) return rc;
+    if ((rc = launch_step(e, w.icnn, true, &w.dgrid, targets, loss->kind, n_images, nullptr, s, w.dxd))) return rc;
+    launch_reduce(e, w.icnn, n_images, icnn_grads, loss_out, s);
+    launch_flow_bwd(w, flow, grid, n_images, s);
+    launch_flow_update(w, flow, n_images, 1, (float*)flow_params, nullptr, flow_grads, nullptr, 0.f, 0, nullptr, 0, s);
+    return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
+}
+
+int inrfit_cdn_fit(const InrModelDesc* model, const InrFlowDesc* flow, float* icnn_params, float* flow_params,
+                   float* icnn_opt_state, float* flow_opt_state, const InrGridDesc* grid, const float* targets,
+                   const InrLossDesc* loss, const InrOptDesc* opt, float wd_on_weight_g, int n_images, int steps, int step0,
+                   float* loss_hist, float* final_logits, int32_t* status, void* workspace, int64_t workspace_bytes,
+                   void* stream) {
+    const KernelEntry* e;
+    CdnWs w;
+    if (!icnn_params || !flow_params || !icnn_opt_state || !flow_opt_state || !targets || !opt || steps < 0 || step0 < 0)
+        return INR_EINVAL;
+    if (opt->kind != INR_OPT_ADAM) return INR_EINVAL;
+    int rc = check_loss(loss);
+    if (rc) return rc;
+    if (loss->kind == INR_LOSS_EXTERNAL) return INR_EINVAL;
+    if ((rc = check_cdn(model, flow, grid, n_images, workspace, workspace_bytes, true, &e, &w))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(loss_coef_kernel, dim3(n_images), dim3(256), 0, s, targets, (long long)grid->n_points, *loss, w.icnn.coef);
+    hipLaunchKernelGGL(opt_init_kernel, dim3(n_images), dim3(64), 0, s, icnn_opt_state, e->P, *opt, step0);
+    if (status && hipMemsetAsync(status, 0, sizeof(int32_t) * n_images, s) != hipSuccess) return INR_ELAUNCH;
+    if ((rc = launch_pack(e, w.icnn, icnn_params, n_images, s))) return rc;
+    launch_flow_update(w, flow, n_images, 2, flow_params, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0, s);  // effective weights
+    UpdArgs u{};
+    u.wimg = w.icnn.wimg;
+    u.img = e->img;
+    u.params = icnn_params;
+    u.opt_state = icnn_opt_state;
+    u.slabs = w.icnn.slabs;
+    u.loss_hist = loss_hist;
+    u.status = status;
+    u.opt = *opt;
+    u.P = e->P;
+    u.PS = w.icnn.PS;
+    u.wgs = w.icnn.wgs;
+    u.n_images = n_images;
+    u.hist_stride = steps;
+    u.one_minus_b1 = (float)(1.0 - (double)opt->beta1);
+    u.one_minus_b2 = (float)(1.0 - (double)opt->beta2);
+    u.mode = 0;
+    for (int k = 0; k < 3; ++k) u.clamp_lo[k] = u.clamp_hi[k] = 0;
+    for (int k = 0; k < e->img.L; ++k) {
+        u.clamp_lo[k] = e->img.p_w[k];
+        u.clamp_hi[k] = e->img.p_w[k] + e->img.H * e->img.H;
+    }
+    u.clamp_lo[2] = e->img.p_wo;
+    u.clamp_hi[2] = e->img.p_wo + e->img.H;
+    const dim3 ugrid((e->P + 1 + UPD_PARAMS - 1) / UPD_PARAMS, n_images);
+    const long long hdr_stride = 2 * (long long)e->P + INR_OPT_HEADER_FLOATS;
+    for (int it = 0; it < steps; ++it) {
+        launch_flow_fwd(w, grid, n_images, w.xd, s);
+        if ((rc = launch_step(e, w.icnn, true, &w.dgrid, targets, loss->kind, n_images, nullptr, s, w.dxd))) return rc;
+        u.t = step0 + it + 1;
+        u.bc1 = 1.0 - pow((double)opt->beta1, (double)u.t);
+        u.bc2_sqrt = (float)sqrt(1.0 - pow((double)opt->beta2, (double)u.t));
+        u.hist_idx = it;
+        hipLaunchKernelGGL(icnn_update_kernel, ugrid, dim3(UPD_PARAMS / 4, UPD_GROUPS), 0, s, u);
+        launch_flow_bwd(w, flow, grid, n_images, s);
+        // the learning rate of THIS step sits in header[t & 1] (the plateau thread wrote the next one into the other slot)
+        launch_flow_update(w, flow, n_images, 0, flow_params, flow_opt_state, nullptr, opt, wd_on_weight_g, u.t,
+                           icnn_opt_state + 2 * (size_t)e->P, hdr_stride, s);
+    }
+    if (hipGetLastError() != hipSuccess) return INR_ELAUNCH;
+    if (final_logits) {
+        launch_flow_fwd(w, grid, n_images, w.xd, s);
+        return launch_step(e, w.icnn, false, &w.dgrid, nullptr, 0, n_images, final_logits, s);
+    }
     return INR_OK;
 }
 

@@ -156,6 +156,41 @@ int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const
 int inrfit_miou(const float* out, const float* tgt, int n_images, int64_t n_points, float thr_out, float thr_tgt, int invert,
                 float* iou, void* stream);
 
+/* ---- path-connected prior: ICNN(flow(Ax + b)), ConvexDiffeomorphismNet (awesome/model/convex_diffeomorphism_net.py:130-188)
+ * with the weight-normalised coupling flow NormalizingFlow1D(backbone='normal_block') of awesome/model/diffeomorphism_net.py:
+ * 169-302 (2-D grids only, like the reference).  Flat flow parameter vector (W = width, K = num_coupling):
+ *     linear.weight [2][2] | linear.bias [2] |
+ *     for i in 0..K-1, for net in (s, t):  in_linear weight_v [W] | weight_g | bias [W] | out_linear weight_v [W] | weight_g | bias
+ *     for i in 0..K-1 (WNScale):  weight | scale.bias | scale.weight_g | scale.weight_v
+ *   FP = 6 + 2K(3W + 3) + 4K.   flow_opt_state = n_images * 2 * FP floats (exp_avg | exp_avg_sq), zero for a cold fit. */
+typedef struct InrFlowDesc {
+    int32_t width;        /* W <= 256 */
+    int32_t num_coupling; /* K in {2, 4, 6, 8} */
+} InrFlowDesc;
+
+int64_t inrfit_flow_param_count(const InrFlowDesc* flow);
+int64_t inrfit_cdn_workspace_bytes(const InrModelDesc* model, const InrFlowDesc* flow, const InrGridDesc* grid, int n_images);
+/* out_coords[n_images][2][n_points] = flow(A x + b): ConvexDiffeomorphismNet.get_deformation (:179-184). */
+int inrfit_flow_forward(const InrFlowDesc* flow, const float* flow_params, const InrGridDesc* grid, int n_images,
+                        float* out_coords, void* workspace, int64_t workspace_bytes, void* stream);
+/* logits[n_images][n_points] = ICNN(flow(A x + b)): ConvexDiffeomorphismNet.forward (:173-178). */
+int inrfit_cdn_forward(const InrModelDesc* model, const InrFlowDesc* flow, const float* icnn_params, const float* flow_params,
+                       const InrGridDesc* grid, int n_images, float* logits, void* workspace, int64_t workspace_bytes,
+                       void* stream);
+/* loss and the gradient w.r.t. every parameter (ICNN flat order, flow flat order) of the data term. */
+int inrfit_cdn_loss_grad(const InrModelDesc* model, const InrFlowDesc* flow, const float* icnn_params,
+                         const float* flow_params, const InrGridDesc* grid, const float* targets, const InrLossDesc* loss,
+                         int n_images, float* loss_out, float* icnn_grads, float* flow_grads, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+/* `steps` full-batch steps of ConvexDiffeomorphismNet.pretrain's inner loop (:405-430): forward, criterion, backward,
+ * Adam over the parameter groups of get_weight_normalized_param_groups (awesome/util/torch.py:19-35: weight decay
+ * `wd_on_weight_g` on every *weight_g, none elsewhere; opt->kind must be INR_OPT_ADAM), ReduceLROnPlateau, enforce_convexity. */
+int inrfit_cdn_fit(const InrModelDesc* model, const InrFlowDesc* flow, float* icnn_params, float* flow_params,
+                   float* icnn_opt_state, float* flow_opt_state, const InrGridDesc* grid, const float* targets,
+                   const InrLossDesc* loss, const InrOptDesc* opt, float wd_on_weight_g, int n_images, int steps, int step0,
+                   float* loss_hist, float* final_logits, int32_t* status, void* workspace, int64_t workspace_bytes,
+                   void* stream);
+
 /* Measurement hook (bench.py, rocprof): launch ONLY the fused forward+loss+backward step kernel `iters` times
  * back-to-back on `stream` (no optimizer step), so its average duration can be bracketed with events. */
 int inrfit_step_only(const InrModelDesc* model, const float* params, const InrGridDesc* grid, const float* targets,

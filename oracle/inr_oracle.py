@@ -368,3 +368,48 @@ def to_convexnext_keys(sd: Dict[str, Tensor]) -> Dict[str, Tensor]:
     if "W0y.weight" in sd:
         return {CONVEXNET_KEYMAP[k]: v for k, v in sd.items()}
     return dict(sd)
+
+
+# --------------------------------------------------------------------------------------
+# a13 (path-connected prior)  the inner loop of ConvexDiffeomorphismNet.pretrain
+# --------------------------------------------------------------------------------------
+
+
+def fit_convex_diffeo(sd0: Dict[str, Tensor], grid: Tensor, unaries: Tensor, steps: int, num_coupling: int, lr: float = 3e-3,
+                      loss_kind: str = "bce", weight_decay_on_weight_g: float = 5e-5, plateau: Optional[dict] = None
+                      ) -> Tuple[Dict[str, Tensor], List[float], Tensor]:
+    """awesome/model/convex_diffeomorphism_net.py:405-430: Adam over two parameter groups (every `*weight_g` with weight
+    decay, the rest without - awesome/util/torch.py:19-35), criterion on sigmoid(model(grid)), ReduceLROnPlateau stepped
+    with the loss, enforce_convexity (ICNN part only) after every step.  grid (1,2,H,W), unaries (1,1,H,W)."""
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in sd0.items()}
+    st = AdamState(p)
+    sched = PlateauState(lr, **plateau) if plateau is not None else None
+    rows = pixelize(grid)
+    _, _, h, w = grid.shape
+    losses: List[float] = []
+    cur_lr = lr
+    norm_keys = [k for k in p if k.endswith("weight_g")]
+    other_keys = [k for k in p if not k.endswith("weight_g")]
+    for _ in range(steps):
+        for v in p.values():
+            v.grad = None
+        out = torch.sigmoid(unpixelize(convex_diffeo_forward(p, rows, num_coupling), 1, h, w))
+        loss = weighted_loss(out, unaries, loss_kind)
+        loss.backward()
+        st.step += 1
+        for keys, wd in ((norm_keys, weight_decay_on_weight_g), (other_keys, 0.0)):
+            sub, g = {k: p[k] for k in keys}, {k: p[k].grad for k in keys}
+            sst = AdamState.__new__(AdamState)
+            sst.step, sst.m, sst.v = st.step - 1, st.m, st.v
+            adam_step(sub, g, sst, cur_lr, weight_decay=wd)
+        with torch.no_grad():
+            for k in p:
+                if k.startswith("convex_net.") and (k.endswith("ln.weight")) and not k.startswith("convex_net.input"):
+                    p[k].copy_(F.relu(p[k]))
+        lv = float(loss.item())
+        losses.append(lv)
+        if sched is not None:
+            cur_lr = sched.step(lv)
+    with torch.no_grad():
+        logits = unpixelize(convex_diffeo_forward(p, rows, num_coupling), 1, h, w)
+    return {k: v.detach() for k, v in p.items()}, losses, logits

@@ -84,3 +84,74 @@ def test_convex_diffeomorphism_net(dev, layers):
         ref = sdo[k].grad.numpy()
         scale = float(np.abs(ref).max())
         np.testing.assert_allclose(prm.grad.cpu().numpy(), ref, rtol=1e-3, atol=1e-5 * scale + 1e-7, err_msg=k)  # floor: d/dv of g*v/|v| is exactly 0 for a scalar v
+
+
+# ---- fused HIP flow kernels + ICNN(flow) fit -------------------------------------------------------------------------------
+def _cdn_case(layers, width, K, h=130, seed=5):
+    from awesome_amd.model import ConvexDiffeomorphismNet
+    torch.manual_seed(seed)
+    m = ConvexDiffeomorphismNet(n_hidden=h, n_hidden_layers=layers, nf_layers=K, nf_hidden=width, in_features=2)
+    with torch.no_grad():   # move the weight_g / scale parameters off their init values so every chain-rule term is exercised
+        for k, p in m.named_parameters():
+            if k.endswith("weight_g") or "scale" in k:
+                p.mul_(1.0 + 0.2 * torch.rand_like(p))
+    return m, {k: v.clone() for k, v in m.state_dict().items()}
+
+
+@pytest.mark.parametrize("layers,width,K", [(1, 130, 6), (2, 24, 4), (1, 70, 2)])
+def test_hip_flow_forward_and_cdn_gradients(dev, layers, width, K):
+    import awesome_amd as A
+    from awesome_amd import flow as FL
+    m, sd = _cdn_case(layers, width, K)
+    ispec, fspec = A.IcnnSpec(130, 2, layers), FL.FlowSpec(width, K)
+    assert fspec.n_params == sum(int(np.prod(s)) if s else 1 for _, s in fspec.keys_shapes())
+    H, W = 9, 23   # N = 207: ragged
+    grid_t = O.positional_grid(W, H)[None] * 1.3 - 0.2
+    un = torch.rand(1, 1, H, W)
+    ip, fp = FL.split_cdn_state_dict(ispec, fspec, sd, dev)
+    ip, fp = ip[None].contiguous(), fp[None].contiguous()
+    grid = A.Grid.from_image_grid(grid_t.to(dev))
+    # oracle
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    rows = O.pixelize(grid_t)
+    xd_ref = O.flow1d_forward(sdo, torch.nn.functional.linear(rows, sdo["linear.weight"], sdo["linear.bias"]), K, prefix="diffeo_net.")
+    yo = O.convex_diffeo_forward(sdo, rows, K)
+    lo = O.weighted_loss(torch.sigmoid(O.unpixelize(yo, 1, H, W)), un, "bce")
+    lo.backward()
+    # HIP
+    xd = FL.flow_forward(fspec, fp, grid)
+    np.testing.assert_allclose(xd[0].cpu().numpy(), xd_ref.detach().t().numpy(), rtol=2e-5, atol=2e-6)
+    y = FL.cdn_forward(ispec, fspec, ip, fp, grid)
+    np.testing.assert_allclose(y[0].cpu().numpy(), yo.detach().reshape(-1).numpy(), rtol=1e-4, atol=3e-5)
+    loss, gi, gf = FL.cdn_loss_grad(ispec, fspec, ip, fp, grid, un.reshape(1, -1).to(dev), loss="bce")
+    assert float(loss[0]) == pytest.approx(float(lo.detach()), rel=2e-5)
+    got = FL.merge_cdn_state_dict(ispec, fspec, gi[0].cpu(), gf[0].cpu())
+    for k in sdo:
+        ref = sdo[k].grad.numpy()
+        scale = float(np.abs(ref).max())
+        np.testing.assert_allclose(got[k].numpy(), ref, rtol=1e-3, atol=2e-5 * scale + 1e-7, err_msg=k)
+
+
+def test_hip_cdn_fit_trajectory(dev):
+    """15 steps of the fused ICNN(flow) fit (Adam, weight decay on weight_g, plateau, clamp) vs the oracle loop."""
+    import awesome_amd as A
+    from awesome_amd import flow as FL
+    layers, width, K = 1, 130, 6
+    m, sd = _cdn_case(layers, width, K, seed=9)
+    ispec, fspec = A.IcnnSpec(130, 2, layers), FL.FlowSpec(width, K)
+    H, W = 16, 16
+    grid_t = O.positional_grid(W, H)[None]
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    un = (((yy - 8) ** 2 + (xx - 7) ** 2) > 20).float()[None, None]
+    steps = 15
+    pf, losses, logits = O.fit_convex_diffeo(sd, grid_t, un, steps, K, lr=3e-3, loss_kind="bce", weight_decay_on_weight_g=5e-3,
+                                             plateau=dict(patience=3, factor=0.5))
+    ip, fp = FL.split_cdn_state_dict(ispec, fspec, sd, dev)
+    res = FL.cdn_fit(ispec, fspec, ip[None].contiguous(), fp[None].contiguous(), A.Grid.linspace(W, H, dev),
+                     un.reshape(1, -1).to(dev), steps, lr=3e-3, loss="bce", weight_decay_on_weight_g=5e-3,
+                     plateau=dict(patience=3, factor=0.5))
+    np.testing.assert_allclose(res.loss_hist[0].cpu().numpy(), np.asarray(losses, np.float32), rtol=5e-4)
+    got = FL.merge_cdn_state_dict(ispec, fspec, res.icnn_params[0].cpu(), res.flow_params[0].cpu())
+    for k in pf:
+        np.testing.assert_allclose(got[k].numpy(), pf[k].numpy(), rtol=5e-3, atol=3e-4, err_msg=k)
+    np.testing.assert_allclose(res.logits[0].cpu().numpy(), logits.reshape(-1).numpy(), rtol=5e-3, atol=2e-3)
