@@ -17,7 +17,8 @@ INR_OPT_ADAM, INR_OPT_ADAMAX = 0, 1
 INR_OPT_HEADER_FLOATS = 8
 INRFIT_ABI_VERSION = 1
 
-LOSS_KINDS = {"se": INR_LOSS_SE, "bce": INR_LOSS_BCE}
+INR_LOSS_EXTERNAL = 2
+LOSS_KINDS = {"se": INR_LOSS_SE, "bce": INR_LOSS_BCE, "external": INR_LOSS_EXTERNAL}
 WEIGHT_MODES = {"none": INR_WEIGHT_NONE, "equal": INR_WEIGHT_EQUAL, "ratio": INR_WEIGHT_RATIO, "sssdms": INR_WEIGHT_SSSDMS,
                 "explicit": INR_WEIGHT_EXPLICIT}
 OPT_KINDS = {"adam": INR_OPT_ADAM, "adamax": INR_OPT_ADAMAX}

@@ -27,7 +27,7 @@ struct FlowMap {   // layouts derived from (W, K)
     int W, K;
     int nb_stride;    // flat params per coupling net: v1[W] g1 b1[W] v2[W] g2 b2
     int p_nb, p_scale, FP;
-    int e_nb_stride;  // effective weights per coupling net: w1[W] b1[W] w2[W] b2 (padded to 4)
+    int e_nb_stride;  // effective weights per coupling net: [W][4] = (w1, b1, w2, w1*w2) per unit, then b2 (padded to 4)
     int e_nb, e_scale, FE;
 };
 
@@ -39,7 +39,7 @@ __host__ __device__ inline FlowMap make_flow_map(int W, int K) {
     m.p_nb = 6;
     m.p_scale = m.p_nb + 2 * K * m.nb_stride;
     m.FP = m.p_scale + 4 * K;
-    m.e_nb_stride = (3 * W + 1 + 3) / 4 * 4;
+    m.e_nb_stride = 4 * W + 4;
     m.e_nb = 8;
     m.e_scale = m.e_nb + 2 * K * m.e_nb_stride;
     m.FE = (m.e_scale + K + 3) / 4 * 4;
@@ -58,18 +58,35 @@ __device__ __forceinline__ void load_coords2(const InrGridDesc& gd, int img, lon
     }
 }
 
-// tanh(w2 . leaky_relu(w1 u + b1) + b2) of one coupling net; weights are wave-uniform
-__device__ __forceinline__ float nb_forward(const float* __restrict__ e, int W, float u) {
-    const float* __restrict__ w1 = e;
-    const float* __restrict__ b1 = e + W;
-    const float* __restrict__ w2 = e + 2 * W;
-    float acc = e[3 * W];
-#pragma unroll 4
-    for (int j = 0; j < W; ++j) {
-        const float pre = fmaf(w1[j], u, b1[j]);
-        acc = fmaf(w2[j], fmaxf(pre, LEAKY_SLOPE * pre), acc);
+// The effective weights of one image (<= 25 KB) are copied into LDS once per block; inside the unit loops every lane reads
+// the same 16-byte record (w1, b1, w2, w1*w2) of unit j: one broadcast ds_read_b128 per unit, pipelined by unrolling.
+__device__ __forceinline__ void flow_weights_to_lds(const float* __restrict__ src, float* dst, int n_floats) {
+    const f32x4* __restrict__ s4 = (const f32x4*)src;
+    for (int i = threadIdx.x; i < n_floats / 4; i += blockDim.x) ((f32x4*)dst)[i] = s4[i];
+    __syncthreads();
+}
+
+// tanh(w2 . leaky_relu(w1 u + b1) + b2) of one coupling net
+__device__ __forceinline__ float nb_forward(const float* e, int W, float u) {
+    float acc0 = e[4 * W], acc1 = 0.f;
+    int j = 0;
+    for (; j + 8 <= W; j += 8) {
+        f32x4 q[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = *(const f32x4*)(e + 4 * (j + k));
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            const float p0 = fmaf(q[k][0], u, q[k][1]), p1 = fmaf(q[k + 1][0], u, q[k + 1][1]);
+            acc0 = fmaf(q[k][2], fmaxf(p0, LEAKY_SLOPE * p0), acc0);
+            acc1 = fmaf(q[k + 1][2], fmaxf(p1, LEAKY_SLOPE * p1), acc1);
+        }
     }
-    return tanhf(acc);
+    for (; j < W; ++j) {
+        const f32x4 q = *(const f32x4*)(e + 4 * j);
+        const float pre = fmaf(q[0], u, q[1]);
+        acc0 = fmaf(q[2], fmaxf(pre, LEAKY_SLOPE * pre), acc0);
+    }
+    return tanhf(acc0 + acc1);
 }
 
 struct FlowFwdArgs {
@@ -85,7 +102,9 @@ __global__ __launch_bounds__(256) void flow_fwd_kernel(const FlowFwdArgs a) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     const int N = (int)a.N;
     const int pc = p < N ? p : N - 1;
-    const float* __restrict__ e = a.FE + (size_t)img * a.m.FE;
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    flow_weights_to_lds(a.FE + (size_t)img * a.m.FE, fsm, a.m.FE);
+    const float* e = fsm;
     float xin[2];
     load_coords2(a.grid, img, a.N, pc, xin);
     float x1 = fmaf(e[0], xin[0], fmaf(e[1], xin[1], e[4]));
@@ -124,7 +143,9 @@ __global__ __launch_bounds__(256) void flow_bwd_points_kernel(const FlowBwdArgs 
     const int N = (int)a.N, W = a.m.W;
     const bool valid = p < N;
     const int pc = valid ? p : N - 1;
-    const float* __restrict__ e = a.FE + (size_t)img * a.m.FE;
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    flow_weights_to_lds(a.FE + (size_t)img * a.m.FE, fsm, a.m.FE);
+    const float* e = fsm;
     float xin[2];
     load_coords2(a.grid, img, a.N, pc, xin);
     // forward, keeping the state in front of every coupling and the net outputs
@@ -169,10 +190,11 @@ __global__ __launch_bounds__(256) void flow_bwd_points_kernel(const FlowBwdArgs 
         float dus = 0.f, dut = 0.f;
 #pragma unroll 4
         for (int j = 0; j < W; ++j) {
-            const float ps_ = fmaf(es[j], u, es[W + j]);
-            const float pt_ = fmaf(et[j], u, et[W + j]);
-            dus = fmaf(es[2 * W + j] * es[j], ps_ > 0.f ? 1.f : LEAKY_SLOPE, dus);
-            dut = fmaf(et[2 * W + j] * et[j], pt_ > 0.f ? 1.f : LEAKY_SLOPE, dut);
+            const f32x4 qs = *(const f32x4*)(es + 4 * j), qt = *(const f32x4*)(et + 4 * j);
+            const float ps_ = fmaf(qs[0], u, qs[1]);
+            const float pt_ = fmaf(qt[0], u, qt[1]);
+            dus = fmaf(qs[3], ps_ > 0.f ? 1.f : LEAKY_SLOPE, dus);   // qs[3] = w1 * w2
+            dut = fmaf(qt[3], pt_ > 0.f ? 1.f : LEAKY_SLOPE, dut);
         }
         const float du = gqs * dus + gqt * dut;
         if (valid) {
@@ -234,7 +256,7 @@ __global__ __launch_bounds__(256) void flow_bwd_units_kernel(const FlowUnitsArgs
     const int unit = ub * 64 + lane;
     const bool on = unit < W;
     const float* __restrict__ e = a.FE + (size_t)img * a.m.FE + a.m.e_nb + nb * a.m.e_nb_stride;
-    const float w1 = on ? e[unit] : 0.f, b1 = on ? e[W + unit] : 0.f, w2 = on ? e[2 * W + unit] : 0.f;
+    const float w1 = on ? e[4 * unit] : 0.f, b1 = on ? e[4 * unit + 1] : 0.f, w2 = on ? e[4 * unit + 2] : 0.f;
     const int per_chunk = (N + a.chunks - 1) / a.chunks;
     const int per_wave = (per_chunk + 3) / 4;
     const int p0 = chunk * per_chunk + wave * per_wave;
@@ -253,18 +275,26 @@ __global__ __launch_bounds__(256) void flow_bwd_units_kernel(const FlowUnitsArgs
         aw1 = fmaf(dh, u, aw1);
         ab1 += dh;
     };
-    int p = p0;
-    for (; p + 8 <= p1; p += 8) {   // u, gq are wave-uniform (scalar loads); 8 points per trip keep the loads in flight
-        float uu[8], gg[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            uu[k] = pu[p + k];
-            gg[k] = pg[p + k];
+    // 64 points per trip: one coalesced vector load per array (the next trip's loads are already in flight), then every
+    // point's (u, gq) is broadcast to the wave with v_readlane - no memory access inside the 64-point body
+    float un = 0.f, gn = 0.f;
+    if (p0 + lane < p1) {
+        un = pu[p0 + lane];
+        gn = pg[p0 + lane];
+    }
+    for (int p = p0; p < p1; p += 64) {
+        const float uc = un, gc = gn;   // gq = 0 for the lanes past p1: those points contribute nothing
+        un = 0.f;
+        gn = 0.f;
+        if (p + 64 + lane < p1) {
+            un = pu[p + 64 + lane];
+            gn = pg[p + 64 + lane];
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) one(uu[k], gg[k]);
+        for (int k = 0; k < 64; ++k)
+            one(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, uc), k)),
+                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gc), k)));
     }
-    for (; p < p1; ++p) one(pu[p], pg[p]);
     __shared__ float red[4][3][64];
     red[wave][0][lane] = aw1;
     red[wave][1][lane] = ab1;
@@ -397,20 +427,29 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
         // effective weights for the next forward
         const float n1 = sqrtf(block_sum256(v1 * v1, sm)), n2 = sqrtf(block_sum256(v2 * v2, sm));
         if (on) {
-            fe[eb + tid] = v1 * (g1 / n1);
-            fe[eb + W + tid] = b1;
-            fe[eb + 2 * W + tid] = v2 * (g2 / n2);
+            const float w1e = v1 * (g1 / n1), w2e = v2 * (g2 / n2);
+            *(f32x4*)(fe + eb + 4 * tid) = f32x4{w1e, b1, w2e, w1e * w2e};
         }
-        if (tid == 0) fe[eb + 3 * W] = b2;
+        if (tid == 0) fe[eb + 4 * W] = b2;
         return;
     }
-    // last block: WNScale parameters of every coupling + the 2x2 linear (a handful of scalars: thread per item)
+    // last block: WNScale parameters of every coupling + the 2x2 linear: first reduce their per-block partial sums
+    __shared__ float tot[64];
+    if (u.mode != 2) {
+        for (int k = 0; k < 3 * K + 6; ++k) {
+            if (k >= K && k < 3 * K) continue;   // db2 sums belong to the coupling-net blocks
+            float part = 0.f;
+            for (int b = tid; b < u.blocks1; b += 256) part += u.slab1[((size_t)img * u.blocks1 + b) * u.S1 + k];
+            const float t = block_sum256(part, sm);
+            if (tid == 0) tot[k] = t;
+        }
+        __syncthreads();
+    }
     if (tid < K) {
         const int i = tid, pb = m.p_scale + 4 * i;  // weight, sc_bias, sc_g, sc_v
         float w = fp[pb], sb = fp[pb + 1], sg = fp[pb + 2], sv = fp[pb + 3];
         if (u.mode != 2) {
-            float dsc = 0.f;
-            for (int b = 0; b < u.blocks1; ++b) dsc += u.slab1[((size_t)img * u.blocks1 + b) * u.S1 + i];
+            const float dsc = tot[i];
             const float sgn = sv / fabsf(sv);        // weight_norm(dim=0) of a 1x1 weight: v / |v|
             const float dw = dsc * sg * sgn, dsb = dsc, dsg = dsc * w * sgn, dsv = 0.f;
             if (u.mode == 1) {
@@ -428,8 +467,7 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
         const int k = tid - 64;  // A[0][0], A[0][1], A[1][0], A[1][1], b[0], b[1]
         float p = fp[k];
         if (u.mode != 2) {
-            float d = 0.f;
-            for (int b = 0; b < u.blocks1; ++b) d += u.slab1[((size_t)img * u.blocks1 + b) * u.S1 + 3 * K + k];
+            const float d = tot[3 * K + k];
             if (u.mode == 1) go[k] = d;
             else {
                 p = adam_apply(u, p, d, lr, 0.f, &om[k], &ov[k]);

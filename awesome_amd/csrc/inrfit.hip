@@ -689,7 +689,7 @@ void launch_flow_fwd(const CdnWs& w, const InrGridDesc* grid, int n_images, floa
     a.grid = *grid;
     a.N = grid->n_points;
     a.m = w.fm;
-    hipLaunchKernelGGL(flow_fwd_kernel, dim3(w.blocks1, n_images), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(flow_fwd_kernel, dim3(w.blocks1, n_images), dim3(256), w.fm.FE * sizeof(float), s, a);
 }
 
 void launch_flow_bwd(const CdnWs& w, const InrFlowDesc* f, const InrGridDesc* grid, int n_images, hipStream_t s) {
@@ -704,10 +704,10 @@ void launch_flow_bwd(const CdnWs& w, const InrFlowDesc* f, const InrGridDesc* gr
     a.S1 = w.S1;
     const dim3 g1(w.blocks1, n_images), b1(256);
     switch (f->num_coupling) {
-        case 2: hipLaunchKernelGGL(flow_bwd_points_kernel<2>, g1, b1, 0, s, a); break;
-        case 4: hipLaunchKernelGGL(flow_bwd_points_kernel<4>, g1, b1, 0, s, a); break;
-        case 6: hipLaunchKernelGGL(flow_bwd_points_kernel<6>, g1, b1, 0, s, a); break;
-        default: hipLaunchKernelGGL(flow_bwd_points_kernel<8>, g1, b1, 0, s, a); break;
+        case 2: hipLaunchKernelGGL(flow_bwd_points_kernel<2>, g1, b1, w.fm.FE * sizeof(float), s, a); break;
+        case 4: hipLaunchKernelGGL(flow_bwd_points_kernel<4>, g1, b1, w.fm.FE * sizeof(float), s, a); break;
+        case 6: hipLaunchKernelGGL(flow_bwd_points_kernel<6>, g1, b1, w.fm.FE * sizeof(float), s, a); break;
+        default: hipLaunchKernelGGL(flow_bwd_points_kernel<8>, g1, b1, w.fm.FE * sizeof(float), s, a); break;
     }
     FlowUnitsArgs ua{};
     ua.FE = w.FE;

@@ -5,9 +5,10 @@ Reference: WNLinear (awesome/model/real_nvp/resnet_1d.py:39-63), NormalBlock / W
 Same constructor kwargs and state_dict keys (torch's legacy weight_norm parametrisation: `weight_g` / `weight_v`), same
 creation order of the leaves (seeded construction = reference init).
 
-Round-1 status: the ICNN stage runs on the HIP path (forward, parameter gradients and the coordinate gradient that flows
-back into the deformation); the coupling layers themselves are still plain torch ops on the GPU - a fused HIP flow stage
-is the next row of SURVEY.md §8 (a6-a8)."""
+`ConvexDiffeomorphismNet.forward` and its autograd backward run entirely on the HIP path (flow kernels + ICNN kernels,
+`inrfit_cdn_forward` / `inrfit_cdn_loss_grad` with an external dL/dlogits); `fit_images` is the fused device-resident
+form of `ConvexDiffeomorphismNet.pretrain`'s inner loop (`inrfit_cdn_fit`).  The stand-alone flow modules
+(`NormalizingFlow1D`, `NormalBlock`, ...) are torch-op modules (they are the containers of the parameters)."""
 from __future__ import annotations
 
 import math
@@ -18,7 +19,35 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import flow as FL
+from .. import icnn as K
 from .convex_net import ConvexNextNet, _kaiming_uniform_reset
+
+
+class _CdnFunction(torch.autograd.Function):
+    """logits = ICNN(flow(A x + b)) on the HIP path; backward = gradients w.r.t. every parameter for a given dL/dlogits."""
+
+    @staticmethod
+    def forward(ctx, coords: torch.Tensor, ispec, fspec, n_icnn: int, *params: torch.Tensor):
+        flat = lambda ps: torch.cat([p.reshape(-1) for p in ps]).to(torch.float32)[None].contiguous()  # noqa: E731
+        ip, fp = flat(params[:n_icnn]), flat(params[n_icnn:])
+        grid = K.Grid.explicit(coords)
+        ctx.ispec, ctx.fspec, ctx.grid, ctx.n_icnn = ispec, fspec, grid, n_icnn
+        ctx.shapes = [p.shape for p in params]
+        ctx.save_for_backward(ip, fp)
+        return FL.cdn_forward(ispec, fspec, ip, fp, grid)[0]
+
+    @staticmethod
+    def backward(ctx, dlogits: torch.Tensor):
+        ip, fp = ctx.saved_tensors
+        _, gi, gf = FL.cdn_loss_grad(ctx.ispec, ctx.fspec, ip, fp, ctx.grid, dlogits.contiguous()[None], loss="external")
+        g = torch.cat([gi[0], gf[0]])
+        outs, off = [], 0
+        for shp in ctx.shapes:
+            n = math.prod(shp) if len(shp) else 1
+            outs.append(g[off:off + n].reshape(shp))
+            off += n
+        return (None, None, None, None, *outs)
 
 
 class WNLinear(nn.Module):
@@ -157,8 +186,42 @@ class ConvexDiffeomorphismNet(nn.Module):
             return self.diffeo_net(self.linear(rows)).reshape(b, h, w, c).permute(0, 3, 1, 2)
         return self.diffeo_net(self.linear(x))
 
+    def _specs(self):
+        nf = self.diffeo_net
+        return self.convex_net.spec, FL.FlowSpec(nf.s[0].in_linear.linear.weight_v.shape[0], nf.num_coupling)
+
+    def _ordered_params(self):
+        ispec, fspec = self._specs()
+        sd = dict(self.named_parameters())
+        icnn = [sd["convex_net." + k] for k, _ in ispec.keys_shapes()]
+        flow = [sd[k] for k, _ in fspec.keys_shapes()]
+        return ispec, fspec, icnn, flow
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.convex_net(self.get_deformation(x))
+        """(B,2,H,W) -> (B,1,H,W) or (N,2) -> (N,1), forward and backward on the HIP path."""
+        if not x.is_cuda:
+            raise RuntimeError("awesome_amd modules run on the MI355X only (no CPU fallback); move module and input to cuda")
+        if self.in_features != 2:
+            raise ValueError("the coupling flow is 2-D only (like the reference, diffeomorphism_net.py:288)")
+        ispec, fspec, icnn, flow = self._ordered_params()
+        run = lambda coords: _CdnFunction.apply(coords, ispec, fspec, len(icnn), *icnn, *flow)  # noqa: E731
+        if x.dim() == 4:
+            b, c, h, w = x.shape
+            return torch.stack([run(x[i].reshape(c, h * w)).reshape(1, h, w) for i in range(b)], 0)
+        return run(x.t().contiguous())[:, None]
 
     def enforce_convexity(self) -> None:
         self.convex_net.enforce_convexity()
+
+    def fit_images(self, grid: "K.Grid", unaries: torch.Tensor, num_epochs: int = 2000, lr: float = 3e-3, loss: str = "bce",
+                   weight_decay_on_weight_g: float = 5e-5, plateau=None, init_from_self: bool = True):
+        """Fused device-resident form of `pretrain`'s inner loop (convex_diffeomorphism_net.py:405-430) for a batch of
+        images: every image starts from this module's current parameters; returns the CdnFitResult (flat parameters per
+        image; `FL.merge_cdn_state_dict` turns a row back into a state_dict for the PriorCache)."""
+        ispec, fspec, icnn, flow = self._ordered_params()
+        n, dev = unaries.shape[0], unaries.device
+        ip = torch.cat([p.detach().reshape(-1) for p in icnn]).to(torch.float32)[None].repeat(n, 1).contiguous().to(dev)
+        fp = torch.cat([p.detach().reshape(-1) for p in flow]).to(torch.float32)[None].repeat(n, 1).contiguous().to(dev)
+        return FL.cdn_fit(ispec, fspec, ip, fp, grid, unaries, num_epochs, lr=lr, loss=loss,
+                          weight_decay_on_weight_g=weight_decay_on_weight_g,
+                          plateau=dict(patience=200, factor=0.5) if plateau is None else (plateau or None))
