@@ -1,0 +1,95 @@
+"""The composition boundary: segmentation module (any torch module) + prior module (HIP path) -> (B, 2, H, W).
+
+Mirrors the behaviour of the reference's WrapperModule for the configuration every path-connectedness / convexity config
+uses (awesome/model/wrapper_module.py:13-49, 157-340): `input_mode='image'`, `prior_arg_mode='param_clean_grid'` (the
+prior is evaluated on the clean xy grid = second positional extra argument), sigmoid on both outputs, optional 1-x
+inversion of the segmentation, channel-concat `[seg, prior]`, one image per batch element.  The segmentation module is
+out of scope of the HIP path and runs as it is (torch / MIOpen)."""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+
+class ForwardModule(nn.Module):
+    """awesome/model/forward_module.py: forwards its input (used when the unaries are given directly)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+
+    def forward(self, fwd_input: torch.Tensor, *args, **kwargs) -> torch.Tensor:
+        return fwd_input if fwd_input.dim() >= 4 else fwd_input[None]
+
+
+class WrapperModule(nn.Module):
+    def __init__(self, segmentation_module: nn.Module = None, prior_module: Optional[nn.Module] = None, mode: str = "single",
+                 prior_arg_mode: str = "param_clean_grid", input_mode: str = "image", use_segmentation_sigmoid: bool = True,
+                 use_segmentation_output_inversion: bool = False, use_prior_sigmoid: bool = True, **kwargs):
+        super().__init__()
+        if input_mode != "image":
+            raise NotImplementedError("only input_mode='image' (dense grids) is on the MI355X path")
+        if prior_arg_mode not in ("param_clean_grid", "none"):
+            raise NotImplementedError(f"prior_arg_mode {prior_arg_mode!r} is not supported")
+        self.segmentation_module, self.prior_module = segmentation_module, prior_module
+        self.mode, self.prior_arg_mode, self.input_mode = mode, prior_arg_mode, input_mode
+        self.use_segmentation_sigmoid = use_segmentation_sigmoid
+        self.use_segmentation_output_inversion = use_segmentation_output_inversion
+        self.use_prior_sigmoid = use_prior_sigmoid
+        self.evaluate_prior = True  # TemporaryProperty(wrapper, evaluate_prior=False) in the pretrain loop (:832-836)
+
+    # -- pieces with the reference's names ---------------------------------------------------------------------------
+    def get_prior_args(self, _input: torch.Tensor, *args, segm: Optional[Any] = None, **kwargs) -> Tuple[List[Any], Dict[str, Any]]:
+        if self.prior_arg_mode == "none":
+            return [], {}
+        return [args[1]], {}   # param_clean_grid: (img, feat, xy_clean, ...) -> xy_clean   (wrapper_module.py:120-124)
+
+    def get_segmentation_module_args(self, primary: Any, args: Tuple[Any, ...], kwargs: Dict[str, Any]):
+        seg_args = args[:1] + (args[2:] if len(args) > 2 else ())   # the clean grid is withheld from the seg. net (:142-155)
+        return primary, seg_args, kwargs
+
+    def process_segmentation_output(self, segm: torch.Tensor) -> torch.Tensor:
+        if segm.shape[0] == 1:
+            segm = segm[0]
+        if self.use_segmentation_sigmoid:
+            segm = torch.sigmoid(segm)
+        return 1 - segm if self.use_segmentation_output_inversion else segm
+
+    def process_prior_output(self, prior: torch.Tensor, use_sigmoid: Optional[bool] = None, squeeze: bool = True) -> torch.Tensor:
+        if squeeze and prior.dim() == 4 and prior.shape[0] == 1:
+            prior = prior[0]
+        if (use_sigmoid is None and self.use_prior_sigmoid) or use_sigmoid:
+            prior = torch.sigmoid(prior)
+        return prior
+
+    def forward(self, _input: torch.Tensor, *args, **kwargs) -> torch.Tensor:
+        if _input.dim() == 3:
+            _input = _input[None]
+            args = tuple(a[None] if isinstance(a, torch.Tensor) and a.dim() == 3 else a for a in args)
+        res = []
+        for i in range(_input.shape[0]):
+            one = lambda t: t[i][None] if isinstance(t, torch.Tensor) else t  # noqa: E731
+            xi, ai = one(_input), tuple(one(a) for a in args)
+            seg_in, seg_args, seg_kwargs = self.get_segmentation_module_args(xi, ai, kwargs)
+            seg = self.process_segmentation_output(self.segmentation_module(seg_in, *seg_args, **seg_kwargs))
+            if self.prior_module is not None and self.evaluate_prior:
+                pa, pk = self.get_prior_args(xi, *ai, segm=seg)
+                prior = self.process_prior_output(self.prior_module(*pa, **pk))
+                res.append(torch.cat([seg, prior], dim=0))
+            else:
+                res.append(seg)
+        return torch.stack(res, dim=0)
+
+    def split_model_output(self, output: torch.Tensor, additional_data=None) -> List[Tuple[torch.Tensor, Optional[torch.Tensor]]]:
+        if output.dim() == 3:
+            output = output[None]
+        out = []
+        for b in range(output.shape[0]):
+            o = output[b]
+            out.append((o[: o.shape[0] // 2], o[o.shape[0] // 2:]) if self.prior_module is not None else (o, None))
+        return out
+
+    def enforce_convexity(self) -> None:
+        if self.prior_module is not None:
+            self.prior_module.enforce_convexity()

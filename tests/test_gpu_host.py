@@ -99,3 +99,38 @@ def test_run_py_config_entrypoint(tmp_path):
     assert summary["images"] == 1 and summary["ForegroundBinaryMIOU_vs_unaries"] > 0.98
     cache = torch.load(os.path.join(summary["output"], "prior_cache_epoch_0.pth"))
     assert "0" in cache["cache"] and "skip.0.ln.weight" in cache["cache"]["0"]
+
+
+def test_wrapper_module_joint_step(dev):
+    """WrapperModule(ForwardModule, ConvexNextNet) + AwesomeImageLoss: one joint training step like TorchAgent._perform_step
+    (forward -> (B,2,H,W), criterion, backward, step, enforce_convexity) against the oracle."""
+    from awesome_amd.measures import AwesomeImageLoss
+    from awesome_amd.model import ConvexNextNet, ForwardModule, WrapperModule
+    torch.manual_seed(4)
+    prior = ConvexNextNet(n_hidden=130)
+    sd = {k: v.clone() for k, v in prior.state_dict().items()}
+    w = WrapperModule(ForwardModule(), prior).to(dev)
+    H, W = 12, 9
+    grid = O.positional_grid(W, H)[None]
+    seg_logits = torch.randn(1, 1, H, W)
+    tgt = (torch.rand(1, 1, H, W) > 0.5).float()
+    out = w(seg_logits.to(dev), torch.zeros(1, 1, H, W, device=dev), grid.to(dev))
+    assert out.shape == (1, 2, H, W)
+    crit = AwesomeImageLoss(alpha=0.7)
+    crit.extra_penalty = True
+    loss = crit(out, tgt.to(dev))
+    loss.backward()
+    # oracle
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref_out = torch.cat([torch.sigmoid(seg_logits), torch.sigmoid(O.icnn_forward_image(p, grid))], dim=1)
+    ref_loss = O.awesome_image_loss(ref_out, tgt, alpha=0.7, extra_penalty=True)
+    ref_loss.backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref_out.detach().numpy(), atol=2e-6)
+    assert float(loss.detach()) == pytest.approx(float(ref_loss.detach()), rel=1e-5)
+    for k, prm in prior.named_parameters():
+        r = p[k].grad.numpy()
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), r, rtol=5e-4, atol=2e-6 * float(np.abs(r).max()) + 1e-9, err_msg=k)
+    seg, pr = w.split_model_output(out)[0]
+    assert seg.shape == (1, H, W) and pr.shape == (1, H, W)
+    w.evaluate_prior = False
+    assert w(seg_logits.to(dev), torch.zeros(1, 1, H, W, device=dev), grid.to(dev)).shape == (1, 1, H, W)
