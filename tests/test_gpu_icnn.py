@@ -214,3 +214,60 @@ def test_large_grid_properties(amd):
         assert float(got[k].min()) >= 0.0
     h = res.loss_hist[0].cpu().numpy()
     assert np.isfinite(h).all() and h[-1] < h[0]
+
+
+def test_edge_sizes_tiny_and_many_images(amd):
+    """N < one chunk (also N = 1), and more images than compute units (one workgroup per image)."""
+    dev = torch.device("cuda:0")
+    spec = amd.IcnnSpec(32, 2, 1)
+    torch.manual_seed(2)
+    for n_img, N in [(1, 1), (2, 5), (300, 37)]:
+        ps = [{k: (torch.rand(shp) - 0.4) * 0.6 for k, shp in spec.keys_shapes()} for _ in range(min(n_img, 3))]
+        flat = torch.stack([amd.pack_state_dict(spec, ps[i % len(ps)]) for i in range(n_img)]).to(dev)
+        coords = torch.rand(n_img, 2, N)
+        un = torch.rand(n_img, N)
+        grid = amd.Grid.explicit(coords.to(dev))
+        logits = amd.forward(spec, flat, grid).cpu()
+        loss, grads = amd.loss_grad(spec, flat, grid, un.to(dev))
+        for i in ([0, n_img - 1] if n_img > 1 else [0]):
+            p = ps[i % len(ps)]
+            g4 = coords[i].reshape(1, 2, 1, N)
+            ref = O.icnn_forward_image(p, g4).reshape(-1)
+            np.testing.assert_allclose(logits[i].numpy(), ref.numpy(), atol=5e-6, rtol=1e-5)
+            l_ref, g_ref = O.loss_and_grads(p, g4, un[i].reshape(1, 1, 1, N))
+            assert float(loss[i]) == pytest.approx(l_ref, rel=2e-5)
+            g = amd.unpack_params(spec, grads[i].cpu())
+            for k in g_ref:
+                sc = float(g_ref[k].abs().max())
+                np.testing.assert_allclose(g[k].numpy(), g_ref[k].numpy(), rtol=3e-4, atol=3e-6 * sc + 1e-9, err_msg=k)
+
+
+def test_spatio_temporal_grid_c4(amd):
+    """BASELINE configs[3] shape: ONE network over a 128x128x16 (x, y, t) volume (path_connected_net.py:511-728 fits one
+    prior for all frames): N = 262144 points, 3 coordinate channels, explicit planar grid.  Size-independent properties
+    plus oracle agreement of loss and gradient."""
+    dev = torch.device("cuda:0")
+    spec = amd.IcnnSpec(130, 3, 1)
+    torch.manual_seed(8)
+    p = {k: (torch.rand(shp) - 0.45) * 0.3 for k, shp in spec.keys_shapes()}
+    T, H, W = 16, 128, 128
+    frames = [O.positional_grid(W, H, t=float(t), t_max=float(T - 1)) for t in range(T)]     # (3,H,W) each
+    coords = torch.stack(frames, 1).reshape(3, T * H * W)                                        # planar [C][N]
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    un = torch.stack([(((yy - 60) ** 2 + (xx - 40 - 2 * t) ** 2) > 25 ** 2).float() for t in range(T)]).reshape(1, -1)
+    flat = amd.pack_state_dict(spec, p, dev)[None]
+    grid = amd.Grid.explicit(coords.to(dev))
+    l1, g1 = amd.loss_grad(spec, flat, grid, un.to(dev), loss="bce", weight_mode="sssdms")
+    l2, g2 = amd.loss_grad(spec, flat, grid, un.to(dev), loss="bce", weight_mode="sssdms")
+    assert torch.equal(l1, l2) and torch.equal(g1, g2)                      # reproducible at 4096 chunks
+    g4 = coords.reshape(1, 3, 1, -1)
+    l_ref, g_ref = O.loss_and_grads(p, g4, un.reshape(1, 1, 1, -1), "bce", "sssdms")
+    assert float(l1[0]) == pytest.approx(l_ref, rel=3e-5)
+    g = amd.unpack_params(spec, g1[0].cpu())
+    for k in g_ref:
+        sc = float(g_ref[k].abs().max())
+        np.testing.assert_allclose(g[k].numpy(), g_ref[k].numpy(), rtol=1e-3, atol=1e-5 * sc + 1e-10, err_msg=k)
+    res = amd.fit(spec, flat.clone(), grid, un.to(dev), 30, lr=1e-3, optimizer="adamax", loss="bce", weight_mode="sssdms",
+                  plateau=dict(patience=200, factor=0.5))
+    h = res.loss_hist[0].cpu().numpy()
+    assert np.isfinite(h).all() and h[-1] < h[0] and int(res.status[0]) == 0
