@@ -21,7 +21,7 @@ def hipcc_path() -> str:
 def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
-    deps = [SRC, os.path.join(HERE, "csrc", "icnn_step.h"), os.path.join(INCLUDE, "inrfit.h")]
+    deps = [SRC, os.path.join(INCLUDE, "inrfit.h")] + [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".h")]
     return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
 
 

@@ -22,6 +22,7 @@
 //   * fp32 everywhere (exact-f32 MFMA == fmaf chain), fixed-order reductions, no atomics: results are reproducible.
 #include "icnn_step.h"
 #include "icnn_step2.h"
+#include "icnn_step8.h"
 #include "flow.h"
 
 namespace {
@@ -280,11 +281,21 @@ struct KernelEntry {
     int h, c, l;
     void (*train)(const StepArgs);
     void (*train_dx)(const StepArgs);  // also writes dL/dcoords
+    void (*train8)(const StepArgs);    // 8-wave variant (two waves per SIMD) or null
     void (*fwd)(const StepArgs);
     int lds_bytes;
     int P;
     ImgMap img;
 };
+
+#ifndef INR_USE_WG8
+#define INR_USE_WG8 0  // experiment (icnn_step8.h): correct, but 108 us vs 73 us at 256x256 - spills at 256 regs/wave and doubled VALU issue
+#endif
+template <int H, int C>
+auto train8_of() -> void (*)(const StepArgs) {
+    if constexpr (INR_USE_WG8 && Cfg<H, C>::TM == 8 && Cfg<H, C>::HR <= 2) return icnn_step8_kernel<H, C>;
+    else return nullptr;
+}
 
 template <int H, int C>
 KernelEntry make_entry() {
@@ -296,8 +307,8 @@ KernelEntry make_entry() {
     for (int e = 0; e < 4; ++e) m.ext[e] = e < G::NEXT ? G::ext_pos(e) : 0;
     m.p_bin = G::P_BIN; m.p_w[0] = G::P_W1; m.p_b[0] = G::P_B1; m.p_s[0] = G::P_S1; m.p_wo = G::P_WO; m.p_bo = G::P_BO;
     m.p_so = G::P_SO; m.P = G::P;
-    return KernelEntry{H, C, 1, icnn_step_kernel<H, C, true>, icnn_step_kernel<H, C, true, true>, icnn_step_kernel<H, C, false>,
-                       G::LDS_BYTES, G::P, m};
+    return KernelEntry{H, C, 1, icnn_step_kernel<H, C, true>, icnn_step_kernel<H, C, true, true>, train8_of<H, C>(),
+                       icnn_step_kernel<H, C, false>, G::LDS_BYTES, G::P, m};
 }
 
 template <int H, int C>
@@ -311,7 +322,7 @@ KernelEntry make_entry2() {
     for (int e = 0; e < 4; ++e) m.ext[e] = e < G::NEXT ? G::ext_pos(e) : 0;
     m.p_bin = G::P_BIN; m.p_w[0] = G::P_W1; m.p_b[0] = G::P_B1; m.p_s[0] = G::P_S1; m.p_w[1] = G::P_W2; m.p_b[1] = G::P_B2;
     m.p_s[1] = G::P_S2; m.p_wo = G::P_WO; m.p_bo = G::P_BO; m.p_so = G::P_SO; m.P = G::P;
-    return KernelEntry{H, C, 2, icnn2_step_kernel<H, C, true>, icnn2_step_kernel<H, C, true, true>,
+    return KernelEntry{H, C, 2, icnn2_step_kernel<H, C, true>, icnn2_step_kernel<H, C, true, true>, nullptr,
                        icnn2_step_kernel<H, C, false>, G::LDS_BYTES, G::P, m};
 }
 
@@ -367,6 +378,9 @@ int set_lds(const KernelEntry* e) {
     if (hipFuncSetAttribute((const void*)e->fwd, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes) != hipSuccess)
         return INR_ELAUNCH;
     if (hipFuncSetAttribute((const void*)e->train_dx, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes) != hipSuccess)
+        return INR_ELAUNCH;
+    if (e->train8 &&
+        hipFuncSetAttribute((const void*)e->train8, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes + 1024) != hipSuccess)
         return INR_ELAUNCH;
     return INR_OK;
 }
@@ -445,8 +459,12 @@ static int launch_step(const KernelEntry* e, const Workspace& w, bool train, con
     a.wgs = w.wgs;
     a.PS = w.PS;
     a.loss_kind = loss_kind;
-    hipLaunchKernelGGL(train ? (dcoords ? e->train_dx : e->train) : e->fwd, dim3((unsigned)(n_images * w.wgs)), dim3(WG_THREADS),
-                       e->lds_bytes, s, a);
+    if (train && !dcoords && e->train8) {
+        hipLaunchKernelGGL(e->train8, dim3((unsigned)(n_images * w.wgs)), dim3(WG8_THREADS), e->lds_bytes + 1024, s, a);
+    } else {
+        hipLaunchKernelGGL(train ? (dcoords ? e->train_dx : e->train) : e->fwd, dim3((unsigned)(n_images * w.wgs)), dim3(WG_THREADS),
+                           e->lds_bytes, s, a);
+    }
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 
