@@ -53,16 +53,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # BENCH_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices and the
+    # collectives run on CPU tensors); the real multi-GPU run uses "nccl" (= RCCL over xGMI on ROCm), one rank per GPU.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)  # "nccl" == RCCL on ROCm
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product has no CPU path)")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if backend == "nccl" else torch.device("cpu")   # where the (tiny) collective payloads live
 
     import awesome_amd as A
     from awesome_amd.dataset import convex_blob_unaries
@@ -102,7 +108,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -111,8 +117,9 @@ def main():
     iou = A.miou((prob > 0.5).float(), (unaries > 0.5).float(), invert=True)
     status_bad = int((res.status != 0).sum().item())
     if world > 1:
-        gathered = [torch.zeros_like(iou) for _ in range(world)]
-        dist.all_gather(gathered, iou)   # the only data collective: a few bytes of metrics
+        iou_c = iou.to(cdev)
+        gathered = [torch.zeros_like(iou_c) for _ in range(world)]
+        dist.all_gather(gathered, iou_c)   # the only data collective: a few bytes of metrics
         iou_all = torch.cat(gathered)
     else:
         iou_all = iou
@@ -157,7 +164,7 @@ def main():
         barrier()
         tdt = time.perf_counter() - t1
         if world > 1:
-            tt = torch.tensor([tdt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([tdt], dtype=torch.float64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             tdt = float(tt.item())
         tiou = A.miou((torch.sigmoid(tres.logits) > 0.5).float(), (tun > 0.5).float(), invert=True)
