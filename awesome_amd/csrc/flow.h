@@ -27,7 +27,9 @@ struct FlowMap {   // layouts derived from (W, K)
     int W, K;
     int nb_stride;    // flat params per coupling net: v1[W] g1 b1[W] v2[W] g2 b2
     int p_nb, p_scale, FP;
-    int e_nb_stride;  // effective weights per coupling net: [W][4] = (w1, b1, w2, w1*w2) per unit, then b2 (padded to 4)
+    int e_cp_stride;  // effective weights per COUPLING (see "relu form" below): [W][8] records
+                      // (w1s, w1t, b1s, b1t, w2's, w2't, w1s*w2's, w1t*w2't) per unit, then (b2's, b2't, a's, a't):
+                      // the s and t nets share their input, so they are evaluated as one packed pair
     int e_nb, e_scale, FE;
 };
 
@@ -39,9 +41,9 @@ __host__ __device__ inline FlowMap make_flow_map(int W, int K) {
     m.p_nb = 6;
     m.p_scale = m.p_nb + 2 * K * m.nb_stride;
     m.FP = m.p_scale + 4 * K;
-    m.e_nb_stride = 4 * W + 4;
+    m.e_cp_stride = 8 * W + 4;
     m.e_nb = 8;
-    m.e_scale = m.e_nb + 2 * K * m.e_nb_stride;
+    m.e_scale = m.e_nb + K * m.e_cp_stride;
     m.FE = (m.e_scale + K + 3) / 4 * 4;
     return m;
 }
@@ -66,27 +68,66 @@ __device__ __forceinline__ void flow_weights_to_lds(const float* __restrict__ sr
     __syncthreads();
 }
 
-// tanh(w2 . leaky_relu(w1 u + b1) + b2) of one coupling net
-__device__ __forceinline__ float nb_forward(const float* e, int W, float u) {
-    float acc0 = e[4 * W], acc1 = 0.f;
-    int j = 0;
-    for (; j + 8 <= W; j += 8) {
-        f32x4 q[8];
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// "relu form" of a coupling net.  leaky_relu(p) = slope p + (1 - slope) relu(p), and the slope part is affine in u:
+//   w2 . leaky_relu(w1 u + b1) + b2  =  (b2 + slope <w2, b1>)  +  slope <w2, w1> u  +  sum_j w2'_j relu(w1_j u + b1_j)
+// with w2' = (1 - slope) w2.  The update kernel keeps b2' = b2 + slope <w2, b1>, a' = slope <w2, w1> and w2' in the
+// effective weights, so a unit costs fma + max + fma here, and its derivative is a' + sum_j (w1_j w2'_j) step(pre_j).
+// step(p) = (p > 0) is one multiply by 2^126 with the [0, 1] output clamp (exact for every normal p).
+__device__ __forceinline__ f32x2 step01(f32x2 pre) {
+    f32x2 r;
+    const f32x2 big = f32x2{0x1p126f, 0x1p126f};
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(pre), "v"(big));
+    return r;
+}
+
+// Points per lane.  Measured at one image (256x256, K=6, W=130; one wave per SIMD): forward 22 us / backward 29 us with one
+// point per lane; two points per lane (half the record reads, half the waves) 27 / 36 us; requesting the records one group
+// ahead behind sched_barriers 30 / 29 us (one point) and 29 / 36 us (two) - hipcc's own order of the plain loop wins.
+constexpr int FLOW_PPL = 1;
+
+// (NB_s(u), NB_t(u)) of one coupling for both nets at once on packed f32 pairs (v_pk_fma_f32: half the VALU
+// instructions of two scalar evaluations); DU adds the derivatives d(pre-tanh)/du: every unit adds (w1 w2') step(pre)
+template <bool DU>
+__device__ __forceinline__ void nb_pair_forward(const float* e, int W, const float (&u)[FLOW_PPL], f32x2 (&st)[FLOW_PPL],
+                                                f32x2 (&dpre_du)[FLOW_PPL]) {
+    const f32x4 tail = *(const f32x4*)(e + 8 * W);
+    f32x2 acc[FLOW_PPL], d[FLOW_PPL];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) q[k] = *(const f32x4*)(e + 4 * (j + k));
+    for (int q = 0; q < FLOW_PPL; ++q) {
+        acc[q] = f32x2{tail[2], tail[3]} * f32x2{u[q], u[q]} + f32x2{tail[0], tail[1]};
+        d[q] = f32x2{tail[2], tail[3]};
+    }
+    auto unit = [&](const f32x4& lo, const f32x4& hi) {   // lo = (w1s, w1t, b1s, b1t), hi = (w2's, w2't, w1s w2's, w1t w2't)
 #pragma unroll
-        for (int k = 0; k < 8; k += 2) {
-            const float p0 = fmaf(q[k][0], u, q[k][1]), p1 = fmaf(q[k + 1][0], u, q[k + 1][1]);
-            acc0 = fmaf(q[k][2], fmaxf(p0, LEAKY_SLOPE * p0), acc0);
-            acc1 = fmaf(q[k + 1][2], fmaxf(p1, LEAKY_SLOPE * p1), acc1);
+        for (int q = 0; q < FLOW_PPL; ++q) {
+            const f32x2 pre = f32x2{lo[0], lo[1]} * f32x2{u[q], u[q]} + f32x2{lo[2], lo[3]};
+            if (DU) {
+                const f32x2 sp = step01(pre);
+                acc[q] += f32x2{hi[0], hi[1]} * (pre * sp);
+                d[q] += f32x2{hi[2], hi[3]} * sp;
+            } else {
+                acc[q] += f32x2{hi[0], hi[1]} * f32x2{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f)};
+            }
         }
+    };
+    int j = 0;
+    for (; j + 4 <= W; j += 4) {
+        f32x4 r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = *(const f32x4*)(e + 8 * j + 4 * k);
+        unit(r[0], r[1]);
+        unit(r[2], r[3]);
+        unit(r[4], r[5]);
+        unit(r[6], r[7]);
     }
-    for (; j < W; ++j) {
-        const f32x4 q = *(const f32x4*)(e + 4 * j);
-        const float pre = fmaf(q[0], u, q[1]);
-        acc0 = fmaf(q[2], fmaxf(pre, LEAKY_SLOPE * pre), acc0);
+    for (; j < W; ++j) unit(*(const f32x4*)(e + 8 * j), *(const f32x4*)(e + 8 * j + 4));
+#pragma unroll
+    for (int q = 0; q < FLOW_PPL; ++q) {
+        st[q] = f32x2{tanhf(acc[q][0]), tanhf(acc[q][1])};
+        dpre_du[q] = d[q];
     }
-    return tanhf(acc0 + acc1);
 }
 
 struct FlowFwdArgs {
@@ -97,31 +138,43 @@ struct FlowFwdArgs {
     FlowMap m;
 };
 
+// grid: x = blocks of 256 * FLOW_PPL points (lane t of the block owns points base + q * 256 + t), y = image
 __global__ __launch_bounds__(256) void flow_fwd_kernel(const FlowFwdArgs a) {
     const int img = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
     const int N = (int)a.N;
-    const int pc = p < N ? p : N - 1;
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     flow_weights_to_lds(a.FE + (size_t)img * a.m.FE, fsm, a.m.FE);
     const float* e = fsm;
-    float xin[2];
-    load_coords2(a.grid, img, a.N, pc, xin);
-    float x1 = fmaf(e[0], xin[0], fmaf(e[1], xin[1], e[4]));
-    float x2 = fmaf(e[2], xin[0], fmaf(e[3], xin[1], e[5]));
+    int p[FLOW_PPL];
+    float x1[FLOW_PPL], x2[FLOW_PPL];
+#pragma unroll
+    for (int q = 0; q < FLOW_PPL; ++q) {
+        p[q] = (blockIdx.x * FLOW_PPL + q) * 256 + threadIdx.x;
+        float xin[2];
+        load_coords2(a.grid, img, a.N, p[q] < N ? p[q] : N - 1, xin);
+        x1[q] = fmaf(e[0], xin[0], fmaf(e[1], xin[1], e[4]));
+        x2[q] = fmaf(e[2], xin[0], fmaf(e[3], xin[1], e[5]));
+    }
     for (int i = 0; i < a.m.K; ++i) {
-        const float u = (i & 1) ? x2 : x1;
-        const float* es = e + a.m.e_nb + (2 * i) * a.m.e_nb_stride;
-        const float s = nb_forward(es, a.m.W, u);
-        const float t = nb_forward(es + a.m.e_nb_stride, a.m.W, u);
-        const float ex = expf(e[a.m.e_scale + i] * s);
-        if (i & 1) x1 = fmaf(ex, x1, t);
-        else x2 = fmaf(ex, x2, t);
+        float u[FLOW_PPL];
+        f32x2 st[FLOW_PPL], dd[FLOW_PPL];
+#pragma unroll
+        for (int q = 0; q < FLOW_PPL; ++q) u[q] = (i & 1) ? x2[q] : x1[q];
+        nb_pair_forward<false>(e + a.m.e_nb + i * a.m.e_cp_stride, a.m.W, u, st, dd);
+        const float sc = e[a.m.e_scale + i];
+#pragma unroll
+        for (int q = 0; q < FLOW_PPL; ++q) {
+            const float ex = expf(sc * st[q][0]);
+            if (i & 1) x1[q] = fmaf(ex, x1[q], st[q][1]);
+            else x2[q] = fmaf(ex, x2[q], st[q][1]);
+        }
     }
-    if (p < N) {
-        a.xd[((size_t)img * 2) * N + p] = x1;
-        a.xd[((size_t)img * 2 + 1) * N + p] = x2;
-    }
+#pragma unroll
+    for (int q = 0; q < FLOW_PPL; ++q)
+        if (p[q] < N) {
+            a.xd[((size_t)img * 2) * N + p[q]] = x1[q];
+            a.xd[((size_t)img * 2 + 1) * N + p[q]] = x2[q];
+        }
 }
 
 // ---- backward, lane = point ----------------------------------------------------------------------------------------------
@@ -138,87 +191,95 @@ struct FlowBwdArgs {
 
 template <int K>
 __global__ __launch_bounds__(256) void flow_bwd_points_kernel(const FlowBwdArgs a) {
+    constexpr int Q = FLOW_PPL;
     const int img = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
     const int N = (int)a.N, W = a.m.W;
-    const bool valid = p < N;
-    const int pc = valid ? p : N - 1;
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     flow_weights_to_lds(a.FE + (size_t)img * a.m.FE, fsm, a.m.FE);
     const float* e = fsm;
-    float xin[2];
-    load_coords2(a.grid, img, a.N, pc, xin);
-    // forward, keeping the state in front of every coupling and the net outputs
-    float x1s[K], x2s[K], sv[K], tv[K], ev[K];
-    float x1 = fmaf(e[0], xin[0], fmaf(e[1], xin[1], e[4]));
-    float x2 = fmaf(e[2], xin[0], fmaf(e[3], xin[1], e[5]));
+    int p[Q];
+    bool valid[Q];
+    float xin[Q][2];
+    // forward, keeping the state in front of every coupling, the net outputs and their input derivatives
+    float x1s[K][Q], x2s[K][Q], sv[K][Q], tv[K][Q], ev[K][Q], dsu[K][Q], dtu[K][Q];
+    float x1[Q], x2[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        p[q] = (blockIdx.x * Q + q) * 256 + threadIdx.x;
+        valid[q] = p[q] < N;
+        load_coords2(a.grid, img, a.N, valid[q] ? p[q] : N - 1, xin[q]);
+        x1[q] = fmaf(e[0], xin[q][0], fmaf(e[1], xin[q][1], e[4]));
+        x2[q] = fmaf(e[2], xin[q][0], fmaf(e[3], xin[q][1], e[5]));
+    }
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-        x1s[i] = x1;
-        x2s[i] = x2;
-        const float u = (i & 1) ? x2 : x1;
-        const float* es = e + a.m.e_nb + (2 * i) * a.m.e_nb_stride;
-        sv[i] = nb_forward(es, W, u);
-        tv[i] = nb_forward(es + a.m.e_nb_stride, W, u);
-        ev[i] = expf(e[a.m.e_scale + i] * sv[i]);
-        if (i & 1) x1 = fmaf(ev[i], x1, tv[i]);
-        else x2 = fmaf(ev[i], x2, tv[i]);
+        float u[Q];
+        f32x2 st[Q], dd[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            x1s[i][q] = x1[q];
+            x2s[i][q] = x2[q];
+            u[q] = (i & 1) ? x2[q] : x1[q];
+        }
+        nb_pair_forward<true>(e + a.m.e_nb + i * a.m.e_cp_stride, W, u, st, dd);
+        const float sc = e[a.m.e_scale + i];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            sv[i][q] = st[q][0];
+            tv[i][q] = st[q][1];
+            dsu[i][q] = dd[q][0];
+            dtu[i][q] = dd[q][1];
+            ev[i][q] = expf(sc * sv[i][q]);
+            if (i & 1) x1[q] = fmaf(ev[i][q], x1[q], tv[i][q]);
+            else x2[q] = fmaf(ev[i][q], x2[q], tv[i][q]);
+        }
     }
-    float d1 = valid ? a.dxd[((size_t)img * 2) * N + pc] : 0.f;
-    float d2 = valid ? a.dxd[((size_t)img * 2 + 1) * N + pc] : 0.f;
     float acc[3 * K + 6];  // dscale[K] | db2_s[K] | db2_t[K] | dA[4] | db[2]
 #pragma unroll
     for (int k = 0; k < 3 * K + 6; ++k) acc[k] = 0.f;
 #pragma unroll
-    for (int ii = 0; ii < K; ++ii) {
-        const int i = K - 1 - ii;
-        const bool odd = i & 1;
-        const float u = odd ? x2s[i] : x1s[i];
-        const float tpre = odd ? x1s[i] : x2s[i];
-        const float dpost = odd ? d1 : d2;
-        const float de = dpost * tpre;             // d/d exp(s)
-        const float sc = e[a.m.e_scale + i];
-        const float dse = de * ev[i];              // d/d (scale * s_raw)
-        acc[i] += dse * sv[i];                     // d/d scale_i
-        const float gqs = dse * sc * (1.f - sv[i] * sv[i]);   // d/d pre-tanh of the s net
-        const float gqt = dpost * (1.f - tv[i] * tv[i]);      // d/d pre-tanh of the t net
-        acc[K + i] += gqs;
-        acc[2 * K + i] += gqt;
-        // du = sum_j gq * w2_j * leaky'(pre_j) * w1_j  over both nets
-        const float* es = e + a.m.e_nb + (2 * i) * a.m.e_nb_stride;
-        const float* et = es + a.m.e_nb_stride;
-        float dus = 0.f, dut = 0.f;
-#pragma unroll 4
-        for (int j = 0; j < W; ++j) {
-            const f32x4 qs = *(const f32x4*)(es + 4 * j), qt = *(const f32x4*)(et + 4 * j);
-            const float ps_ = fmaf(qs[0], u, qs[1]);
-            const float pt_ = fmaf(qt[0], u, qt[1]);
-            dus = fmaf(qs[3], ps_ > 0.f ? 1.f : LEAKY_SLOPE, dus);   // qs[3] = w1 * w2
-            dut = fmaf(qt[3], pt_ > 0.f ? 1.f : LEAKY_SLOPE, dut);
+    for (int q = 0; q < Q; ++q) {
+        float d1 = valid[q] ? a.dxd[((size_t)img * 2) * N + p[q]] : 0.f;
+        float d2 = valid[q] ? a.dxd[((size_t)img * 2 + 1) * N + p[q]] : 0.f;
+#pragma unroll
+        for (int ii = 0; ii < K; ++ii) {
+            const int i = K - 1 - ii;
+            const bool odd = i & 1;
+            const float u = odd ? x2s[i][q] : x1s[i][q];
+            const float tpre = odd ? x1s[i][q] : x2s[i][q];
+            const float dpost = odd ? d1 : d2;
+            const float de = dpost * tpre;                // d/d exp(s)
+            const float sc = e[a.m.e_scale + i];
+            const float dse = de * ev[i][q];              // d/d (scale * s_raw)
+            acc[i] += dse * sv[i][q];                     // d/d scale_i
+            const float gqs = dse * sc * (1.f - sv[i][q] * sv[i][q]);   // d/d pre-tanh of the s net
+            const float gqt = dpost * (1.f - tv[i][q] * tv[i][q]);      // d/d pre-tanh of the t net
+            acc[K + i] += gqs;
+            acc[2 * K + i] += gqt;
+            const float du = gqs * dsu[i][q] + gqt * dtu[i][q];   // through both nets' inputs
+            if (valid[q]) {
+                float* pp = a.ps + (((size_t)img * K + i) * 3) * N + p[q];
+                pp[0] = u;
+                pp[(size_t)N] = gqs;
+                pp[2 * (size_t)N] = gqt;
+            }
+            const float dtpre = dpost * ev[i][q];
+            if (odd) {
+                d1 = dtpre;
+                d2 += du;
+            } else {
+                d2 = dtpre;
+                d1 += du;
+            }
         }
-        const float du = gqs * dus + gqt * dut;
-        if (valid) {
-            float* pp = a.ps + (((size_t)img * K + i) * 3) * N + p;
-            pp[0] = u;
-            pp[(size_t)N] = gqs;
-            pp[2 * (size_t)N] = gqt;
-        }
-        const float dtpre = dpost * ev[i];
-        if (odd) {
-            d1 = dtpre;
-            d2 += du;
-        } else {
-            d2 = dtpre;
-            d1 += du;
-        }
+        // nn.Linear(2,2): y_r = sum_c A[r][c] x_c + b_r
+        acc[3 * K + 0] += d1 * xin[q][0];
+        acc[3 * K + 1] += d1 * xin[q][1];
+        acc[3 * K + 2] += d2 * xin[q][0];
+        acc[3 * K + 3] += d2 * xin[q][1];
+        acc[3 * K + 4] += d1;
+        acc[3 * K + 5] += d2;
     }
-    // nn.Linear(2,2): y_r = sum_c A[r][c] x_c + b_r
-    acc[3 * K + 0] = d1 * xin[0];
-    acc[3 * K + 1] = d1 * xin[1];
-    acc[3 * K + 2] = d2 * xin[0];
-    acc[3 * K + 3] = d2 * xin[1];
-    acc[3 * K + 4] = d1;
-    acc[3 * K + 5] = d2;
     // block reduction (fixed order): wave sums by DPP/permlane, then the 4 waves through LDS
     __shared__ float red[4][3 * K + 6];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -244,19 +305,29 @@ struct FlowUnitsArgs {
     int chunks, Wp;      // Wp = unit blocks * 64
 };
 
+template <int UPL>   // units per lane: lane l owns units l, l + 64, ...
 __global__ __launch_bounds__(256) void flow_bwd_units_kernel(const FlowUnitsArgs a) {
-    // grid: x = chunk, y = (coupling*2 + net) * unit_blocks + ub, z = image; wave w of the block takes a quarter of the chunk
-    const int UB = a.Wp / 64;
-    const int img = blockIdx.z, chunk = blockIdx.x;
-    const int nb = blockIdx.y / UB, ub = blockIdx.y - nb * UB;
+    // grid: x = chunk, y = coupling*2 + net, z = image; wave w of the block takes a quarter of the chunk.
+    // In the relu form (above) the three effective-weight gradients of unit j need only two sums over the points,
+    //   A0_j = sum_p gq_p step(pre_jp),  A1_j = sum_p gq_p u_p step(pre_jp)      (and the unit-independent G0, G1 = sum gq, gq u):
+    //   db1_j = w2_j (slope G0 + (1-slope) A0_j),  dw1_j = w2_j (slope G1 + (1-slope) A1_j),
+    //   dw2_j = w1_j (slope G1 + (1-slope) A1_j) + b1_j (slope G0 + (1-slope) A0_j)
+    // i.e. per unit and PAIR of points one packed fma (pre), one packed step and two packed fmas.
+    const int img = blockIdx.z, chunk = blockIdx.x, nb = blockIdx.y;
     const int i = nb >> 1, net = nb & 1;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = (int)a.N, W = a.m.W;
-    const int unit = ub * 64 + lane;
-    const bool on = unit < W;
-    const float* __restrict__ e = a.FE + (size_t)img * a.m.FE + a.m.e_nb + nb * a.m.e_nb_stride;
-    const float w1 = on ? e[4 * unit] : 0.f, b1 = on ? e[4 * unit + 1] : 0.f, w2 = on ? e[4 * unit + 2] : 0.f;
+    const float* __restrict__ e = a.FE + (size_t)img * a.m.FE + a.m.e_nb + i * a.m.e_cp_stride + net;
+    float w1[UPL], b1[UPL], w2p[UPL];
+#pragma unroll
+    for (int r = 0; r < UPL; ++r) {
+        const int unit = r * 64 + lane;
+        const bool on = unit < W;
+        w1[r] = on ? e[8 * unit] : 0.f;
+        b1[r] = on ? e[8 * unit + 2] : 0.f;
+        w2p[r] = on ? e[8 * unit + 4] : 0.f;
+    }
     const int per_chunk = (N + a.chunks - 1) / a.chunks;
     const int per_wave = (per_chunk + 3) / 4;
     const int p0 = chunk * per_chunk + wave * per_wave;
@@ -266,24 +337,22 @@ __global__ __launch_bounds__(256) void flow_bwd_units_kernel(const FlowUnitsArgs
     if (p1 > N) p1 = N;
     const float* __restrict__ pu = a.ps + (((size_t)img * a.m.K + i) * 3) * N;
     const float* __restrict__ pg = pu + (size_t)(1 + net) * N;
-    float aw1 = 0.f, ab1 = 0.f, aw2 = 0.f;
-    auto one = [&](float u, float gq) {
-        const float pre = fmaf(w1, u, b1);
-        const float h = fmaxf(pre, LEAKY_SLOPE * pre);
-        aw2 = fmaf(gq, h, aw2);
-        const float dh = gq * w2 * (pre > 0.f ? 1.f : LEAKY_SLOPE);
-        aw1 = fmaf(dh, u, aw1);
-        ab1 += dh;
-    };
+    f32x2 A0[UPL], A1[UPL];
+#pragma unroll
+    for (int r = 0; r < UPL; ++r) A0[r] = A1[r] = f32x2{0.f, 0.f};
+    float g0 = 0.f, g1 = 0.f;
     // 64 points per trip: one coalesced vector load per array (the next trip's loads are already in flight), then every
-    // point's (u, gq) is broadcast to the wave with v_readlane - no memory access inside the 64-point body
+    // point's (u, gq, gq u) is broadcast to the wave with v_readlane - no memory access inside the 64-point body
     float un = 0.f, gn = 0.f;
     if (p0 + lane < p1) {
         un = pu[p0 + lane];
         gn = pg[p0 + lane];
     }
+    auto bc = [](float v, int k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k)); };
     for (int p = p0; p < p1; p += 64) {
-        const float uc = un, gc = gn;   // gq = 0 for the lanes past p1: those points contribute nothing
+        const float uc = un, gc = gn, guc = gn * un;   // gq = 0 for the lanes past p1: those points contribute nothing
+        g0 += gc;
+        g1 += guc;
         un = 0.f;
         gn = 0.f;
         if (p + 64 + lane < p1) {
@@ -291,19 +360,32 @@ __global__ __launch_bounds__(256) void flow_bwd_units_kernel(const FlowUnitsArgs
             gn = pg[p + 64 + lane];
         }
 #pragma unroll
-        for (int k = 0; k < 64; ++k)
-            one(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, uc), k)),
-                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gc), k)));
+        for (int k = 0; k < 64; k += 2) {
+            const f32x2 u2 = f32x2{bc(uc, k), bc(uc, k + 1)}, gq2 = f32x2{bc(gc, k), bc(gc, k + 1)};
+            const f32x2 gu2 = f32x2{bc(guc, k), bc(guc, k + 1)};
+#pragma unroll
+            for (int r = 0; r < UPL; ++r) {
+                const f32x2 st = step01(f32x2{w1[r], w1[r]} * u2 + f32x2{b1[r], b1[r]});
+                A0[r] += gq2 * st;
+                A1[r] += gu2 * st;
+            }
+        }
     }
-    __shared__ float red[4][3][64];
-    red[wave][0][lane] = aw1;
-    red[wave][1][lane] = ab1;
-    red[wave][2][lane] = aw2;
+    const float G0 = sum_over_groups(sum_over_points(g0)), G1 = sum_over_groups(sum_over_points(g1));   // in every lane
+    __shared__ float red[4][UPL][3][64];
+    constexpr float SL = LEAKY_SLOPE / (1.f - LEAKY_SLOPE);
+#pragma unroll
+    for (int r = 0; r < UPL; ++r) {
+        const float a0 = fmaf(SL, G0, A0[r][0] + A0[r][1]), a1 = fmaf(SL, G1, A1[r][0] + A1[r][1]);   // / (1 - slope)
+        red[wave][r][0][lane] = w2p[r] * a1;                                      // dw1
+        red[wave][r][1][lane] = w2p[r] * a0;                                      // db1
+        red[wave][r][2][lane] = (1.f - LEAKY_SLOPE) * fmaf(w1[r], a1, b1[r] * a0);   // dw2
+    }
     __syncthreads();
-    if (threadIdx.x < 192) {
-        const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
-        const float v = ((red[0][q][l] + red[1][q][l]) + red[2][q][l]) + red[3][q][l];
-        a.slab2[((((size_t)img * a.chunks + chunk) * (a.m.K * 2) + nb) * 3 + q) * a.Wp + ub * 64 + l] = v;
+    for (int t = threadIdx.x; t < UPL * 192; t += 256) {
+        const int r = t / 192, q = (t - r * 192) >> 6, l = t & 63;
+        const float v = ((red[0][r][q][l] + red[1][r][q][l]) + red[2][r][q][l]) + red[3][r][q][l];
+        a.slab2[((((size_t)img * a.chunks + chunk) * (a.m.K * 2) + nb) * 3 + q) * a.Wp + r * 64 + l] = v;
     }
 }
 
@@ -360,7 +442,7 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
     const float lr = u.lr_hdr ? u.lr_hdr[(size_t)img * u.hdr_stride + (u.t & 1)] : u.opt_desc.lr;
     if (nb < 2 * K) {
         const int pb = m.p_nb + nb * m.nb_stride;    // v1[W] g1 b1[W] v2[W] g2 b2
-        const int eb = m.e_nb + nb * m.e_nb_stride;  // w1[W] b1[W] w2[W] b2
+        const int eb = m.e_nb + (nb >> 1) * m.e_cp_stride + (nb & 1);  // this net's slots in the coupling's records
         const int i = nb >> 1, net = nb & 1;
         const bool on = tid < W;
         float v1 = on ? fp[pb + tid] : 0.f, b1 = on ? fp[pb + W + 1 + tid] : 0.f, v2 = on ? fp[pb + 2 * W + 1 + tid] : 0.f;
@@ -370,6 +452,7 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
             float dw1 = 0.f, db1 = 0.f, dw2 = 0.f;
             if (on) {
                 const float* s2 = u.slab2 + (((size_t)img * u.chunks * (K * 2) + nb) * 3) * u.Wp + tid;
+#pragma unroll 16
                 for (int c = 0; c < u.chunks; ++c) {
                     const float* q = s2 + (size_t)c * (K * 2) * 3 * u.Wp;
                     dw1 += q[0];
@@ -426,11 +509,19 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
         }
         // effective weights for the next forward
         const float n1 = sqrtf(block_sum256(v1 * v1, sm)), n2 = sqrtf(block_sum256(v2 * v2, sm));
+        const float w1e = v1 * (g1 / n1), w2e = v2 * (g2 / n2);   // 0 for the threads past W
+        const float sa = block_sum256(w2e * w1e, sm), sb = block_sum256(w2e * b1, sm);
         if (on) {
-            const float w1e = v1 * (g1 / n1), w2e = v2 * (g2 / n2);
-            *(f32x4*)(fe + eb + 4 * tid) = f32x4{w1e, b1, w2e, w1e * w2e};
+            const float w2p = (1.f - LEAKY_SLOPE) * w2e;
+            fe[eb + 8 * tid] = w1e;
+            fe[eb + 8 * tid + 2] = b1;
+            fe[eb + 8 * tid + 4] = w2p;
+            fe[eb + 8 * tid + 6] = w1e * w2p;
         }
-        if (tid == 0) fe[eb + 4 * W] = b2;
+        if (tid == 0) {
+            fe[eb + 8 * W] = fmaf(LEAKY_SLOPE, sb, b2);
+            fe[eb + 8 * W + 2] = LEAKY_SLOPE * sa;
+        }
         return;
     }
     // last block: WNScale parameters of every coupling + the 2x2 linear: first reduce their per-block partial sums

@@ -645,9 +645,9 @@ CdnWs carve_cdn(const KernelEntry* e, const InrFlowDesc* f, const InrGridDesc* g
     CdnWs w;
     const long long N = grid->n_points;
     w.fm = make_flow_map(f->width, f->num_coupling);
-    w.blocks1 = (int)((N + 255) / 256);
+    w.blocks1 = (int)((N + 256 * FLOW_PPL - 1) / (256 * FLOW_PPL));
     w.Wp = (f->width + 63) / 64 * 64;
-    w.chunks = 16;
+    w.chunks = 64;   // x 2K nets x 4 waves: enough waves for 1024 SIMDs at one image
     while (w.chunks > 1 && N / w.chunks < 256) w.chunks /= 2;
     w.S1 = 3 * f->num_coupling + 6;
     char* b = (char*)base;
@@ -735,7 +735,13 @@ void launch_flow_bwd(const CdnWs& w, const InrFlowDesc* f, const InrGridDesc* gr
     ua.m = w.fm;
     ua.chunks = w.chunks;
     ua.Wp = w.Wp;
-    hipLaunchKernelGGL(flow_bwd_units_kernel, dim3(w.chunks, 2 * f->num_coupling * (w.Wp / 64), n_images), dim3(256), 0, s, ua);
+    const dim3 g2(w.chunks, 2 * f->num_coupling, n_images);
+    switch (w.Wp / 64) {
+        case 1: hipLaunchKernelGGL(flow_bwd_units_kernel<1>, g2, dim3(256), 0, s, ua); break;
+        case 2: hipLaunchKernelGGL(flow_bwd_units_kernel<2>, g2, dim3(256), 0, s, ua); break;
+        case 3: hipLaunchKernelGGL(flow_bwd_units_kernel<3>, g2, dim3(256), 0, s, ua); break;
+        default: hipLaunchKernelGGL(flow_bwd_units_kernel<4>, g2, dim3(256), 0, s, ua); break;
+    }
 }
 
 int check_cdn(const InrModelDesc* model, const InrFlowDesc* flow, const InrGridDesc* grid, int n_images, void* workspace,

@@ -98,7 +98,7 @@ def _cdn_case(layers, width, K, h=130, seed=5):
     return m, {k: v.clone() for k, v in m.state_dict().items()}
 
 
-@pytest.mark.parametrize("layers,width,K", [(1, 130, 6), (2, 24, 4), (1, 70, 2)])
+@pytest.mark.parametrize("layers,width,K", [(1, 130, 6), (2, 24, 4), (1, 70, 2), (1, 200, 8), (2, 256, 2)])
 def test_hip_flow_forward_and_cdn_gradients(dev, layers, width, K):
     import awesome_amd as A
     from awesome_amd import flow as FL
