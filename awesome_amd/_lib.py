@@ -38,6 +38,15 @@ class InrFlowDesc(C.Structure):
     _fields_ = [("width", C.c_int32), ("num_coupling", C.c_int32)]
 
 
+INR_RNVP_MAX_FLOWS = 32
+
+
+class InrRnvpDesc(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("hidden_units", C.c_int32), ("n_flows", C.c_int32), ("output_fn", C.c_int32),
+                ("output_scale", C.c_float), ("vmin", C.c_float * 3), ("vmax", C.c_float * 3), ("new_min", C.c_float),
+                ("new_max", C.c_float), ("masks", C.c_uint32 * INR_RNVP_MAX_FLOWS)]
+
+
 class InrLossDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("weight_mode", C.c_int32), ("ratio", C.c_float), ("c_fg", C.c_float),
                 ("c_bg", C.c_float)]
@@ -76,6 +85,21 @@ EXPORTS = {
                                        C.POINTER(InrGridDesc), C.c_void_p, C.POINTER(InrLossDesc), C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "inrfit_cdn_fit": (C.c_int, [C.POINTER(InrModelDesc), C.POINTER(InrFlowDesc), C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.POINTER(InrGridDesc), C.c_void_p, C.POINTER(InrLossDesc),
+                                 C.POINTER(InrOptDesc), C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_rnvp_param_count": (C.c_int64, [C.POINTER(InrRnvpDesc)]),
+    "inrfit_pcn_workspace_bytes": (C.c_int64, [C.POINTER(InrModelDesc), C.POINTER(InrRnvpDesc), C.POINTER(InrGridDesc), C.c_int]),
+    "inrfit_rnvp_actnorm_init": (C.c_int, [C.POINTER(InrRnvpDesc), C.c_void_p, C.POINTER(InrGridDesc), C.c_int, C.c_void_p,
+                                           C.c_int64, C.c_void_p]),
+    "inrfit_rnvp_forward": (C.c_int, [C.POINTER(InrRnvpDesc), C.c_void_p, C.POINTER(InrGridDesc), C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_pcn_forward": (C.c_int, [C.POINTER(InrModelDesc), C.POINTER(InrRnvpDesc), C.c_void_p, C.c_void_p,
+                                     C.POINTER(InrGridDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_pcn_loss_grad": (C.c_int, [C.POINTER(InrModelDesc), C.POINTER(InrRnvpDesc), C.c_void_p, C.c_void_p,
+                                       C.POINTER(InrGridDesc), C.c_void_p, C.POINTER(InrLossDesc), C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_pcn_fit": (C.c_int, [C.POINTER(InrModelDesc), C.POINTER(InrRnvpDesc), C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.POINTER(InrGridDesc), C.c_void_p, C.POINTER(InrLossDesc),
                                  C.POINTER(InrOptDesc), C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -24,6 +24,7 @@
 #include "icnn_step2.h"
 #include "icnn_step8.h"
 #include "flow.h"
+#include "rnvp.h"
 
 namespace {
 
@@ -475,6 +476,36 @@ static int check_loss(const InrLossDesc* l) {
     return INR_OK;
 }
 
+// the ICNN update arguments shared by every fit loop (t, bias corrections and hist_idx are set per step)
+static UpdArgs make_upd_args(const KernelEntry* e, const Workspace& w, float* params, float* opt_state, float* loss_hist,
+                             int32_t* status, const InrOptDesc* opt, int n_images, int steps) {
+    UpdArgs u{};
+    u.wimg = w.wimg;
+    u.img = e->img;
+    u.params = params;
+    u.opt_state = opt_state;
+    u.slabs = w.slabs;
+    u.loss_hist = loss_hist;
+    u.status = status;
+    u.opt = *opt;
+    u.P = e->P;
+    u.PS = w.PS;
+    u.wgs = w.wgs;
+    u.n_images = n_images;
+    u.hist_stride = steps;
+    u.one_minus_b1 = (float)(1.0 - (double)opt->beta1);
+    u.one_minus_b2 = (float)(1.0 - (double)opt->beta2);
+    u.mode = 0;
+    for (int k = 0; k < 3; ++k) u.clamp_lo[k] = u.clamp_hi[k] = 0;
+    for (int k = 0; k < e->img.L; ++k) {
+        u.clamp_lo[k] = e->img.p_w[k];
+        u.clamp_hi[k] = e->img.p_w[k] + e->img.H * e->img.H;
+    }
+    u.clamp_lo[2] = e->img.p_wo;
+    u.clamp_hi[2] = e->img.p_wo + e->img.H;
+    return u;
+}
+
 // common argument checks + workspace carve
 static int prepare(const InrModelDesc* model, const InrGridDesc* grid, int n_images, void* workspace, int64_t workspace_bytes,
                    const KernelEntry** e_out, Workspace* w_out) {
@@ -582,30 +613,7 @@ int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const
         if (hipMemsetAsync(status, 0, sizeof(int32_t) * n_images, s) != hipSuccess) return INR_ELAUNCH;
     }
     if ((rc = launch_pack(e, w, params, n_images, s))) return rc;
-    UpdArgs u{};
-    u.wimg = w.wimg;
-    u.img = e->img;
-    u.params = params;
-    u.opt_state = opt_state;
-    u.slabs = w.slabs;
-    u.loss_hist = loss_hist;
-    u.status = status;
-    u.opt = *opt;
-    u.P = e->P;
-    u.PS = w.PS;
-    u.wgs = w.wgs;
-    u.n_images = n_images;
-    u.hist_stride = steps;
-    u.one_minus_b1 = (float)(1.0 - (double)opt->beta1);
-    u.one_minus_b2 = (float)(1.0 - (double)opt->beta2);
-    u.mode = 0;
-    for (int k = 0; k < 3; ++k) u.clamp_lo[k] = u.clamp_hi[k] = 0;
-    for (int k = 0; k < e->img.L; ++k) {
-        u.clamp_lo[k] = e->img.p_w[k];
-        u.clamp_hi[k] = e->img.p_w[k] + e->img.H * e->img.H;
-    }
-    u.clamp_lo[2] = e->img.p_wo;
-    u.clamp_hi[2] = e->img.p_wo + e->img.H;
+    UpdArgs u = make_upd_args(e, w, params, opt_state, loss_hist, status, opt, n_images, steps);
     const dim3 ugrid((e->P + 1 + UPD_PARAMS - 1) / UPD_PARAMS, n_images);
     for (int it = 0; it < steps; ++it) {
         if ((rc = launch_step(e, w, true, grid, targets, loss->kind, n_images, nullptr, s))) return rc;
@@ -856,30 +864,7 @@ int inrfit_cdn_fit(const InrModelDesc* model, const InrFlowDesc* flow, float* ic
     if (status && hipMemsetAsync(status, 0, sizeof(int32_t) * n_images, s) != hipSuccess) return INR_ELAUNCH;
     if ((rc = launch_pack(e, w.icnn, icnn_params, n_images, s))) return rc;
     launch_flow_update(w, flow, n_images, 2, flow_params, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0, s);  // effective weights
-    UpdArgs u{};
-    u.wimg = w.icnn.wimg;
-    u.img = e->img;
-    u.params = icnn_params;
-    u.opt_state = icnn_opt_state;
-    u.slabs = w.icnn.slabs;
-    u.loss_hist = loss_hist;
-    u.status = status;
-    u.opt = *opt;
-    u.P = e->P;
-    u.PS = w.icnn.PS;
-    u.wgs = w.icnn.wgs;
-    u.n_images = n_images;
-    u.hist_stride = steps;
-    u.one_minus_b1 = (float)(1.0 - (double)opt->beta1);
-    u.one_minus_b2 = (float)(1.0 - (double)opt->beta2);
-    u.mode = 0;
-    for (int k = 0; k < 3; ++k) u.clamp_lo[k] = u.clamp_hi[k] = 0;
-    for (int k = 0; k < e->img.L; ++k) {
-        u.clamp_lo[k] = e->img.p_w[k];
-        u.clamp_hi[k] = e->img.p_w[k] + e->img.H * e->img.H;
-    }
-    u.clamp_lo[2] = e->img.p_wo;
-    u.clamp_hi[2] = e->img.p_wo + e->img.H;
+    UpdArgs u = make_upd_args(e, w.icnn, icnn_params, icnn_opt_state, loss_hist, status, opt, n_images, steps);
     const dim3 ugrid((e->P + 1 + UPD_PARAMS - 1) / UPD_PARAMS, n_images);
     const long long hdr_stride = 2 * (long long)e->P + INR_OPT_HEADER_FLOATS;
     for (int it = 0; it < steps; ++it) {
@@ -898,6 +883,309 @@ int inrfit_cdn_fit(const InrModelDesc* model, const InrFlowDesc* flow, float* ic
     if (hipGetLastError() != hipSuccess) return INR_ELAUNCH;
     if (final_logits) {
         launch_flow_fwd(w, grid, n_images, w.xd, s);
+        return launch_step(e, w.icnn, false, &w.dgrid, nullptr, 0, n_images, final_logits, s);
+    }
+    return INR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// path-connected prior with the normflows RealNVP deformation: ICNN(minmax^-1(RealNVP(minmax(a (.) x + b))))
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct PcnWs {
+    Workspace icnn;
+    float *xd, *dxd, *zs, *ps, *slab1, *slab2;
+    int blocks1, chunks, S1;
+    RnvpMap rm;
+    long long bytes;
+    InrGridDesc dgrid;
+};
+
+bool rnvp_ok(const InrRnvpDesc* r) {
+    if (!r || (r->channels != 2 && r->channels != 3)) return false;
+    if (r->hidden_units < 1 || r->hidden_units > 64 || r->n_flows < 1 || r->n_flows > INR_RNVP_MAX_FLOWS) return false;
+    if (r->output_fn != 0 && r->output_fn != 1) return false;
+    for (int f = 0; f < r->n_flows; ++f)
+        if (r->masks[f] < 1u || r->masks[f] > (1u << r->channels) - 2u) return false;   // at least one input and one output
+    for (int c = 0; c < r->channels; ++c)
+        if (!(r->vmax[c] > r->vmin[c])) return false;
+    if (!(r->new_max > r->new_min)) return false;
+    const int ldsf = RNVP_HDR + r->n_flows * (r->hidden_units * RNVP_REC + RNVP_TAIL);
+    return (ldsf + 4 * (r->n_flows * 4 * r->channels + 2 * r->channels)) * 4 <= 64 * 1024;
+}
+
+RnvpMap make_rnvp_map(const InrRnvpDesc* r) {
+    RnvpMap m{};
+    m.C = r->channels;
+    m.HID = r->hidden_units;
+    m.F = r->n_flows;
+    m.net = 2 * m.HID * m.C + m.HID + m.C;
+    m.pf = 2 * m.net + 2 * m.C;
+    m.RP = 2 * m.C + m.F * m.pf;
+    m.fl = m.HID * RNVP_REC + RNVP_TAIL;
+    m.LDSF = RNVP_HDR + m.F * m.fl;
+    m.A = 2 * m.C - 1;
+    m.out_fn = r->output_fn;
+    m.out_scale = r->output_fn ? (r->output_scale != 0.f ? r->output_scale : 1.f) : 1.f;
+    for (int c = 0; c < 3; ++c) {
+        m.vmin[c] = c < m.C ? r->vmin[c] : 0.f;
+        m.vmax[c] = c < m.C ? r->vmax[c] : 1.f;
+    }
+    m.nmin = r->new_min;
+    m.nmax = r->new_max;
+    for (int f = 0; f < RNVP_MAX_FLOWS; ++f) m.masks[f] = f < m.F ? r->masks[f] : 1u;
+    return m;
+}
+
+PcnWs carve_pcn(const KernelEntry* e, const InrRnvpDesc* r, const InrGridDesc* grid, int n_images, void* base) {
+    PcnWs w;
+    const long long N = grid->n_points;
+    w.rm = make_rnvp_map(r);
+    const int C = w.rm.C, F = w.rm.F;
+    w.blocks1 = (int)((N + 255) / 256);
+    w.chunks = 16;
+    while (w.chunks > 1 && N / w.chunks < 256) w.chunks /= 2;
+    w.S1 = F * 4 * C + 2 * C;
+    char* b = (char*)base;
+    long long off = 0;
+    auto take = [&](long long bytes) { float* p = (float*)(b + off); off += align256(bytes); return p; };
+    w.xd = take((long long)n_images * C * N * 4);
+    w.dxd = take((long long)n_images * C * N * 4);
+    w.zs = take((long long)n_images * F * C * N * 4);
+    w.ps = take((long long)n_images * F * w.rm.A * N * 4);
+    w.slab1 = take((long long)n_images * w.blocks1 * w.S1 * 4);
+    w.slab2 = take((long long)n_images * w.chunks * F * 2 * (2 * C + 1) * 64 * 4);
+    w.dgrid = *grid;
+    w.dgrid.mode = INR_GRID_EXPLICIT;
+    w.dgrid.coords = w.xd;
+    w.dgrid.coords_image_stride = (long long)C * N;
+    if (e) {
+        w.icnn = carve(e, N, n_images, b + off);
+        off += align256(w.icnn.bytes);
+    }
+    w.bytes = off;
+    return w;
+}
+
+int check_pcn(const InrModelDesc* model, const InrRnvpDesc* r, const InrGridDesc* grid, int n_images, void* workspace,
+              int64_t workspace_bytes, bool need_icnn, const KernelEntry** e_out, PcnWs* w_out) {
+    if (!rnvp_ok(r)) return INR_EUNSUPPORTED;
+    const KernelEntry* e = nullptr;
+    if (need_icnn) {
+        e = find_entry(model);
+        if (!e) return INR_EUNSUPPORTED;
+        if (e->c != r->channels) return INR_EINVAL;
+    }
+    if (!workspace || !grid || grid->n_points <= 0 || grid->n_points > 0x7fffffffLL || n_images <= 0) return INR_EINVAL;
+    if (grid->mode == INR_GRID_SEPARABLE) {
+        if (!grid->xs || !grid->ys || (long long)grid->width * grid->height != grid->n_points) return INR_EINVAL;
+        if (r->channels == 3 && !grid->ts) return INR_EINVAL;
+    } else if (grid->mode == INR_GRID_EXPLICIT) {
+        if (!grid->coords) return INR_EINVAL;
+    } else {
+        return INR_EINVAL;
+    }
+    *w_out = carve_pcn(e, r, grid, n_images, workspace);
+    if (workspace_bytes < w_out->bytes) return INR_EWORKSPACE;
+    if (e) {
+        const int rc = set_lds(e);
+        if (rc) return rc;
+    }
+    *e_out = e;
+    return INR_OK;
+}
+
+void launch_rnvp_fwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, int n_images, float* out, bool keep, hipStream_t s) {
+    RnvpFwdArgs a{};
+    a.RP = rp;
+    a.xd = out;
+    a.zs = keep ? w.zs : nullptr;
+    a.grid = *grid;
+    a.N = grid->n_points;
+    a.m = w.rm;
+    const dim3 g(w.blocks1, n_images);
+    const size_t lds = (size_t)w.rm.LDSF * sizeof(float);
+    if (w.rm.C == 2) hipLaunchKernelGGL(rnvp_fwd_kernel<2>, g, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(rnvp_fwd_kernel<3>, g, dim3(256), lds, s, a);
+}
+
+void launch_rnvp_bwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, int n_images, hipStream_t s) {
+    RnvpBwdArgs a{};
+    a.RP = rp;
+    a.dxd = w.dxd;
+    a.zs = w.zs;
+    a.ps = w.ps;
+    a.slab1 = w.slab1;
+    a.grid = *grid;
+    a.N = grid->n_points;
+    a.m = w.rm;
+    a.S1 = w.S1;
+    const dim3 g1(w.blocks1, n_images);
+    const size_t lds = (size_t)(w.rm.LDSF + 4 * w.S1) * sizeof(float);
+    if (w.rm.C == 2) hipLaunchKernelGGL(rnvp_bwd_points_kernel<2>, g1, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(rnvp_bwd_points_kernel<3>, g1, dim3(256), lds, s, a);
+    RnvpUnitsArgs ua{};
+    ua.RP = rp;
+    ua.ps = w.ps;
+    ua.slab2 = w.slab2;
+    ua.N = grid->n_points;
+    ua.m = w.rm;
+    ua.chunks = w.chunks;
+    const dim3 g2(w.chunks, 2 * w.rm.F, n_images);
+    if (w.rm.C == 2) hipLaunchKernelGGL(rnvp_bwd_units_kernel<2>, g2, dim3(256), 0, s, ua);
+    else hipLaunchKernelGGL(rnvp_bwd_units_kernel<3>, g2, dim3(256), 0, s, ua);
+}
+
+void launch_rnvp_update(const PcnWs& w, int n_images, int mode, float* rp, float* opt, float* grads_out, const InrOptDesc* od,
+                        float wd_flow, int t, const float* lr_hdr, long long hdr_stride, const int32_t* status, hipStream_t s) {
+    RnvpUpdArgs u{};
+    u.RP = rp;
+    u.opt = opt;
+    u.grads_out = grads_out;
+    u.slab1 = w.slab1;
+    u.slab2 = w.slab2;
+    u.lr_hdr = lr_hdr;
+    u.hdr_stride = hdr_stride;
+    u.status = status;
+    if (od) u.opt_desc = *od;
+    u.m = w.rm;
+    u.blocks1 = w.blocks1;
+    u.S1 = w.S1;
+    u.chunks = w.chunks;
+    u.t = t;
+    if (od && t > 0) {
+        u.bc1 = 1.0 - pow((double)od->beta1, (double)t);
+        u.bc2_sqrt = (float)sqrt(1.0 - pow((double)od->beta2, (double)t));
+        u.one_minus_b1 = (float)(1.0 - (double)od->beta1);
+        u.one_minus_b2 = (float)(1.0 - (double)od->beta2);
+    }
+    u.wd_flow = wd_flow;
+    u.mode = mode;
+    const dim3 g(w.rm.F + 1, n_images);
+    if (w.rm.C == 2) hipLaunchKernelGGL(rnvp_update_kernel<2>, g, dim3(256), 0, s, u);
+    else hipLaunchKernelGGL(rnvp_update_kernel<3>, g, dim3(256), 0, s, u);
+}
+
+}  // namespace
+
+int64_t inrfit_rnvp_param_count(const InrRnvpDesc* rnvp) {
+    if (!rnvp_ok(rnvp)) return INR_EUNSUPPORTED;
+    return make_rnvp_map(rnvp).RP;
+}
+
+int64_t inrfit_pcn_workspace_bytes(const InrModelDesc* model, const InrRnvpDesc* rnvp, const InrGridDesc* grid, int n_images) {
+    if (!rnvp_ok(rnvp)) return INR_EUNSUPPORTED;
+    if (!grid || grid->n_points <= 0 || n_images <= 0) return INR_EINVAL;
+    const KernelEntry* e = model ? find_entry(model) : nullptr;
+    if (model && !e) return INR_EUNSUPPORTED;
+    return carve_pcn(e, rnvp, grid, n_images, nullptr).bytes;
+}
+
+int inrfit_rnvp_actnorm_init(const InrRnvpDesc* rnvp, float* flow_params, const InrGridDesc* grid, int n_images, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+    const KernelEntry* e;
+    PcnWs w;
+    if (!flow_params) return INR_EINVAL;
+    int rc = check_pcn(nullptr, rnvp, grid, n_images, workspace, workspace_bytes, false, &e, &w);
+    if (rc) return rc;
+    RnvpInitArgs a{};
+    a.RP = flow_params;
+    a.z = w.xd;
+    a.grid = *grid;
+    a.N = grid->n_points;
+    a.m = w.rm;
+    const size_t lds = (size_t)(RNVP_HDR + w.rm.fl) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (w.rm.C == 2) hipLaunchKernelGGL(rnvp_actnorm_init_kernel<2>, dim3(n_images), dim3(1024), lds, s, a);
+    else hipLaunchKernelGGL(rnvp_actnorm_init_kernel<3>, dim3(n_images), dim3(1024), lds, s, a);
+    return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
+}
+
+int inrfit_rnvp_forward(const InrRnvpDesc* rnvp, const float* flow_params, const InrGridDesc* grid, int n_images,
+                        float* out_coords, void* workspace, int64_t workspace_bytes, void* stream) {
+    const KernelEntry* e;
+    PcnWs w;
+    if (!flow_params || !out_coords) return INR_EINVAL;
+    int rc = check_pcn(nullptr, rnvp, grid, n_images, workspace, workspace_bytes, false, &e, &w);
+    if (rc) return rc;
+    launch_rnvp_fwd(w, flow_params, grid, n_images, out_coords, false, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
+}
+
+int inrfit_pcn_forward(const InrModelDesc* model, const InrRnvpDesc* rnvp, const float* icnn_params, const float* flow_params,
+                       const InrGridDesc* grid, int n_images, float* logits, void* workspace, int64_t workspace_bytes,
+                       void* stream) {
+    const KernelEntry* e;
+    PcnWs w;
+    if (!icnn_params || !flow_params || !logits) return INR_EINVAL;
+    int rc = check_pcn(model, rnvp, grid, n_images, workspace, workspace_bytes, true, &e, &w);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    launch_rnvp_fwd(w, flow_params, grid, n_images, w.xd, false, s);
+    if ((rc = launch_pack(e, w.icnn, icnn_params, n_images, s))) return rc;
+    return launch_step(e, w.icnn, false, &w.dgrid, nullptr, 0, n_images, logits, s);
+}
+
+int inrfit_pcn_loss_grad(const InrModelDesc* model, const InrRnvpDesc* rnvp, const float* icnn_params,
+                         const float* flow_params, const InrGridDesc* grid, const float* targets, const InrLossDesc* loss,
+                         int n_images, float* loss_out, float* icnn_grads, float* flow_grads, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
+    const KernelEntry* e;
+    PcnWs w;
+    if (!icnn_params || !flow_params || !targets || !loss_out || !icnn_grads || !flow_grads) return INR_EINVAL;
+    int rc = check_loss(loss);
+    if (rc) return rc;
+    if ((rc = check_pcn(model, rnvp, grid, n_images, workspace, workspace_bytes, true, &e, &w))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    launch_rnvp_fwd(w, flow_params, grid, n_images, w.xd, true, s);
+    hipLaunchKernelGGL(loss_coef_kernel, dim3(n_images), dim3(256), 0, s, targets, (long long)grid->n_points, *loss, w.icnn.coef);
+    if ((rc = launch_pack(e, w.icnn, icnn_params, n_images, s))) return rc;
+    if ((rc = launch_step(e, w.icnn, true, &w.dgrid, targets, loss->kind, n_images, nullptr, s, w.dxd))) return rc;
+    launch_reduce(e, w.icnn, n_images, icnn_grads, loss_out, s);
+    launch_rnvp_bwd(w, flow_params, grid, n_images, s);
+    launch_rnvp_update(w, n_images, 1, (float*)flow_params, nullptr, flow_grads, nullptr, 0.f, 0, nullptr, 0, nullptr, s);
+    return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
+}
+
+int inrfit_pcn_fit(const InrModelDesc* model, const InrRnvpDesc* rnvp, float* icnn_params, float* flow_params,
+                   float* icnn_opt_state, float* flow_opt_state, const InrGridDesc* grid, const float* targets,
+                   const InrLossDesc* loss, const InrOptDesc* opt, float flow_weight_decay, int n_images, int steps, int step0,
+                   float* loss_hist, float* final_logits, int32_t* status, void* workspace, int64_t workspace_bytes,
+                   void* stream) {
+    const KernelEntry* e;
+    PcnWs w;
+    if (!icnn_params || !flow_params || !icnn_opt_state || !flow_opt_state || !targets || !opt || steps < 0 || step0 < 0)
+        return INR_EINVAL;
+    if (opt->kind != INR_OPT_ADAM && opt->kind != INR_OPT_ADAMAX) return INR_EINVAL;
+    int rc = check_loss(loss);
+    if (rc) return rc;
+    if (loss->kind == INR_LOSS_EXTERNAL) return INR_EINVAL;
+    if ((rc = check_pcn(model, rnvp, grid, n_images, workspace, workspace_bytes, true, &e, &w))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(loss_coef_kernel, dim3(n_images), dim3(256), 0, s, targets, (long long)grid->n_points, *loss, w.icnn.coef);
+    hipLaunchKernelGGL(opt_init_kernel, dim3(n_images), dim3(64), 0, s, icnn_opt_state, e->P, *opt, step0);
+    if (status && hipMemsetAsync(status, 0, sizeof(int32_t) * n_images, s) != hipSuccess) return INR_ELAUNCH;
+    if ((rc = launch_pack(e, w.icnn, icnn_params, n_images, s))) return rc;
+    UpdArgs u = make_upd_args(e, w.icnn, icnn_params, icnn_opt_state, loss_hist, status, opt, n_images, steps);
+    const dim3 ugrid((e->P + 1 + UPD_PARAMS - 1) / UPD_PARAMS, n_images);
+    const long long hdr_stride = 2 * (long long)e->P + INR_OPT_HEADER_FLOATS;
+    for (int it = 0; it < steps; ++it) {
+        launch_rnvp_fwd(w, flow_params, grid, n_images, w.xd, true, s);
+        if ((rc = launch_step(e, w.icnn, true, &w.dgrid, targets, loss->kind, n_images, nullptr, s, w.dxd))) return rc;
+        u.t = step0 + it + 1;
+        u.bc1 = 1.0 - pow((double)opt->beta1, (double)u.t);
+        u.bc2_sqrt = (float)sqrt(1.0 - pow((double)opt->beta2, (double)u.t));
+        u.hist_idx = it;
+        hipLaunchKernelGGL(icnn_update_kernel, ugrid, dim3(UPD_PARAMS / 4, UPD_GROUPS), 0, s, u);
+        launch_rnvp_bwd(w, flow_params, grid, n_images, s);
+        // the learning rate of THIS step sits in header[t & 1] (the plateau thread wrote the next one into the other slot)
+        launch_rnvp_update(w, n_images, 0, flow_params, flow_opt_state, nullptr, opt, flow_weight_decay, u.t,
+                           icnn_opt_state + 2 * (size_t)e->P, hdr_stride, status, s);
+    }
+    if (hipGetLastError() != hipSuccess) return INR_ELAUNCH;
+    if (final_logits) {
+        launch_rnvp_fwd(w, flow_params, grid, n_images, w.xd, false, s);
         return launch_step(e, w.icnn, false, &w.dgrid, nullptr, 0, n_images, final_logits, s);
     }
     return INR_OK;

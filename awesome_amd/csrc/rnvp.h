@@ -1,0 +1,720 @@
+// rnvp.h - HIP kernels for the RealNVP deformation of PathConnectedNet (jp-schneider/awesome awesome/model/path_connected_net.py:
+// 79-85; flow built by awesome/model/net_factory.py:70-114,124-175 from the third-party package normflows==1.7.3).
+//
+// The arithmetic of the flow lives in normflows, which is NOT part of the reference checkout: what follows restates its
+// published definitions (PARITY UNPINNED), anchored on the reference's call sites:
+//   v   = a (.) x + b                                       1x1 depthwise conv "linear"      path_connected_net.py:65-77
+//   z   = (v - min)/(max - min) * (new_max - new_min) + new_min      MinMax.transform       transforms/min_max.py:8-19,53-55
+//   for f in 0..F-1:                                        init_realnvp                     net_factory.py:70-114
+//       zm = b_f (.) z                                      nf.flows.MaskedAffineFlow(b, t, s)
+//       s  = out(W2s relu(W1s zm + b1s) + b2s) ;  t likewise   nf.nets.MLP([C, hid, C], init_zeros, output_fn='tanh')
+//       z  = zm + (1 - b_f) (.) (z (.) exp(s) + t)
+//       z  = z (.) exp(as_f) + at_f                         nf.flows.ActNorm(C) (data-dependent init at first forward)
+//   xd  = (z - new_min)/(new_max - new_min) * (max - min) + min       MinMax.inverse_transform   norm_net.py:17-27
+// Masks b_f count in binary over the channels (net_factory.py:86-99): every flow has NIN = |b| inputs and NOUT = C - NIN
+// outputs; C = 2 -> (1,1), C = 3 -> (1,2) or (2,1).  Only those rows/columns of the MLPs ever receive a gradient.
+//
+// Elementwise per point with two tiny C -> hid -> C MLPs per flow: VALU work (hid = 32: 1.5k MAC per point at C = 2,
+// 4 % of the ICNN behind it).  The s and t nets share their input and are evaluated as packed f32 pairs.
+//   rnvp_fwd_kernel<C>         lane = point; optionally keeps the state in front of every flow (zs) for the backward
+//   rnvp_bwd_points_kernel<C>  lane = point; walks the flows backwards from zs: per point and flow the MLP inputs and the
+//                              gradients at the MLP outputs (ps), block sums of the per-point-scalar gradients (b2, ActNorm, a, b)
+//   rnvp_bwd_units_kernel      lane = hidden unit; streams ps and accumulates the moment sums that give dW1, db1, dW2
+//   rnvp_update_kernel         fixed-order slab sums + Adam/Adamax (weight decay on every flow parameter,
+//                              path_connected_net.py:924-929)
+//   rnvp_actnorm_init_kernel   ActNorm's data-dependent initialisation, flow after flow
+#pragma once
+#include "flow.h"
+
+namespace {
+
+constexpr int RNVP_MAX_FLOWS = 32;
+constexpr int RNVP_REC = 8;     // LDS floats per hidden unit: (W1s,W1t)[NIN] (b1s,b1t) (W2s,W2t)[NOUT], 2(C+1) <= 8
+constexpr int RNVP_TAIL = 12;   // per flow: (b2s,b2t)[2] | exp(as)[3] | at[3] | pad
+constexpr int RNVP_HDR = 16;    // a[3] | b[3] | pad
+
+struct RnvpMap {
+    int C, HID, F;
+    int net;    // floats per MLP: W1 [HID][C] | b1 [HID] | W2 [C][HID] | b2 [C]
+    int pf;     // floats per flow: s-net | t-net | as [C] | at [C]
+    int RP;     // lin.weight [C] | lin.bias [C] | flows
+    int fl;     // LDS floats per flow
+    int LDSF;   // LDS floats of the whole image
+    int A;      // per-point arrays per flow in ps: zin [NIN] | do_s [NOUT] | do_t [NOUT]  (<= 2C - 1)
+    int out_fn; // 0 = none, 1 = tanh
+    float out_scale;
+    float vmin[3], vmax[3], nmin, nmax;
+    unsigned masks[RNVP_MAX_FLOWS];
+};
+
+struct FlowIdx {   // wave-uniform; scalars + selects only (an indexed member array would live in scratch)
+    int nin, nout;
+    int in0, in1, out0, out1;
+    __host__ __device__ int in(int q) const { return q == 0 ? in0 : in1; }
+    __host__ __device__ int out(int q) const { return q == 0 ? out0 : out1; }
+};
+
+template <int C>
+__host__ __device__ inline FlowIdx flow_idx(unsigned mask) {
+    const bool b0 = mask & 1u, b1 = (mask >> 1) & 1u, b2 = C > 2 && ((mask >> 2) & 1u);
+    FlowIdx x;
+    x.nin = (int)b0 + (int)b1 + (int)b2;
+    x.nout = C - x.nin;
+    x.in0 = b0 ? 0 : (b1 ? 1 : 2);
+    x.in1 = (b0 && b1) ? 1 : 2;
+    x.out0 = !b0 ? 0 : (!b1 ? 1 : 2);
+    x.out1 = (!b0 && !b1) ? 1 : 2;
+    return x;
+}
+
+template <int C>
+__device__ __forceinline__ float sel(const float (&z)[C], int idx) {   // uniform idx: no dynamic register indexing
+    float v = z[0];
+    if (idx == 1) v = z[1];
+    if (C > 2 && idx == 2) v = z[C > 2 ? 2 : 0];
+    return v;
+}
+
+__device__ __forceinline__ float minmax_fwd(float v, float lo, float hi, float nlo, float nhi) {   // transforms/min_max.py:8-19
+    return (v - lo) / (hi - lo) * (nhi - nlo) + nlo;
+}
+
+// flat parameters of one image -> LDS image (records by flow; only the active rows/columns of every flow's MLPs)
+template <int C>
+__device__ __forceinline__ void rnvp_params_to_lds(const float* __restrict__ rp, float* lds, const RnvpMap& m, int f0, int f1) {
+    for (int i = threadIdx.x; i < RNVP_HDR; i += blockDim.x) lds[i] = i < 3 ? (i < C ? rp[i] : 0.f) : (i < 6 ? (i - 3 < C ? rp[C + i - 3] : 0.f) : 0.f);
+    for (int f = f0; f < f1; ++f) {
+        const FlowIdx x = flow_idx<C>(m.masks[f]);
+        const float* __restrict__ pf = rp + 2 * C + (size_t)f * m.pf;
+        float* dst = lds + RNVP_HDR + (f - f0) * m.fl;
+        for (int i = threadIdx.x; i < m.HID * RNVP_REC; i += blockDim.x) {
+            const int j = i >> 3, slot = i & 7, q = slot >> 1;
+            const float* __restrict__ pn = pf + (slot & 1) * m.net;
+            float v = 0.f;
+            if (q < x.nin) v = pn[j * C + x.in(q)];
+            else if (q == x.nin) v = pn[m.HID * C + j];
+            else if (q < x.nin + 1 + x.nout) v = pn[m.HID * C + m.HID + x.out(q - x.nin - 1) * m.HID + j];
+            dst[i] = v;
+        }
+        for (int i = threadIdx.x; i < RNVP_TAIL; i += blockDim.x) {
+            float v = 0.f;
+            if (i < 4) {
+                const int k = i >> 1;
+                if (k < x.nout) v = pf[(i & 1) * m.net + 2 * m.HID * C + m.HID + x.out(k)];
+            } else if (i < 7) {
+                if (i - 4 < C) v = expf(pf[2 * m.net + i - 4]);
+            } else if (i < 10) {
+                if (i - 7 < C) v = pf[2 * m.net + C + i - 7];
+            }
+            dst[m.HID * RNVP_REC + i] = v;
+        }
+    }
+    __syncthreads();
+}
+
+// pre-activation outputs o[k] = (o_s, o_t) of the two MLPs of one flow for the NOUT active output channels;
+// DU: also J[k][m] = d o[k] / d zin[m] (packed for both nets).
+template <int NIN, int NOUT, bool DU>
+__device__ __forceinline__ void rnvp_nets(const float* rec, int HID, const float (&zin)[NIN], f32x2 (&o)[NOUT], f32x2 (&J)[NOUT][NIN]) {
+    const f32x4 tl = *(const f32x4*)(rec + HID * RNVP_REC);
+    o[0] = f32x2{tl[0], tl[1]};
+    if (NOUT > 1) o[NOUT - 1] = f32x2{tl[2], tl[3]};
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k)
+#pragma unroll
+        for (int mm = 0; mm < NIN; ++mm) J[k][mm] = f32x2{0.f, 0.f};
+#pragma unroll 4
+    for (int j = 0; j < HID; ++j) {
+        const f32x4 r0 = *(const f32x4*)(rec + RNVP_REC * j), r1 = *(const f32x4*)(rec + RNVP_REC * j + 4);
+        const float v[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+        f32x2 pre = f32x2{v[2 * NIN], v[2 * NIN + 1]};
+#pragma unroll
+        for (int mm = 0; mm < NIN; ++mm) pre += f32x2{v[2 * mm], v[2 * mm + 1]} * f32x2{zin[mm], zin[mm]};
+        if (DU) {
+            const f32x2 st = step01(pre);
+            const f32x2 h = pre * st;
+            f32x2 t[NIN];
+#pragma unroll
+            for (int mm = 0; mm < NIN; ++mm) t[mm] = st * f32x2{v[2 * mm], v[2 * mm + 1]};
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) {
+                const f32x2 w2 = f32x2{v[2 * (NIN + 1 + k)], v[2 * (NIN + 1 + k) + 1]};
+                o[k] += w2 * h;
+#pragma unroll
+                for (int mm = 0; mm < NIN; ++mm) J[k][mm] += w2 * t[mm];
+            }
+        } else {
+            const f32x2 h = f32x2{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f)};
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) o[k] += f32x2{v[2 * (NIN + 1 + k)], v[2 * (NIN + 1 + k) + 1]} * h;
+        }
+    }
+}
+
+// dispatch on the flow's mask shape; results in fixed [2]-arrays (unused slots untouched)
+template <int C, bool DU>
+__device__ __forceinline__ void rnvp_nets_any(const float* rec, int HID, const FlowIdx& x, const float (&z)[C], f32x2 (&o)[2],
+                                              f32x2 (&J)[2][2]) {
+    if (C == 2 || x.nin == 1) {
+        const float zin[1] = {sel<C>(z, x.in(0))};
+        if (C == 2) {
+            f32x2 o1[1], J1[1][1];
+            rnvp_nets<1, 1, DU>(rec, HID, zin, o1, J1);
+            o[0] = o1[0];
+            J[0][0] = J1[0][0];
+        } else {
+            f32x2 o2[2], J2[2][1];
+            rnvp_nets<1, 2, DU>(rec, HID, zin, o2, J2);
+            o[0] = o2[0];
+            o[1] = o2[1];
+            J[0][0] = J2[0][0];
+            J[1][0] = J2[1][0];
+        }
+    } else {
+        const float zin[2] = {sel<C>(z, x.in(0)), sel<C>(z, x.in(1))};
+        f32x2 o1[1], J1[1][2];
+        rnvp_nets<2, 1, DU>(rec, HID, zin, o1, J1);
+        o[0] = o1[0];
+        J[0][0] = J1[0][0];
+        J[0][1] = J1[0][1];
+    }
+}
+
+// one flow on z (MaskedAffineFlow, then ActNorm unless !ACTNORM); y[k] = (s, t) after the output function
+template <int C, bool ACTNORM>
+__device__ __forceinline__ void rnvp_flow_forward(const float* rec, const RnvpMap& m, const FlowIdx& x, float (&z)[C]) {
+    f32x2 o[2], J[2][2];
+    rnvp_nets_any<C, false>(rec, m.HID, x, z, o, J);
+#pragma unroll
+    for (int k = 0; k < C - 1; ++k) {   // fixed bounds + guards: no dynamically indexed registers
+        if (k < x.nout) {
+            float s = o[k][0], t = o[k][1];
+            if (m.out_fn) {
+                s = tanhf(s) * m.out_scale;
+                t = tanhf(t) * m.out_scale;
+            }
+            const float es = expf(s);
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                if (c == x.out(k)) z[c] = fmaf(z[c], es, t);
+        }
+    }
+    if (ACTNORM) {
+        const float* tl = rec + m.HID * RNVP_REC;
+#pragma unroll
+        for (int c = 0; c < C; ++c) z[c] = fmaf(z[c], tl[4 + c], tl[7 + c]);
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void load_coords(const InrGridDesc& gd, int img, long long N, int pc, float (&x)[C]) {
+    if (gd.mode == INR_GRID_SEPARABLE) {
+        const int row = pc / gd.width;
+        x[0] = gd.xs[pc - row * gd.width];
+        x[1] = gd.ys[row];
+        if (C > 2) x[C - 1] = gd.ts[img];
+    } else {
+        const float* cp = gd.coords + (size_t)img * gd.coords_image_stride;
+#pragma unroll
+        for (int c = 0; c < C; ++c) x[c] = cp[(size_t)c * N + pc];
+    }
+}
+
+struct RnvpFwdArgs {
+    const float* RP;   // [n_images][RP]
+    float* xd;         // [n_images][C][N] deformed coordinates
+    float* zs;         // [n_images][F][C][N] state in front of every flow, or null
+    InrGridDesc grid;
+    long long N;
+    RnvpMap m;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void rnvp_fwd_kernel(const RnvpFwdArgs a) {
+    const int img = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int N = (int)a.N;
+    const bool valid = p < N;
+    extern __shared__ __attribute__((aligned(16))) float rsm[];
+    rnvp_params_to_lds<C>(a.RP + (size_t)img * a.m.RP, rsm, a.m, 0, a.m.F);
+    float x[C], z[C];
+    load_coords<C>(a.grid, img, a.N, valid ? p : N - 1, x);
+#pragma unroll
+    for (int c = 0; c < C; ++c) z[c] = minmax_fwd(fmaf(rsm[c], x[c], rsm[3 + c]), a.m.vmin[c], a.m.vmax[c], a.m.nmin, a.m.nmax);
+    for (int f = 0; f < a.m.F; ++f) {
+        if (a.zs != nullptr && valid) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) a.zs[(((size_t)img * a.m.F + f) * C + c) * N + p] = z[c];
+        }
+        rnvp_flow_forward<C, true>(rsm + RNVP_HDR + f * a.m.fl, a.m, flow_idx<C>(a.m.masks[f]), z);
+    }
+    if (valid) {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            a.xd[((size_t)img * C + c) * N + p] = minmax_fwd(z[c], a.m.nmin, a.m.nmax, a.m.vmin[c], a.m.vmax[c]);
+    }
+}
+
+// ---- backward, lane = point ----------------------------------------------------------------------------------------------
+struct RnvpBwdArgs {
+    const float* RP;
+    const float* dxd;   // [n_images][C][N]
+    const float* zs;    // [n_images][F][C][N]
+    float* ps;          // [n_images][F][A][N]
+    float* slab1;       // [n_images][blocks][S1]; S1 = F*4C (b2s[C] b2t[C] as[C] at[C] per flow) + 2C (a, b)
+    InrGridDesc grid;
+    long long N;
+    RnvpMap m;
+    int S1;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void rnvp_bwd_points_kernel(const RnvpBwdArgs a) {
+    const int img = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int N = (int)a.N, F = a.m.F;
+    const bool valid = p < N;
+    const int pc = valid ? p : N - 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ __attribute__((aligned(16))) float rsm[];
+    float* red = rsm + a.m.LDSF;   // [4][S1]
+    rnvp_params_to_lds<C>(a.RP + (size_t)img * a.m.RP, rsm, a.m, 0, F);
+    // gradient at the flow output: through MinMax.inverse_transform
+    float g[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float d = valid ? a.dxd[((size_t)img * C + c) * N + pc] : 0.f;
+        g[c] = d * (a.m.vmax[c] - a.m.vmin[c]) / (a.m.nmax - a.m.nmin);
+    }
+    for (int f = F - 1; f >= 0; --f) {
+        const float* rec = rsm + RNVP_HDR + f * a.m.fl;
+        const float* tl = rec + a.m.HID * RNVP_REC;
+        const FlowIdx x = flow_idx<C>(a.m.masks[f]);
+        float z[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) z[c] = a.zs[(((size_t)img * F + f) * C + c) * N + pc];
+        f32x2 o[2], J[2][2];
+        rnvp_nets_any<C, true>(rec, a.m.HID, x, z, o, J);
+        float acc[4 * C];   // db2s[C] | db2t[C] | das[C] | dat[C]
+#pragma unroll
+        for (int k = 0; k < 4 * C; ++k) acc[k] = 0.f;
+        // post-coupling state and the outputs of the nets
+        float zc[C], es[2], dfs[2], dft[2];
+#pragma unroll
+        for (int c = 0; c < C; ++c) zc[c] = z[c];
+#pragma unroll
+        for (int k = 0; k < C - 1; ++k) {
+            es[k] = dfs[k] = dft[k] = 0.f;
+            if (k < x.nout) {
+                float s = o[k][0], t = o[k][1];
+                dfs[k] = dft[k] = 1.f;
+                if (a.m.out_fn) {
+                    const float ths = tanhf(s), tht = tanhf(t);
+                    s = ths * a.m.out_scale;
+                    t = tht * a.m.out_scale;
+                    dfs[k] = (1.f - ths * ths) * a.m.out_scale;
+                    dft[k] = (1.f - tht * tht) * a.m.out_scale;
+                }
+                es[k] = expf(s);
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (c == x.out(k)) zc[c] = fmaf(z[c], es[k], t);
+            }
+        }
+        // ActNorm: y = zc * exp(as) + at
+        float gz[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float ea = tl[4 + c];
+            acc[2 * C + c] = g[c] * zc[c] * ea;
+            acc[3 * C + c] = g[c];
+            gz[c] = g[c] * ea;
+        }
+        // coupling
+        float dos[2] = {0.f, 0.f}, dot[2] = {0.f, 0.f}, gin[2] = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < C - 1; ++k) {
+            if (k < x.nout) {
+                const float gk = sel<C>(gz, x.out(k)), zk = sel<C>(z, x.out(k));
+                dos[k] = gk * zk * es[k] * dfs[k];
+                dot[k] = gk * dft[k];
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (c == x.out(k)) {
+                        gz[c] = gk * es[k];
+                        acc[c] = dos[k];
+                        acc[C + c] = dot[k];
+                    }
+#pragma unroll
+                for (int mm = 0; mm < C - 1; ++mm)
+                    if (mm < x.nin) gin[mm] += dos[k] * J[k][mm][0] + dot[k] * J[k][mm][1];
+            }
+        }
+#pragma unroll
+        for (int mm = 0; mm < C - 1; ++mm) {
+            if (mm < x.nin) {
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (c == x.in(mm)) gz[c] += gin[mm];
+            }
+        }
+        if (valid) {
+            float* pp = a.ps + (((size_t)img * F + f) * a.m.A) * N + p;
+            int q = 0;
+#pragma unroll
+            for (int mm = 0; mm < C - 1; ++mm)
+                if (mm < x.nin) pp[(size_t)(q++) * N] = sel<C>(z, x.in(mm));
+#pragma unroll
+            for (int k = 0; k < C - 1; ++k)
+                if (k < x.nout) pp[(size_t)(q++) * N] = dos[k];
+#pragma unroll
+            for (int k = 0; k < C - 1; ++k)
+                if (k < x.nout) pp[(size_t)(q++) * N] = dot[k];
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) g[c] = gz[c];
+#pragma unroll
+        for (int k = 0; k < 4 * C; ++k) {
+            const float v = sum_over_groups(sum_over_points(acc[k]));
+            if (lane == 0) red[wave * a.S1 + f * 4 * C + k] = v;
+        }
+    }
+    // MinMax.transform and the 1x1 "linear": z0 = ((a x + b) - min)/(max - min) * (nmax - nmin) + nmin
+    {
+        float x[C];
+        load_coords<C>(a.grid, img, a.N, pc, x);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float gv = g[c] * (a.m.nmax - a.m.nmin) / (a.m.vmax[c] - a.m.vmin[c]);
+            const float da = sum_over_groups(sum_over_points(gv * x[c])), db = sum_over_groups(sum_over_points(gv));
+            if (lane == 0) {
+                red[wave * a.S1 + F * 4 * C + c] = da;
+                red[wave * a.S1 + F * 4 * C + C + c] = db;
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < a.S1; k += 256)
+        a.slab1[((size_t)img * gridDim.x + blockIdx.x) * a.S1 + k] = ((red[k] + red[a.S1 + k]) + red[2 * a.S1 + k]) + red[3 * a.S1 + k];
+}
+
+// ---- backward, lane = hidden unit -----------------------------------------------------------------------------------------
+struct RnvpUnitsArgs {
+    const float* RP;
+    const float* ps;     // [n_images][F][A][N]
+    float* slab2;        // [n_images][chunks][F*2][2C+1][64]  rows: dW1[:, c] (C) | db1 | dW2[c, :] (C)
+    long long N;
+    RnvpMap m;
+    int chunks;
+};
+
+// relu nets: with st = step(pre_j), S0[k] = sum_p do_k st and S1[k][m] = sum_p do_k zin_m st give
+//   db1_j = sum_k W2[k][j] S0[k];  dW1[j][m] = sum_k W2[k][j] S1[k][m];  dW2[k][j] = sum_m W1[j][m] S1[k][m] + b1_j S0[k]
+template <int C, int NIN, int NOUT>
+__device__ __forceinline__ void rnvp_units_body(const RnvpUnitsArgs& a, const FlowIdx& x, float (*red)[2 * 3 + 1][64]) {
+    const int img = blockIdx.z, chunk = blockIdx.x, fn = blockIdx.y;
+    const int f = fn >> 1, net = fn & 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = (int)a.N, HID = a.m.HID;
+    const bool on = lane < HID;
+    const float* __restrict__ pn = a.RP + (size_t)img * a.m.RP + 2 * C + (size_t)f * a.m.pf + net * a.m.net;
+    float w1[NIN], w2[NOUT], b1 = on ? pn[HID * C + lane] : 0.f;
+#pragma unroll
+    for (int mm = 0; mm < NIN; ++mm) w1[mm] = on ? pn[lane * C + x.in(mm)] : 0.f;
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) w2[k] = on ? pn[HID * C + HID + x.out(k) * HID + lane] : 0.f;
+    const int per_chunk = (N + a.chunks - 1) / a.chunks;
+    const int per_wave = (per_chunk + 3) / 4;
+    const int p0 = chunk * per_chunk + wave * per_wave;
+    int p1 = p0 + per_wave;
+    const int cend = (chunk + 1) * per_chunk;
+    if (p1 > cend) p1 = cend;
+    if (p1 > N) p1 = N;
+    const float* __restrict__ base = a.ps + (((size_t)img * a.m.F + f) * a.m.A) * N;
+    const float* __restrict__ pz[NIN];
+    const float* __restrict__ pd[NOUT];
+#pragma unroll
+    for (int mm = 0; mm < NIN; ++mm) pz[mm] = base + (size_t)mm * N;
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) pd[k] = base + (size_t)(NIN + net * NOUT + k) * N;
+    f32x2 S0[NOUT], S1[NOUT][NIN];
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) {
+        S0[k] = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int mm = 0; mm < NIN; ++mm) S1[k][mm] = f32x2{0.f, 0.f};
+    }
+    auto bc = [](float v, int k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k)); };
+    float zn[NIN], dn[NOUT];
+    auto fetch = [&](int p) {
+        const bool in = p + lane < p1;
+#pragma unroll
+        for (int mm = 0; mm < NIN; ++mm) zn[mm] = in ? pz[mm][p + lane] : 0.f;
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) dn[k] = in ? pd[k][p + lane] : 0.f;   // do = 0 past p1: those points contribute nothing
+    };
+    fetch(p0);
+    for (int p = p0; p < p1; p += 64) {
+        float zc[NIN], dc[NOUT], pr[NOUT][NIN];
+#pragma unroll
+        for (int mm = 0; mm < NIN; ++mm) zc[mm] = zn[mm];
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) {
+            dc[k] = dn[k];
+#pragma unroll
+            for (int mm = 0; mm < NIN; ++mm) pr[k][mm] = dn[k] * zn[mm];
+        }
+        fetch(p + 64);
+#pragma unroll
+        for (int q = 0; q < 64; q += 2) {
+            f32x2 pre = f32x2{b1, b1};
+#pragma unroll
+            for (int mm = 0; mm < NIN; ++mm) pre += f32x2{w1[mm], w1[mm]} * f32x2{bc(zc[mm], q), bc(zc[mm], q + 1)};
+            const f32x2 st = step01(pre);
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) {
+                S0[k] += f32x2{bc(dc[k], q), bc(dc[k], q + 1)} * st;
+#pragma unroll
+                for (int mm = 0; mm < NIN; ++mm) S1[k][mm] += f32x2{bc(pr[k][mm], q), bc(pr[k][mm], q + 1)} * st;
+            }
+        }
+    }
+    float s0[NOUT], s1[NOUT][NIN];
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) {
+        s0[k] = S0[k][0] + S0[k][1];
+#pragma unroll
+        for (int mm = 0; mm < NIN; ++mm) s1[k][mm] = S1[k][mm][0] + S1[k][mm][1];
+    }
+    float rows[2 * C + 1];
+#pragma unroll
+    for (int r = 0; r < 2 * C + 1; ++r) rows[r] = 0.f;
+    float db1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) {
+        db1 = fmaf(w2[k], s0[k], db1);
+        float dw2 = b1 * s0[k];
+#pragma unroll
+        for (int mm = 0; mm < NIN; ++mm) dw2 = fmaf(w1[mm], s1[k][mm], dw2);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            if (c == x.out(k)) rows[C + 1 + c] = dw2;
+    }
+#pragma unroll
+    for (int mm = 0; mm < NIN; ++mm) {
+        float dw1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) dw1 = fmaf(w2[k], s1[k][mm], dw1);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            if (c == x.in(mm)) rows[c] = dw1;
+    }
+    rows[C] = db1;
+#pragma unroll
+    for (int r = 0; r < 2 * C + 1; ++r) red[wave][r][lane] = rows[r];
+    __syncthreads();
+    for (int t = threadIdx.x; t < (2 * C + 1) * 64; t += 256) {
+        const int r = t >> 6, l = t & 63;
+        a.slab2[((((size_t)img * a.chunks + chunk) * (a.m.F * 2) + fn) * (2 * C + 1) + r) * 64 + l] =
+            ((red[0][r][l] + red[1][r][l]) + red[2][r][l]) + red[3][r][l];
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void rnvp_bwd_units_kernel(const RnvpUnitsArgs a) {
+    // grid: x = chunk, y = flow*2 + net, z = image; wave w of the block takes a quarter of the chunk
+    __shared__ float red[4][2 * 3 + 1][64];
+    const FlowIdx x = flow_idx<C>(a.m.masks[blockIdx.y >> 1]);
+    if (C == 2) rnvp_units_body<C, 1, 1>(a, x, red);
+    else if (x.nin == 1) rnvp_units_body<C, 1, C == 2 ? 1 : 2>(a, x, red);
+    else rnvp_units_body<C, C == 2 ? 1 : 2, 1>(a, x, red);
+}
+
+// ---- reduction + optimizer --------------------------------------------------------------------------------------------------
+struct RnvpUpdArgs {
+    float* RP;            // [n_images][RP] (in/out)
+    float* opt;           // [n_images][2*RP] exp_avg | exp_avg_sq or exp_inf (mode 0)
+    float* grads_out;     // [n_images][RP] (mode 1)
+    const float* slab1;
+    const float* slab2;
+    const float* lr_hdr;  // ICNN opt-state header: lr of this step is hdr[t & 1]; null -> opt_desc.lr
+    long long hdr_stride;
+    const int32_t* status;   // per image: a non-finite loss freezes the image (like the ICNN update)
+    InrOptDesc opt_desc;
+    RnvpMap m;
+    int blocks1, S1, chunks;
+    int t;
+    double bc1;
+    float bc2_sqrt, one_minus_b1, one_minus_b2;
+    float wd_flow;        // weight decay of the flow_net group (path_connected_net.py:925); the linear has none
+    int mode;             // 0 = optimizer step, 1 = gradients only
+};
+
+__device__ __forceinline__ float opt_apply(const RnvpUpdArgs& u, float p, float g, float lr, float wd, float* m_, float* v_) {
+    if (wd != 0.f) g = __fadd_rn(g, __fmul_rn(wd, p));
+    float m = *m_, v = *v_;
+    m = __fadd_rn(m, __fmul_rn(u.one_minus_b1, __fsub_rn(g, m)));
+    const float clr = (float)((double)lr / u.bc1);
+    if (u.opt_desc.kind == INR_OPT_ADAM) {
+        v = __fadd_rn(__fmul_rn(v, u.opt_desc.beta2), __fmul_rn(__fmul_rn(u.one_minus_b2, g), g));
+        const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), u.bc2_sqrt), u.opt_desc.eps);
+        p = __fadd_rn(p, __fdiv_rn(__fmul_rn(-clr, m), denom));
+    } else {
+        v = fmaxf(__fmul_rn(v, u.opt_desc.beta2), __fadd_rn(fabsf(g), u.opt_desc.eps));
+        p = __fadd_rn(p, __fdiv_rn(__fmul_rn(-clr, m), v));
+    }
+    *m_ = m;
+    *v_ = v;
+    return p;
+}
+
+// grid: x = F flows + 1 (the linear), y = image; 256 threads
+template <int C>
+__global__ __launch_bounds__(256) void rnvp_update_kernel(const RnvpUpdArgs u) {
+    __shared__ float sm[4];
+    __shared__ float tot[4 * 3 + 2 * 3];
+    const int img = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
+    const RnvpMap& m = u.m;
+    const int F = m.F, HID = m.HID;
+    const bool frozen = u.status != nullptr && u.status[img] != INR_STATUS_OK;
+    float* __restrict__ rp = u.RP + (size_t)img * m.RP;
+    float* __restrict__ om = u.opt ? u.opt + (size_t)img * 2 * m.RP : nullptr;
+    float* __restrict__ ov = om ? om + m.RP : nullptr;
+    float* __restrict__ go = u.grads_out ? u.grads_out + (size_t)img * m.RP : nullptr;
+    const float lr = u.lr_hdr ? u.lr_hdr[(size_t)img * u.hdr_stride + (u.t & 1)] : u.opt_desc.lr;
+    // per-point-scalar gradients of this block: fixed-order sums over the point blocks
+    const int k0 = f < F ? f * 4 * C : F * 4 * C, nk = f < F ? 4 * C : 2 * C;
+    for (int k = 0; k < nk; ++k) {
+        float part = 0.f;
+        for (int b = tid; b < u.blocks1; b += 256) part += u.slab1[((size_t)img * u.blocks1 + b) * u.S1 + k0 + k];
+        const float t = block_sum256(part, sm);
+        if (tid == 0) tot[k] = t;
+    }
+    __syncthreads();
+    const int base = f < F ? 2 * C + f * m.pf : 0;
+    const int count = f < F ? m.pf : 2 * C;
+    for (int i = tid; i < count; i += 256) {
+        float g;
+        if (f == F) {
+            g = tot[i];   // a[C] | b[C]
+        } else if (i >= 2 * m.net) {
+            g = tot[2 * C + (i - 2 * m.net)];   // as[C] | at[C]
+        } else {
+            const int net = i >= m.net ? 1 : 0, r = i - net * m.net;
+            int row, j;
+            if (r < HID * C) { j = r / C; row = r - j * C; }                          // W1[j][c]
+            else if (r < HID * C + HID) { j = r - HID * C; row = C; }                 // b1[j]
+            else if (r < 2 * HID * C + HID) { const int q = r - HID * C - HID; row = C + 1 + q / HID; j = q - (q / HID) * HID; }   // W2[c][j]
+            else { row = -1; j = r - (2 * HID * C + HID); }                           // b2[c]
+            if (row < 0) {
+                g = tot[net * C + j];
+            } else {
+                g = 0.f;
+                const float* s2 = u.slab2 + ((((size_t)img * u.chunks) * (F * 2) + f * 2 + net) * (2 * C + 1) + row) * 64 + j;
+#pragma unroll 8
+                for (int c = 0; c < u.chunks; ++c) g += s2[(size_t)c * (F * 2) * (2 * C + 1) * 64];
+            }
+        }
+        if (u.mode == 1) {
+            go[base + i] = g;
+        } else if (!frozen && isfinite(g)) {
+            rp[base + i] = opt_apply(u, rp[base + i], g, lr, f < F ? u.wd_flow : 0.f, &om[base + i], &ov[base + i]);
+        }
+    }
+}
+
+// ---- ActNorm data-dependent initialisation (nf.flows.ActNorm: first forward sets s = -log(std + 1e-6), t = -mean exp(s),
+// statistics over the batch = all points of the image, unbiased std as torch.std) ---------------------------------------
+struct RnvpInitArgs {
+    float* RP;
+    float* z;     // [n_images][C][N] scratch
+    InrGridDesc grid;
+    long long N;
+    RnvpMap m;
+};
+
+__device__ __forceinline__ double block_sum_d(double v, double* sm) {   // 1024 threads, fixed order
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sm[w];
+    return t;
+}
+
+template <int C>
+__global__ __launch_bounds__(1024) void rnvp_actnorm_init_kernel(const RnvpInitArgs a) {
+    const int img = blockIdx.x, N = (int)a.N;
+    extern __shared__ __attribute__((aligned(16))) float rsm[];   // header + ONE flow
+    __shared__ double smd[16];
+    __shared__ float stat[2 * 3];
+    float* __restrict__ rp = a.RP + (size_t)img * a.m.RP;
+    float* __restrict__ zb = a.z + (size_t)img * C * N;
+    rnvp_params_to_lds<C>(rp, rsm, a.m, 0, 0);
+    for (int p = threadIdx.x; p < N; p += blockDim.x) {
+        float x[C];
+        load_coords<C>(a.grid, img, a.N, p, x);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            zb[(size_t)c * N + p] = minmax_fwd(fmaf(rsm[c], x[c], rsm[3 + c]), a.m.vmin[c], a.m.vmax[c], a.m.nmin, a.m.nmax);
+    }
+    for (int f = 0; f < a.m.F; ++f) {
+        __syncthreads();
+        rnvp_params_to_lds<C>(rp, rsm, a.m, f, f + 1);
+        const FlowIdx x = flow_idx<C>(a.m.masks[f]);
+        double s[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) s[c] = 0.0;
+        for (int p = threadIdx.x; p < N; p += blockDim.x) {
+            float z[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) z[c] = zb[(size_t)c * N + p];
+            rnvp_flow_forward<C, false>(rsm + RNVP_HDR, a.m, x, z);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                zb[(size_t)c * N + p] = z[c];
+                s[c] += (double)z[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const double t = block_sum_d(s[c], smd);
+            if (threadIdx.x == 0) stat[c] = (float)(t / (double)N);
+        }
+        __syncthreads();
+        double q[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) q[c] = 0.0;
+        for (int p = threadIdx.x; p < N; p += blockDim.x) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double d = (double)zb[(size_t)c * N + p] - (double)stat[c];
+                q[c] += d * d;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const double t = block_sum_d(q[c], smd);
+            if (threadIdx.x == 0) {
+                const float sd = (float)sqrt(t / (double)(N > 1 ? N - 1 : 1));
+                const float as = -logf(sd + 1e-6f);
+                const float at = -stat[c] * expf(as);
+                rp[2 * C + (size_t)f * a.m.pf + 2 * a.m.net + c] = as;
+                rp[2 * C + (size_t)f * a.m.pf + 2 * a.m.net + C + c] = at;
+                stat[3 + c] = as;
+            }
+        }
+        __syncthreads();
+        for (int p = threadIdx.x; p < N; p += blockDim.x) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float as = stat[3 + c];
+                zb[(size_t)c * N + p] = fmaf(zb[(size_t)c * N + p], expf(as), -stat[c] * expf(as));
+            }
+        }
+    }
+}
+
+}  // namespace

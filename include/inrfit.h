@@ -191,6 +191,57 @@ int inrfit_cdn_fit(const InrModelDesc* model, const InrFlowDesc* flow, float* ic
                    float* loss_hist, float* final_logits, int32_t* status, void* workspace, int64_t workspace_bytes,
                    void* stream);
 
+/* ---- path-connected prior with the RealNVP deformation: PathConnectedNet.forward (awesome/model/path_connected_net.py:79-85)
+ * as built by real_nvp_path_connected_net (awesome/model/net_factory.py:124-175):
+ *     ICNN( MinMax^-1( RealNVP( MinMax( a (.) x + b ) ) ) ),   C = 2 (x, y) or 3 (x, y, t)
+ * RealNVP = n_flows x [ MaskedAffineFlow(mask_f, t = MLP[C, hid, C], s = MLP[C, hid, C]), ActNorm(C) ] from the third-party
+ * package normflows==1.7.3 (net_factory.py:70-114), which is NOT in the reference checkout: the kernels restate its published
+ * definitions (awesome_amd/csrc/rnvp.h) - parity for this variant is UNPINNED.
+ * masks[f]: bit c set = channel c passes through flow f unchanged and feeds its MLPs (net_factory.py:86-99 counts 1 .. 2^C-2
+ * in binary, LSB = channel 0).  vmin/vmax/new_min/new_max: the fitted MinMax buffers (awesome/transforms/min_max.py:22-58).
+ * Flat flow parameter vector (C, hid = hidden_units, F = n_flows):
+ *     linear.weight [C] | linear.bias [C] |
+ *     for f in 0..F-1:  for net in (s, t):  net.0.weight [hid][C] | net.0.bias [hid] | net.2.weight [C][hid] | net.2.bias [C]
+ *                       then ActNorm  s [C] | t [C]
+ *   RP = 2C + F (2 (2 hid C + hid + C) + 2C).   flow_opt_state = n_images * 2 * RP floats, zero for a cold fit. */
+#define INR_RNVP_MAX_FLOWS 32
+typedef struct InrRnvpDesc {
+    int32_t channels;      /* C in {2, 3}; equals the ICNN's in_features */
+    int32_t hidden_units;  /* hid <= 64 */
+    int32_t n_flows;       /* F <= 32 */
+    int32_t output_fn;     /* 0 = none, 1 = tanh (flow_output_fn) */
+    float output_scale;    /* flow_output_scale; 0 or 1 = none */
+    float vmin[3], vmax[3];
+    float new_min, new_max;
+    uint32_t masks[INR_RNVP_MAX_FLOWS];
+} InrRnvpDesc;
+
+int64_t inrfit_rnvp_param_count(const InrRnvpDesc* rnvp);
+int64_t inrfit_pcn_workspace_bytes(const InrModelDesc* model, const InrRnvpDesc* rnvp, const InrGridDesc* grid, int n_images);
+/* ActNorm's data-dependent initialisation (first forward of nf.flows.ActNorm): flow after flow, s = -log(std + 1e-6),
+ * t = -mean * exp(s) over all points of the image; writes the ActNorm entries of flow_params in place. */
+int inrfit_rnvp_actnorm_init(const InrRnvpDesc* rnvp, float* flow_params, const InrGridDesc* grid, int n_images,
+                             void* workspace, int64_t workspace_bytes, void* stream);
+/* out_coords[n_images][C][n_points]: PathConnectedNet.get_deformation (path_connected_net.py:124-128). */
+int inrfit_rnvp_forward(const InrRnvpDesc* rnvp, const float* flow_params, const InrGridDesc* grid, int n_images,
+                        float* out_coords, void* workspace, int64_t workspace_bytes, void* stream);
+/* logits[n_images][n_points]: PathConnectedNet.forward (:79-85). */
+int inrfit_pcn_forward(const InrModelDesc* model, const InrRnvpDesc* rnvp, const float* icnn_params, const float* flow_params,
+                       const InrGridDesc* grid, int n_images, float* logits, void* workspace, int64_t workspace_bytes,
+                       void* stream);
+int inrfit_pcn_loss_grad(const InrModelDesc* model, const InrRnvpDesc* rnvp, const float* icnn_params,
+                         const float* flow_params, const InrGridDesc* grid, const float* targets, const InrLossDesc* loss,
+                         int n_images, float* loss_out, float* icnn_grads, float* flow_grads, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+/* `steps` full-batch steps of _prior_based_pretrain's inner loop (path_connected_net.py:937-962) for PathConnectedNet:
+ * Adamax (or Adam) over the groups of :922-929 - `flow_weight_decay` on every flow_net parameter, none on the ICNN and the
+ * 1x1 linear - ReduceLROnPlateau on the loss, enforce_convexity. */
+int inrfit_pcn_fit(const InrModelDesc* model, const InrRnvpDesc* rnvp, float* icnn_params, float* flow_params,
+                   float* icnn_opt_state, float* flow_opt_state, const InrGridDesc* grid, const float* targets,
+                   const InrLossDesc* loss, const InrOptDesc* opt, float flow_weight_decay, int n_images, int steps, int step0,
+                   float* loss_hist, float* final_logits, int32_t* status, void* workspace, int64_t workspace_bytes,
+                   void* stream);
+
 /* Measurement hook (bench.py, rocprof): launch ONLY the fused forward+loss+backward step kernel `iters` times
  * back-to-back on `stream` (no optimizer step), so its average duration can be bracketed with events. */
 int inrfit_step_only(const InrModelDesc* model, const float* params, const InrGridDesc* grid, const float* targets,

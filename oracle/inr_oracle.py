@@ -413,3 +413,122 @@ def fit_convex_diffeo(sd0: Dict[str, Tensor], grid: Tensor, unaries: Tensor, ste
     with torch.no_grad():
         logits = unpixelize(convex_diffeo_forward(p, rows, num_coupling), 1, h, w)
     return {k: v.detach() for k, v in p.items()}, losses, logits
+
+
+# --------------------------------------------------------------------------------------
+# a10  PathConnectedNet with the normflows RealNVP deformation.  PARITY UNPINNED:
+# the flow's arithmetic is normflows==1.7.3 (poetry.lock pin), which is not part of the
+# reference checkout and not installed here.  The functions below restate its published
+# definitions (nf.nets.MLP, nf.flows.MaskedAffineFlow, nf.flows.ActNorm / AffineConstFlow,
+# nf.NormalizingFlow.forward) and are anchored on the reference's call sites
+# (awesome/model/net_factory.py:70-114,124-175; model/norm_net.py:17-27;
+# transforms/min_max.py:8-58; model/path_connected_net.py:65-85,922-962).
+# --------------------------------------------------------------------------------------
+
+
+def rnvp_masks(channels: int, n_flows: int) -> Tensor:
+    """init_realnvp's coupling masks (net_factory.py:82-99): 1 .. 2^C-2 in binary (LSB = channel 0), repeated / cropped."""
+    vals = torch.arange(1, 2 ** channels - 1)
+    bits = 2 ** torch.arange(channels)
+    base = (vals.unsqueeze(-1).bitwise_and(bits) != 0).to(torch.uint8)
+    rep, crop = divmod(n_flows, base.shape[0])
+    masks = torch.zeros((n_flows, channels), dtype=torch.uint8)
+    if rep > 0:
+        masks[:rep * base.shape[0]] = base.repeat((rep, 1))
+    masks[rep * base.shape[0]:] = base[:crop]
+    return masks
+
+
+def minmax(v: Tensor, v_min, v_max, new_min, new_max) -> Tensor:
+    """awesome/transforms/min_max.py:8-19."""
+    return (v - v_min) / (v_max - v_min) * (new_max - new_min) + new_min
+
+
+def rnvp_mlp(sd: Dict[str, Tensor], prefix: str, x: Tensor, output_fn: Optional[str], output_scale: Optional[float]) -> Tensor:
+    """nf.nets.MLP([C, hid, C], leaky=0.0, init_zeros=True, output_fn, output_scale): Linear, LeakyReLU(0.0), Linear[, Tanh[, x scale]]."""
+    h = F.leaky_relu(F.linear(x, sd[prefix + "net.0.weight"], sd[prefix + "net.0.bias"]), 0.0)
+    o = F.linear(h, sd[prefix + "net.2.weight"], sd[prefix + "net.2.bias"])
+    if output_fn == "tanh":
+        o = torch.tanh(o)
+        if output_scale is not None:
+            o = o * output_scale
+    return o
+
+
+def rnvp_flow_forward(sd: Dict[str, Tensor], z: Tensor, masks: Tensor, output_fn: Optional[str] = "tanh",
+                      output_scale: Optional[float] = None, prefix: str = "flow_net.net.network.",
+                      actnorm_init: bool = False) -> Tensor:
+    """nf.NormalizingFlow.forward over [MaskedAffineFlow(b, t, s), ActNorm(C)] x F on rows z (N, C).
+    MaskedAffineFlow.forward: z_masked = b z; z' = z_masked + (1 - b)(z exp(s(z_masked)) + t(z_masked)).
+    ActNorm (AffineConstFlow): z'' = z' exp(s) + t; its first forward sets s = -log(std(z', 0) + 1e-6), t = -mean exp(s)
+    (actnorm_init=True writes them into sd, like the data-dependent init does)."""
+    for f in range(masks.shape[0]):
+        b = masks[f].to(z.dtype).view(1, -1)
+        zm = b * z
+        s = rnvp_mlp(sd, f"{prefix}flows.{2 * f}.s.", zm, output_fn, output_scale)
+        t = rnvp_mlp(sd, f"{prefix}flows.{2 * f}.t.", zm, output_fn, output_scale)
+        z = zm + (1 - b) * (z * torch.exp(s) + t)
+        ks, kt = f"{prefix}flows.{2 * f + 1}.s", f"{prefix}flows.{2 * f + 1}.t"
+        if actnorm_init:
+            with torch.no_grad():
+                s_init = -torch.log(z.std(dim=0, keepdim=True) + 1e-6)
+                sd[ks] = s_init.detach().clone()
+                sd[kt] = (-z.mean(dim=0, keepdim=True) * torch.exp(s_init)).detach().clone()
+        z = z * torch.exp(sd[ks]) + sd[kt]
+    return z
+
+
+def pcn_deformation(sd: Dict[str, Tensor], x: Tensor, masks: Tensor, vmin: Tensor, vmax: Tensor, new_min: float = -1.0,
+                    new_max: float = 1.0, output_fn: Optional[str] = "tanh", output_scale: Optional[float] = None,
+                    actnorm_init: bool = False) -> Tensor:
+    """PathConnectedNet.get_deformation (path_connected_net.py:124-128) on rows x (N, C): the 1x1 depthwise conv
+    (:65, per-channel a x + b), then NormNet.forward (norm_net.py:17-27): MinMax.transform, flow, MinMax.inverse_transform."""
+    v = x * sd["linear.weight"].view(1, -1) + sd["linear.bias"].view(1, -1)
+    z = minmax(v, vmin.view(1, -1), vmax.view(1, -1), new_min, new_max)
+    z = rnvp_flow_forward(sd, z, masks, output_fn, output_scale, actnorm_init=actnorm_init)
+    return minmax(z, new_min, new_max, vmin.view(1, -1), vmax.view(1, -1))
+
+
+def pcn_forward(sd: Dict[str, Tensor], x: Tensor, masks: Tensor, vmin: Tensor, vmax: Tensor, **kw) -> Tensor:
+    """PathConnectedNet.forward (path_connected_net.py:79-85) on rows: convex_net(flow_net(linear(x)))."""
+    xd = pcn_deformation(sd, x, masks, vmin, vmax, **kw)
+    return icnn_forward({k[len("convex_net."):]: v for k, v in sd.items() if k.startswith("convex_net.")}, xd)
+
+
+def fit_pcn(sd0: Dict[str, Tensor], rows: Tensor, unaries_rows: Tensor, steps: int, masks: Tensor, vmin: Tensor, vmax: Tensor,
+            lr: float = 1e-3, optimizer: str = "adamax", flow_weight_decay: float = 1e-5, loss_kind: str = "se",
+            weight_mode: str = "none", plateau: Optional[dict] = None, **kw) -> Tuple[Dict[str, Tensor], List[float], Tensor]:
+    """_prior_based_pretrain's inner loop for PathConnectedNet (path_connected_net.py:922-962): Adamax over the groups
+    {flow_net: weight_decay=flow_weight_decay, convex_net, linear}, ReduceLROnPlateau(patience 200, factor .5) if `plateau`
+    is given, enforce_convexity after every step.  rows (N, C), unaries_rows (N, 1)."""
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in sd0.items()}
+    st = AdamState(p)
+    sched = PlateauState(lr, **plateau) if plateau is not None else None
+    cur_lr = lr
+    losses: List[float] = []
+    flow_keys = [k for k in p if k.startswith("flow_net.")]
+    other_keys = [k for k in p if not k.startswith("flow_net.")]
+    step_fn = adamax_step if optimizer == "adamax" else adam_step
+    for _ in range(steps):
+        for v in p.values():
+            v.grad = None
+        out = torch.sigmoid(pcn_forward(p, rows, masks, vmin, vmax, **kw))
+        loss = weighted_loss(out.reshape(1, 1, -1, 1), unaries_rows.reshape(1, 1, -1, 1), loss_kind, weight_mode)
+        loss.backward()
+        st.step += 1
+        for keys, wd in ((flow_keys, flow_weight_decay), (other_keys, 0.0)):
+            sub, g = {k: p[k] for k in keys}, {k: p[k].grad for k in keys}
+            sst = AdamState.__new__(AdamState)
+            sst.step, sst.m, sst.v = st.step - 1, st.m, st.v
+            step_fn(sub, g, sst, cur_lr, weight_decay=wd)
+        with torch.no_grad():
+            for k in p:
+                if k.startswith("convex_net.") and k.endswith("ln.weight") and not k.startswith("convex_net.input"):
+                    p[k].copy_(F.relu(p[k]))
+        lv = float(loss.item())
+        losses.append(lv)
+        if sched is not None:
+            cur_lr = sched.step(lv)
+    with torch.no_grad():
+        logits = pcn_forward(p, rows, masks, vmin, vmax, **kw)
+    return {k: v.detach() for k, v in p.items()}, losses, logits

@@ -1,0 +1,201 @@
+"""GPU parity of the RealNVP / PathConnectedNet path (awesome_amd/csrc/rnvp.h through the C ABI) against the oracle's
+restatement of normflows' MaskedAffineFlow / ActNorm / MLP (oracle/inr_oracle.py, section a10).
+
+PARITY UNPINNED for this variant: normflows==1.7.3 is not part of the reference checkout, so the oracle here is pinned
+only on the reference's call sites (net_factory.py:70-114), not on outputs of the real package."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import inr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import awesome_amd._lib as L
+    L.load()
+    return torch.device("cuda:0")
+
+
+def _case(C, hid, F, layers, seed=0, output_fn="tanh", output_scale=None, h=130):
+    """Random PathConnectedNet state (every parameter non-trivial, incl. the zero-initialised last layers)."""
+    import awesome_amd as A
+    from awesome_amd import rnvp as R
+    torch.manual_seed(seed)
+    vmin = tuple(float(v) for v in (-0.1, 0.0, 0.05)[:C])
+    vmax = tuple(float(v) for v in (1.2, 1.0, 0.9)[:C])
+    rspec = R.RnvpSpec(C, hid, F, output_fn, output_scale, vmin, vmax)
+    ispec = A.IcnnSpec(h, C, layers)
+    sd = {}
+    for k, shp in rspec.keys_shapes():
+        if k == "linear.weight":
+            sd[k] = 1.0 + 0.2 * torch.randn(shp)
+        elif k == "linear.bias":
+            sd[k] = 0.1 * torch.randn(shp)
+        elif k.endswith("net.0.weight"):
+            sd[k] = torch.randn(shp) * 0.8
+        elif k.endswith("net.0.bias"):
+            sd[k] = torch.randn(shp) * 0.5
+        elif k.endswith("net.2.weight"):
+            sd[k] = torch.randn(shp) * 0.15
+        elif k.endswith("net.2.bias"):
+            sd[k] = torch.randn(shp) * 0.1
+        else:   # ActNorm s, t
+            sd[k] = torch.randn(shp) * 0.1
+    from awesome_amd.model import ConvexNextNet
+    m = ConvexNextNet(n_hidden=h, n_hidden_layers=layers, in_features=C)
+    for k, v in m.state_dict().items():
+        sd["convex_net." + k] = v.detach().clone()
+    return ispec, rspec, sd
+
+
+def _split(ispec, rspec, sd, dev):
+    import awesome_amd as A
+    from awesome_amd import rnvp as R
+    ip = A.pack_state_dict(ispec, {k[len("convex_net."):]: v for k, v in sd.items() if k.startswith("convex_net.")}, dev)
+    fp = R.pack_rnvp_state_dict(rspec, sd, dev)
+    return ip[None].contiguous(), fp[None].contiguous()
+
+
+def _merge(ispec, rspec, gi, gf):
+    import awesome_amd as A
+    from awesome_amd import rnvp as R
+    out = {"convex_net." + k: v for k, v in A.unpack_params(ispec, gi).items()}
+    out.update(R.unpack_rnvp_params(rspec, gf))
+    return out
+
+
+def _rows(C, H, W, t=0.37):
+    g = O.positional_grid(W, H) if C == 2 else O.positional_grid(W, H, t, 1.0)
+    return g, O.pixelize(g[None])
+
+
+def test_masks_match_reference_factory():
+    from awesome_amd import rnvp as R
+    for C, F in ((2, 12), (3, 18), (3, 7), (2, 5)):
+        ref = O.rnvp_masks(C, F)
+        got = R.rnvp_masks(C, F)
+        assert [int(sum(int(ref[f, c]) << c for c in range(C))) for f in range(F)] == got
+
+
+@pytest.mark.parametrize("C,hid,F,layers,fn,scale", [(2, 32, 12, 2, "tanh", None), (3, 32, 18, 2, "tanh", None),
+                                                      (3, 20, 5, 1, None, None), (2, 64, 3, 1, "tanh", 0.5)])
+def test_forward_and_gradients(dev, C, hid, F, layers, fn, scale):
+    from awesome_amd import rnvp as R
+    import awesome_amd as A
+    ispec, rspec, sd = _case(C, hid, F, layers, seed=C * 7 + F, output_fn=fn, output_scale=scale)
+    assert rspec.n_params == sum(int(np.prod(s)) for _, s in rspec.keys_shapes())
+    H, W = 11, 19   # N = 209: ragged
+    grid_t, rows = _rows(C, H, W)
+    un = torch.rand(H * W, 1)
+    masks = O.rnvp_masks(C, F)
+    vmin, vmax = torch.tensor(rspec.vmin), torch.tensor(rspec.vmax)
+    kw = dict(output_fn=fn, output_scale=scale)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xd_ref = O.pcn_deformation(sdo, rows, masks, vmin, vmax, **kw)
+    yo = O.pcn_forward(sdo, rows, masks, vmin, vmax, **kw)
+    lo = O.weighted_loss(torch.sigmoid(yo).reshape(1, 1, -1, 1), un.reshape(1, 1, -1, 1), "se", "sssdms")
+    lo.backward()
+    ip, fp = _split(ispec, rspec, sd, dev)
+    grid = A.Grid.from_image_grid(grid_t.to(dev))
+    xd = R.rnvp_forward(rspec, fp, grid)
+    np.testing.assert_allclose(xd[0].cpu().numpy(), xd_ref.detach().t().numpy(), rtol=3e-5, atol=5e-6)
+    y = R.pcn_forward(ispec, rspec, ip, fp, grid)
+    np.testing.assert_allclose(y[0].cpu().numpy(), yo.detach().reshape(-1).numpy(), rtol=1e-4, atol=5e-5)
+    loss, gi, gf = R.pcn_loss_grad(ispec, rspec, ip, fp, grid, un.reshape(1, -1).to(dev), loss="se", weight_mode="sssdms")
+    assert float(loss[0]) == pytest.approx(float(lo.detach()), rel=3e-5)
+    got = _merge(ispec, rspec, gi[0].cpu(), gf[0].cpu())
+    for k in sdo:
+        ref = sdo[k].grad.numpy()
+        scale_ = float(np.abs(ref).max())
+        np.testing.assert_allclose(got[k].numpy(), ref, rtol=1e-3, atol=3e-5 * scale_ + 1e-7, err_msg=k)
+
+
+def test_separable_grid_with_time_channel(dev):
+    """C = 3 through the separable grid (xs, ys, ts per image), two images with different t and parameters."""
+    from awesome_amd import rnvp as R
+    import awesome_amd as A
+    C, hid, F = 3, 32, 6
+    H, W = 8, 16
+    cases = [_case(C, hid, F, 1, seed=s) for s in (1, 2)]
+    ispec, rspec = cases[0][0], cases[0][1]
+    ts = torch.tensor([0.25, 0.8])
+    ips, fps = zip(*[_split(ispec, rspec, c[2], dev) for c in cases])
+    ip, fp = torch.cat(ips), torch.cat(fps)
+    grid = A.Grid.linspace(W, H, dev, ts.to(dev))
+    y = R.pcn_forward(ispec, rspec, ip, fp, grid)
+    masks = O.rnvp_masks(C, F)
+    for i, c in enumerate(cases):
+        _, rows = _rows(C, H, W, float(ts[i]))
+        yo = O.pcn_forward(c[2], rows, masks, torch.tensor(rspec.vmin), torch.tensor(rspec.vmax))
+        np.testing.assert_allclose(y[i].cpu().numpy(), yo.reshape(-1).numpy(), rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("C,F", [(2, 12), (3, 6)])
+def test_actnorm_data_dependent_init(dev, C, F):
+    from awesome_amd import rnvp as R
+    import awesome_amd as A
+    ispec, rspec, sd = _case(C, 32, F, 1, seed=5)
+    H, W = 24, 20
+    grid_t, rows = _rows(C, H, W)
+    masks = O.rnvp_masks(C, F)
+    sdo = {k: v.clone() for k, v in sd.items()}
+    O.pcn_deformation(sdo, rows, masks, torch.tensor(rspec.vmin), torch.tensor(rspec.vmax), actnorm_init=True)
+    _, fp = _split(ispec, rspec, sd, dev)
+    R.actnorm_init(rspec, fp, A.Grid.from_image_grid(grid_t.to(dev)))
+    got = R.unpack_rnvp_params(rspec, fp[0].cpu())
+    for f in range(F):
+        for nm in ("s", "t"):
+            k = f"flow_net.net.network.flows.{2 * f + 1}.{nm}"
+            np.testing.assert_allclose(got[k].numpy(), sdo[k].numpy(), rtol=2e-4, atol=2e-5, err_msg=k)
+    # everything else untouched
+    for k in got:
+        if ".flows." in k and k.rsplit(".", 1)[1] in ("s", "t") and int(k.split(".flows.")[1].split(".")[0]) % 2 == 1:
+            continue
+        np.testing.assert_array_equal(got[k].numpy(), sd[k].numpy(), err_msg=k)
+
+
+@pytest.mark.parametrize("C,optimizer", [(2, "adamax"), (3, "adamax"), (2, "adam")])
+def test_fit_trajectory(dev, C, optimizer):
+    """15 steps of the fused PathConnectedNet fit (param groups with flow weight decay, plateau, clamp) vs the oracle loop."""
+    from awesome_amd import rnvp as R
+    import awesome_amd as A
+    F, hid, layers = (12, 32, 2) if C == 2 else (6, 32, 1)
+    ispec, rspec, sd = _case(C, hid, F, layers, seed=11 + C)
+    H, W = 16, 16
+    grid_t, rows = _rows(C, H, W, 0.5)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    un = (((yy - 8) ** 2 + (xx - 7) ** 2) > 20).float().reshape(-1, 1)
+    steps = 15
+    masks = O.rnvp_masks(C, F)
+    pf, losses, logits = O.fit_pcn(sd, rows, un, steps, masks, torch.tensor(rspec.vmin), torch.tensor(rspec.vmax), lr=2e-3,
+                                   optimizer=optimizer, flow_weight_decay=1e-2, plateau=dict(patience=3, factor=0.5))
+    ip, fp = _split(ispec, rspec, sd, dev)
+    res = R.pcn_fit(ispec, rspec, ip, fp, A.Grid.from_image_grid(grid_t.to(dev)), un.reshape(1, -1).to(dev), steps, lr=2e-3,
+                    optimizer=optimizer, flow_weight_decay=1e-2, plateau=dict(patience=3, factor=0.5))
+    assert int(res.status[0]) == 0
+    np.testing.assert_allclose(res.loss_hist[0].cpu().numpy(), np.asarray(losses, np.float32), rtol=5e-4)
+    got = _merge(ispec, rspec, res.icnn_params[0].cpu(), res.flow_params[0].cpu())
+    for k in pf:
+        np.testing.assert_allclose(got[k].numpy(), pf[k].numpy(), rtol=5e-3, atol=3e-4, err_msg=k)
+    np.testing.assert_allclose(res.logits[0].cpu().numpy(), logits.reshape(-1).numpy(), rtol=5e-3, atol=2e-3)
+
+
+def test_fresh_flow_is_identity_after_actnorm_init(dev):
+    """init_zeros=True: every coupling starts as the identity, so after ActNorm's init the deformation is a per-channel
+    affine map of the grid (net_factory.py:104-105)."""
+    from awesome_amd import rnvp as R
+    import awesome_amd as A
+    torch.manual_seed(0)
+    rspec = R.RnvpSpec(2, 32, 12)
+    fp = R.init_rnvp_params(rspec)[None].to(dev)
+    grid = A.Grid.linspace(32, 32, dev)
+    R.actnorm_init(rspec, fp, grid)
+    xd = R.rnvp_forward(rspec, fp, grid)[0].cpu()
+    g = O.positional_grid(32, 32).reshape(2, -1)
+    for c in range(2):
+        A_ = torch.stack([g[c], torch.ones_like(g[c])], 1)
+        sol = torch.linalg.lstsq(A_, xd[c][:, None]).solution
+        assert float((A_ @ sol - xd[c][:, None]).abs().max()) < 1e-4
