@@ -895,8 +895,8 @@ namespace {
 
 struct PcnWs {
     Workspace icnn;
-    float *xd, *dxd, *zs, *ps, *slab1, *slab2;
-    int blocks1, chunks, S1;
+    float *xd, *dxd, *zs, *ps, *slab1, *slab2, *RE;
+    int blocks1, chunks, S1, Q;   // Q = points per lane of the point kernels
     RnvpMap rm;
     long long bytes;
     InrGridDesc dgrid;
@@ -943,9 +943,11 @@ PcnWs carve_pcn(const KernelEntry* e, const InrRnvpDesc* r, const InrGridDesc* g
     const long long N = grid->n_points;
     w.rm = make_rnvp_map(r);
     const int C = w.rm.C, F = w.rm.F;
-    w.blocks1 = (int)((N + 255) / 256);
-    w.chunks = 16;
-    while (w.chunks > 1 && N / w.chunks < 256) w.chunks /= 2;
+    w.Q = 1;   // two points per lane (half the record reads per point) measured slower even at 262144 points: 73 vs 70 us
+               // forward, 155 vs 137 us backward - the loops are VALU-bound, not LDS-bound
+    w.blocks1 = (int)((N + 256 * w.Q - 1) / (256 * w.Q));
+    w.chunks = 32;   // x F flows x 4 waves: enough waves for the 1024 SIMDs
+    while (w.chunks > 1 && N / w.chunks < 1024) w.chunks /= 2;
     w.S1 = F * 4 * C + 2 * C;
     char* b = (char*)base;
     long long off = 0;
@@ -956,6 +958,7 @@ PcnWs carve_pcn(const KernelEntry* e, const InrRnvpDesc* r, const InrGridDesc* g
     w.ps = take((long long)n_images * F * w.rm.A * N * 4);
     w.slab1 = take((long long)n_images * w.blocks1 * w.S1 * 4);
     w.slab2 = take((long long)n_images * w.chunks * F * 2 * (2 * C + 1) * 64 * 4);
+    w.RE = take((long long)n_images * w.rm.LDSF * 4);
     w.dgrid = *grid;
     w.dgrid.mode = INR_GRID_EXPLICIT;
     w.dgrid.coords = w.xd;
@@ -996,9 +999,21 @@ int check_pcn(const InrModelDesc* model, const InrRnvpDesc* r, const InrGridDesc
     return INR_OK;
 }
 
-void launch_rnvp_fwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, int n_images, float* out, bool keep, hipStream_t s) {
-    RnvpFwdArgs a{};
+// parameters -> packed image; once per parameter set, in front of the forward
+void launch_rnvp_pack(const PcnWs& w, const float* rp, int n_images, hipStream_t s) {
+    RnvpPackArgs a{};
     a.RP = rp;
+    a.RE = w.RE;
+    a.m = w.rm;
+    const dim3 g(w.rm.F, n_images);
+    if (w.rm.C == 2) hipLaunchKernelGGL(rnvp_pack_kernel<2>, g, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(rnvp_pack_kernel<3>, g, dim3(256), 0, s, a);
+}
+
+void launch_rnvp_fwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, int n_images, float* out, bool keep, hipStream_t s) {
+    launch_rnvp_pack(w, rp, n_images, s);
+    RnvpFwdArgs a{};
+    a.RE = w.RE;
     a.xd = out;
     a.zs = keep ? w.zs : nullptr;
     a.grid = *grid;
@@ -1006,13 +1021,18 @@ void launch_rnvp_fwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, i
     a.m = w.rm;
     const dim3 g(w.blocks1, n_images);
     const size_t lds = (size_t)w.rm.LDSF * sizeof(float);
-    if (w.rm.C == 2) hipLaunchKernelGGL(rnvp_fwd_kernel<2>, g, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(rnvp_fwd_kernel<3>, g, dim3(256), lds, s, a);
+    if (w.rm.C == 2) {
+        if (w.Q == 1) hipLaunchKernelGGL((rnvp_fwd_kernel<2, 1>), g, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((rnvp_fwd_kernel<2, 2>), g, dim3(256), lds, s, a);
+    } else {
+        if (w.Q == 1) hipLaunchKernelGGL((rnvp_fwd_kernel<3, 1>), g, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((rnvp_fwd_kernel<3, 2>), g, dim3(256), lds, s, a);
+    }
 }
 
 void launch_rnvp_bwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, int n_images, hipStream_t s) {
     RnvpBwdArgs a{};
-    a.RP = rp;
+    a.RE = w.RE;   // packed by the forward of this step
     a.dxd = w.dxd;
     a.zs = w.zs;
     a.ps = w.ps;
@@ -1023,8 +1043,13 @@ void launch_rnvp_bwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, i
     a.S1 = w.S1;
     const dim3 g1(w.blocks1, n_images);
     const size_t lds = (size_t)(w.rm.LDSF + 4 * w.S1) * sizeof(float);
-    if (w.rm.C == 2) hipLaunchKernelGGL(rnvp_bwd_points_kernel<2>, g1, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(rnvp_bwd_points_kernel<3>, g1, dim3(256), lds, s, a);
+    if (w.rm.C == 2) {
+        if (w.Q == 1) hipLaunchKernelGGL((rnvp_bwd_points_kernel<2, 1>), g1, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((rnvp_bwd_points_kernel<2, 2>), g1, dim3(256), lds, s, a);
+    } else {
+        if (w.Q == 1) hipLaunchKernelGGL((rnvp_bwd_points_kernel<3, 1>), g1, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((rnvp_bwd_points_kernel<3, 2>), g1, dim3(256), lds, s, a);
+    }
     RnvpUnitsArgs ua{};
     ua.RP = rp;
     ua.ps = w.ps;
@@ -1032,9 +1057,15 @@ void launch_rnvp_bwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, i
     ua.N = grid->n_points;
     ua.m = w.rm;
     ua.chunks = w.chunks;
-    const dim3 g2(w.chunks, 2 * w.rm.F, n_images);
-    if (w.rm.C == 2) hipLaunchKernelGGL(rnvp_bwd_units_kernel<2>, g2, dim3(256), 0, s, ua);
-    else hipLaunchKernelGGL(rnvp_bwd_units_kernel<3>, g2, dim3(256), 0, s, ua);
+    const dim3 g2(w.chunks, w.rm.F, n_images);
+    const size_t lds2 = (size_t)(RNVP_HDR + w.rm.fl) * sizeof(float);
+    if (w.rm.C == 2) {
+        if (w.rm.HID <= 32) hipLaunchKernelGGL((rnvp_bwd_units_kernel<2, 8>), g2, dim3(256), lds2, s, ua);
+        else hipLaunchKernelGGL((rnvp_bwd_units_kernel<2, 16>), g2, dim3(256), lds2, s, ua);
+    } else {
+        if (w.rm.HID <= 32) hipLaunchKernelGGL((rnvp_bwd_units_kernel<3, 8>), g2, dim3(256), lds2, s, ua);
+        else hipLaunchKernelGGL((rnvp_bwd_units_kernel<3, 16>), g2, dim3(256), lds2, s, ua);
+    }
 }
 
 void launch_rnvp_update(const PcnWs& w, int n_images, int mode, float* rp, float* opt, float* grads_out, const InrOptDesc* od,

@@ -75,134 +75,191 @@ __device__ __forceinline__ float sel(const float (&z)[C], int idx) {   // unifor
     return v;
 }
 
+// tanh / exp of the coupling outputs on the hardware exp2 / rcp (v_exp_f32, v_rcp_f32: 1 ulp each): tanh x = 1 - 2/(1 + e^2x),
+// absolute error <= 2e-7 - the libm calls were a third of the point kernels' instructions
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
+
 __device__ __forceinline__ float minmax_fwd(float v, float lo, float hi, float nlo, float nhi) {   // transforms/min_max.py:8-19
     return (v - lo) / (hi - lo) * (nhi - nlo) + nlo;
 }
 
-// flat parameters of one image -> LDS image (records by flow; only the active rows/columns of every flow's MLPs)
+// flat parameters of one image -> the image the kernels read from LDS (records by flow; only the active rows/columns of
+// every flow's MLPs): header, then one block of `fl` floats per flow
+template <int C>
+__device__ __forceinline__ void rnvp_header_image(const float* __restrict__ rp, float* dst) {
+    for (int i = threadIdx.x; i < RNVP_HDR; i += blockDim.x) dst[i] = i < 3 ? (i < C ? rp[i] : 0.f) : (i < 6 ? (i - 3 < C ? rp[C + i - 3] : 0.f) : 0.f);
+}
+
+template <int C>
+__device__ __forceinline__ void rnvp_flow_image(const float* __restrict__ rp, float* dst, const RnvpMap& m, int f) {
+    const FlowIdx x = flow_idx<C>(m.masks[f]);
+    const float* __restrict__ pf = rp + 2 * C + (size_t)f * m.pf;
+    for (int i = threadIdx.x; i < m.HID * RNVP_REC; i += blockDim.x) {
+        const int j = i >> 3, slot = i & 7, q = slot >> 1;
+        const float* __restrict__ pn = pf + (slot & 1) * m.net;
+        float v = 0.f;
+        if (q < x.nin) v = pn[j * C + x.in(q)];
+        else if (q == x.nin) v = pn[m.HID * C + j];
+        else if (q < x.nin + 1 + x.nout) v = pn[m.HID * C + m.HID + x.out(q - x.nin - 1) * m.HID + j];
+        dst[i] = v;
+    }
+    for (int i = threadIdx.x; i < RNVP_TAIL; i += blockDim.x) {
+        float v = 0.f;
+        if (i < 4) {
+            const int k = i >> 1;
+            if (k < x.nout) v = pf[(i & 1) * m.net + 2 * m.HID * C + m.HID + x.out(k)];
+        } else if (i < 7) {
+            if (i - 4 < C) v = expf(pf[2 * m.net + i - 4]);
+        } else if (i < 10) {
+            if (i - 7 < C) v = pf[2 * m.net + C + i - 7];
+        }
+        dst[m.HID * RNVP_REC + i] = v;
+    }
+}
+
+// header + flows [f0, f1) into LDS
 template <int C>
 __device__ __forceinline__ void rnvp_params_to_lds(const float* __restrict__ rp, float* lds, const RnvpMap& m, int f0, int f1) {
-    for (int i = threadIdx.x; i < RNVP_HDR; i += blockDim.x) lds[i] = i < 3 ? (i < C ? rp[i] : 0.f) : (i < 6 ? (i - 3 < C ? rp[C + i - 3] : 0.f) : 0.f);
-    for (int f = f0; f < f1; ++f) {
-        const FlowIdx x = flow_idx<C>(m.masks[f]);
-        const float* __restrict__ pf = rp + 2 * C + (size_t)f * m.pf;
-        float* dst = lds + RNVP_HDR + (f - f0) * m.fl;
-        for (int i = threadIdx.x; i < m.HID * RNVP_REC; i += blockDim.x) {
-            const int j = i >> 3, slot = i & 7, q = slot >> 1;
-            const float* __restrict__ pn = pf + (slot & 1) * m.net;
-            float v = 0.f;
-            if (q < x.nin) v = pn[j * C + x.in(q)];
-            else if (q == x.nin) v = pn[m.HID * C + j];
-            else if (q < x.nin + 1 + x.nout) v = pn[m.HID * C + m.HID + x.out(q - x.nin - 1) * m.HID + j];
-            dst[i] = v;
-        }
-        for (int i = threadIdx.x; i < RNVP_TAIL; i += blockDim.x) {
-            float v = 0.f;
-            if (i < 4) {
-                const int k = i >> 1;
-                if (k < x.nout) v = pf[(i & 1) * m.net + 2 * m.HID * C + m.HID + x.out(k)];
-            } else if (i < 7) {
-                if (i - 4 < C) v = expf(pf[2 * m.net + i - 4]);
-            } else if (i < 10) {
-                if (i - 7 < C) v = pf[2 * m.net + C + i - 7];
-            }
-            dst[m.HID * RNVP_REC + i] = v;
-        }
-    }
+    rnvp_header_image<C>(rp, lds);
+    for (int f = f0; f < f1; ++f) rnvp_flow_image<C>(rp, lds + RNVP_HDR + (f - f0) * m.fl, m, f);
     __syncthreads();
 }
 
-// pre-activation outputs o[k] = (o_s, o_t) of the two MLPs of one flow for the NOUT active output channels;
-// DU: also J[k][m] = d o[k] / d zin[m] (packed for both nets).
-template <int NIN, int NOUT, bool DU>
-__device__ __forceinline__ void rnvp_nets(const float* rec, int HID, const float (&zin)[NIN], f32x2 (&o)[NOUT], f32x2 (&J)[NOUT][NIN]) {
+// the whole image into HBM once per optimizer step (grid: x = flow, y = image): the point kernels then start with a straight
+// float4 copy instead of a thousand blocks each gathering and transposing the parameters
+struct RnvpPackArgs {
+    const float* RP;
+    float* RE;   // [n_images][LDSF]
+    RnvpMap m;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void rnvp_pack_kernel(const RnvpPackArgs a) {
+    const int img = blockIdx.y, f = blockIdx.x;
+    const float* __restrict__ rp = a.RP + (size_t)img * a.m.RP;
+    float* dst = a.RE + (size_t)img * a.m.LDSF;
+    if (f == 0) rnvp_header_image<C>(rp, dst);
+    rnvp_flow_image<C>(rp, dst + RNVP_HDR + f * a.m.fl, a.m, f);
+}
+
+// pre-activation outputs o[q][k] = (o_s, o_t) of the two MLPs of one flow for the NOUT active output channels of Q points
+// per lane (a record read from LDS serves all Q); DU: also J[q][k][m] = d o[k] / d zin[m] (packed for both nets).
+template <int NIN, int NOUT, bool DU, int Q>
+__device__ __forceinline__ void rnvp_nets(const float* rec, int HID, const float (&zin)[Q][NIN], f32x2 (&o)[Q][NOUT],
+                                          f32x2 (&J)[Q][NOUT][NIN]) {
     const f32x4 tl = *(const f32x4*)(rec + HID * RNVP_REC);
-    o[0] = f32x2{tl[0], tl[1]};
-    if (NOUT > 1) o[NOUT - 1] = f32x2{tl[2], tl[3]};
 #pragma unroll
-    for (int k = 0; k < NOUT; ++k)
+    for (int q = 0; q < Q; ++q) {
+        o[q][0] = f32x2{tl[0], tl[1]};
+        if (NOUT > 1) o[q][NOUT - 1] = f32x2{tl[2], tl[3]};
 #pragma unroll
-        for (int mm = 0; mm < NIN; ++mm) J[k][mm] = f32x2{0.f, 0.f};
+        for (int k = 0; k < NOUT; ++k)
+#pragma unroll
+            for (int mm = 0; mm < NIN; ++mm) J[q][k][mm] = f32x2{0.f, 0.f};
+    }
 #pragma unroll 4
     for (int j = 0; j < HID; ++j) {
         const f32x4 r0 = *(const f32x4*)(rec + RNVP_REC * j), r1 = *(const f32x4*)(rec + RNVP_REC * j + 4);
         const float v[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
-        f32x2 pre = f32x2{v[2 * NIN], v[2 * NIN + 1]};
 #pragma unroll
-        for (int mm = 0; mm < NIN; ++mm) pre += f32x2{v[2 * mm], v[2 * mm + 1]} * f32x2{zin[mm], zin[mm]};
-        if (DU) {
-            const f32x2 st = step01(pre);
-            const f32x2 h = pre * st;
-            f32x2 t[NIN];
+        for (int q = 0; q < Q; ++q) {
+            f32x2 pre = f32x2{v[2 * NIN], v[2 * NIN + 1]};
 #pragma unroll
-            for (int mm = 0; mm < NIN; ++mm) t[mm] = st * f32x2{v[2 * mm], v[2 * mm + 1]};
+            for (int mm = 0; mm < NIN; ++mm) pre += f32x2{v[2 * mm], v[2 * mm + 1]} * f32x2{zin[q][mm], zin[q][mm]};
+            if (DU) {
+                const f32x2 st = step01(pre);
+                const f32x2 h = pre * st;
+                f32x2 t[NIN];
 #pragma unroll
-            for (int k = 0; k < NOUT; ++k) {
-                const f32x2 w2 = f32x2{v[2 * (NIN + 1 + k)], v[2 * (NIN + 1 + k) + 1]};
-                o[k] += w2 * h;
+                for (int mm = 0; mm < NIN; ++mm) t[mm] = st * f32x2{v[2 * mm], v[2 * mm + 1]};
 #pragma unroll
-                for (int mm = 0; mm < NIN; ++mm) J[k][mm] += w2 * t[mm];
+                for (int k = 0; k < NOUT; ++k) {
+                    const f32x2 w2 = f32x2{v[2 * (NIN + 1 + k)], v[2 * (NIN + 1 + k) + 1]};
+                    o[q][k] += w2 * h;
+#pragma unroll
+                    for (int mm = 0; mm < NIN; ++mm) J[q][k][mm] += w2 * t[mm];
+                }
+            } else {
+                const f32x2 h = f32x2{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f)};
+#pragma unroll
+                for (int k = 0; k < NOUT; ++k) o[q][k] += f32x2{v[2 * (NIN + 1 + k)], v[2 * (NIN + 1 + k) + 1]} * h;
             }
-        } else {
-            const f32x2 h = f32x2{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f)};
-#pragma unroll
-            for (int k = 0; k < NOUT; ++k) o[k] += f32x2{v[2 * (NIN + 1 + k)], v[2 * (NIN + 1 + k) + 1]} * h;
         }
     }
 }
 
 // dispatch on the flow's mask shape; results in fixed [2]-arrays (unused slots untouched)
-template <int C, bool DU>
-__device__ __forceinline__ void rnvp_nets_any(const float* rec, int HID, const FlowIdx& x, const float (&z)[C], f32x2 (&o)[2],
-                                              f32x2 (&J)[2][2]) {
+template <int C, bool DU, int Q>
+__device__ __forceinline__ void rnvp_nets_any(const float* rec, int HID, const FlowIdx& x, const float (&z)[Q][C], f32x2 (&o)[Q][2],
+                                              f32x2 (&J)[Q][2][2]) {
     if (C == 2 || x.nin == 1) {
-        const float zin[1] = {sel<C>(z, x.in(0))};
+        float zin[Q][1];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) zin[q][0] = sel<C>(z[q], x.in(0));
         if (C == 2) {
-            f32x2 o1[1], J1[1][1];
-            rnvp_nets<1, 1, DU>(rec, HID, zin, o1, J1);
-            o[0] = o1[0];
-            J[0][0] = J1[0][0];
+            f32x2 o1[Q][1], J1[Q][1][1];
+            rnvp_nets<1, 1, DU, Q>(rec, HID, zin, o1, J1);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                o[q][0] = o1[q][0];
+                J[q][0][0] = J1[q][0][0];
+            }
         } else {
-            f32x2 o2[2], J2[2][1];
-            rnvp_nets<1, 2, DU>(rec, HID, zin, o2, J2);
-            o[0] = o2[0];
-            o[1] = o2[1];
-            J[0][0] = J2[0][0];
-            J[1][0] = J2[1][0];
+            f32x2 o2[Q][2], J2[Q][2][1];
+            rnvp_nets<1, 2, DU, Q>(rec, HID, zin, o2, J2);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                o[q][0] = o2[q][0];
+                o[q][1] = o2[q][1];
+                J[q][0][0] = J2[q][0][0];
+                J[q][1][0] = J2[q][1][0];
+            }
         }
     } else {
-        const float zin[2] = {sel<C>(z, x.in(0)), sel<C>(z, x.in(1))};
-        f32x2 o1[1], J1[1][2];
-        rnvp_nets<2, 1, DU>(rec, HID, zin, o1, J1);
-        o[0] = o1[0];
-        J[0][0] = J1[0][0];
-        J[0][1] = J1[0][1];
+        float zin[Q][2];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            zin[q][0] = sel<C>(z[q], x.in(0));
+            zin[q][1] = sel<C>(z[q], x.in(1));
+        }
+        f32x2 o1[Q][1], J1[Q][1][2];
+        rnvp_nets<2, 1, DU, Q>(rec, HID, zin, o1, J1);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            o[q][0] = o1[q][0];
+            J[q][0][0] = J1[q][0][0];
+            J[q][0][1] = J1[q][0][1];
+        }
     }
 }
 
-// one flow on z (MaskedAffineFlow, then ActNorm unless !ACTNORM); y[k] = (s, t) after the output function
-template <int C, bool ACTNORM>
-__device__ __forceinline__ void rnvp_flow_forward(const float* rec, const RnvpMap& m, const FlowIdx& x, float (&z)[C]) {
-    f32x2 o[2], J[2][2];
-    rnvp_nets_any<C, false>(rec, m.HID, x, z, o, J);
+// one flow on z (MaskedAffineFlow, then ActNorm unless !ACTNORM)
+template <int C, bool ACTNORM, int Q>
+__device__ __forceinline__ void rnvp_flow_forward(const float* rec, const RnvpMap& m, const FlowIdx& x, float (&z)[Q][C]) {
+    f32x2 o[Q][2], J[Q][2][2];
+    rnvp_nets_any<C, false, Q>(rec, m.HID, x, z, o, J);
+    const float* tl = rec + m.HID * RNVP_REC;
 #pragma unroll
-    for (int k = 0; k < C - 1; ++k) {   // fixed bounds + guards: no dynamically indexed registers
-        if (k < x.nout) {
-            float s = o[k][0], t = o[k][1];
-            if (m.out_fn) {
-                s = tanhf(s) * m.out_scale;
-                t = tanhf(t) * m.out_scale;
+    for (int q = 0; q < Q; ++q) {
+#pragma unroll
+        for (int k = 0; k < C - 1; ++k) {   // fixed bounds + guards: no dynamically indexed registers
+            if (k < x.nout) {
+                float s = o[q][k][0], t = o[q][k][1];
+                if (m.out_fn) {
+                    s = fast_tanh(s) * m.out_scale;
+                    t = fast_tanh(t) * m.out_scale;
+                }
+                const float es = fast_exp(s);
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (c == x.out(k)) z[q][c] = fmaf(z[q][c], es, t);
             }
-            const float es = expf(s);
-#pragma unroll
-            for (int c = 0; c < C; ++c)
-                if (c == x.out(k)) z[c] = fmaf(z[c], es, t);
         }
-    }
-    if (ACTNORM) {
-        const float* tl = rec + m.HID * RNVP_REC;
+        if (ACTNORM) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) z[c] = fmaf(z[c], tl[4 + c], tl[7 + c]);
+            for (int c = 0; c < C; ++c) z[q][c] = fmaf(z[q][c], tl[4 + c], tl[7 + c]);
+        }
     }
 }
 
@@ -221,7 +278,7 @@ __device__ __forceinline__ void load_coords(const InrGridDesc& gd, int img, long
 }
 
 struct RnvpFwdArgs {
-    const float* RP;   // [n_images][RP]
+    const float* RE;   // [n_images][LDSF] packed image (rnvp_pack_kernel)
     float* xd;         // [n_images][C][N] deformed coordinates
     float* zs;         // [n_images][F][C][N] state in front of every flow, or null
     InrGridDesc grid;
@@ -229,35 +286,47 @@ struct RnvpFwdArgs {
     RnvpMap m;
 };
 
-template <int C>
+// grid: x = blocks of 256 Q points (lane t of the block owns points base + q 256 + t), y = image.  Q = 2 when there are
+// enough points to keep every SIMD busy with half the waves: the broadcast record reads are the bottleneck of the unit loops.
+template <int C, int Q>
 __global__ __launch_bounds__(256) void rnvp_fwd_kernel(const RnvpFwdArgs a) {
     const int img = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
     const int N = (int)a.N;
-    const bool valid = p < N;
     extern __shared__ __attribute__((aligned(16))) float rsm[];
-    rnvp_params_to_lds<C>(a.RP + (size_t)img * a.m.RP, rsm, a.m, 0, a.m.F);
-    float x[C], z[C];
-    load_coords<C>(a.grid, img, a.N, valid ? p : N - 1, x);
+    flow_weights_to_lds(a.RE + (size_t)img * a.m.LDSF, rsm, a.m.LDSF);
+    int p[Q];
+    float z[Q][C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) z[c] = minmax_fwd(fmaf(rsm[c], x[c], rsm[3 + c]), a.m.vmin[c], a.m.vmax[c], a.m.nmin, a.m.nmax);
+    for (int q = 0; q < Q; ++q) {
+        p[q] = (blockIdx.x * Q + q) * 256 + threadIdx.x;
+        float x[C];
+        load_coords<C>(a.grid, img, a.N, p[q] < N ? p[q] : N - 1, x);
+#pragma unroll
+        for (int c = 0; c < C; ++c) z[q][c] = minmax_fwd(fmaf(rsm[c], x[c], rsm[3 + c]), a.m.vmin[c], a.m.vmax[c], a.m.nmin, a.m.nmax);
+    }
     for (int f = 0; f < a.m.F; ++f) {
-        if (a.zs != nullptr && valid) {
+        if (a.zs != nullptr) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) a.zs[(((size_t)img * a.m.F + f) * C + c) * N + p] = z[c];
+            for (int q = 0; q < Q; ++q)
+                if (p[q] < N) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) a.zs[(((size_t)img * a.m.F + f) * C + c) * N + p[q]] = z[q][c];
+                }
         }
-        rnvp_flow_forward<C, true>(rsm + RNVP_HDR + f * a.m.fl, a.m, flow_idx<C>(a.m.masks[f]), z);
+        rnvp_flow_forward<C, true, Q>(rsm + RNVP_HDR + f * a.m.fl, a.m, flow_idx<C>(a.m.masks[f]), z);
     }
-    if (valid) {
 #pragma unroll
-        for (int c = 0; c < C; ++c)
-            a.xd[((size_t)img * C + c) * N + p] = minmax_fwd(z[c], a.m.nmin, a.m.nmax, a.m.vmin[c], a.m.vmax[c]);
-    }
+    for (int q = 0; q < Q; ++q)
+        if (p[q] < N) {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                a.xd[((size_t)img * C + c) * N + p[q]] = minmax_fwd(z[q][c], a.m.nmin, a.m.nmax, a.m.vmin[c], a.m.vmax[c]);
+        }
 }
 
 // ---- backward, lane = point ----------------------------------------------------------------------------------------------
 struct RnvpBwdArgs {
-    const float* RP;
+    const float* RE;
     const float* dxd;   // [n_images][C][N]
     const float* zs;    // [n_images][F][C][N]
     float* ps;          // [n_images][F][A][N]
@@ -268,111 +337,121 @@ struct RnvpBwdArgs {
     int S1;
 };
 
-template <int C>
+template <int C, int Q>
 __global__ __launch_bounds__(256) void rnvp_bwd_points_kernel(const RnvpBwdArgs a) {
     const int img = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
     const int N = (int)a.N, F = a.m.F;
-    const bool valid = p < N;
-    const int pc = valid ? p : N - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     extern __shared__ __attribute__((aligned(16))) float rsm[];
     float* red = rsm + a.m.LDSF;   // [4][S1]
-    rnvp_params_to_lds<C>(a.RP + (size_t)img * a.m.RP, rsm, a.m, 0, F);
+    flow_weights_to_lds(a.RE + (size_t)img * a.m.LDSF, rsm, a.m.LDSF);
+    int p[Q], pc[Q];
+    bool valid[Q];
     // gradient at the flow output: through MinMax.inverse_transform
-    float g[C];
+    float g[Q][C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const float d = valid ? a.dxd[((size_t)img * C + c) * N + pc] : 0.f;
-        g[c] = d * (a.m.vmax[c] - a.m.vmin[c]) / (a.m.nmax - a.m.nmin);
+    for (int q = 0; q < Q; ++q) {
+        p[q] = (blockIdx.x * Q + q) * 256 + threadIdx.x;
+        valid[q] = p[q] < N;
+        pc[q] = valid[q] ? p[q] : N - 1;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float d = valid[q] ? a.dxd[((size_t)img * C + c) * N + pc[q]] : 0.f;
+            g[q][c] = d * (a.m.vmax[c] - a.m.vmin[c]) / (a.m.nmax - a.m.nmin);
+        }
     }
     for (int f = F - 1; f >= 0; --f) {
         const float* rec = rsm + RNVP_HDR + f * a.m.fl;
         const float* tl = rec + a.m.HID * RNVP_REC;
         const FlowIdx x = flow_idx<C>(a.m.masks[f]);
-        float z[C];
+        float z[Q][C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) z[c] = a.zs[(((size_t)img * F + f) * C + c) * N + pc];
-        f32x2 o[2], J[2][2];
-        rnvp_nets_any<C, true>(rec, a.m.HID, x, z, o, J);
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int c = 0; c < C; ++c) z[q][c] = a.zs[(((size_t)img * F + f) * C + c) * N + pc[q]];
+        f32x2 o[Q][2], J[Q][2][2];
+        rnvp_nets_any<C, true, Q>(rec, a.m.HID, x, z, o, J);
         float acc[4 * C];   // db2s[C] | db2t[C] | das[C] | dat[C]
 #pragma unroll
         for (int k = 0; k < 4 * C; ++k) acc[k] = 0.f;
-        // post-coupling state and the outputs of the nets
-        float zc[C], es[2], dfs[2], dft[2];
 #pragma unroll
-        for (int c = 0; c < C; ++c) zc[c] = z[c];
+        for (int q = 0; q < Q; ++q) {
+            // post-coupling state and the outputs of the nets
+            float zc[C], es[2], dfs[2], dft[2];
 #pragma unroll
-        for (int k = 0; k < C - 1; ++k) {
-            es[k] = dfs[k] = dft[k] = 0.f;
-            if (k < x.nout) {
-                float s = o[k][0], t = o[k][1];
-                dfs[k] = dft[k] = 1.f;
-                if (a.m.out_fn) {
-                    const float ths = tanhf(s), tht = tanhf(t);
-                    s = ths * a.m.out_scale;
-                    t = tht * a.m.out_scale;
-                    dfs[k] = (1.f - ths * ths) * a.m.out_scale;
-                    dft[k] = (1.f - tht * tht) * a.m.out_scale;
-                }
-                es[k] = expf(s);
+            for (int c = 0; c < C; ++c) zc[c] = z[q][c];
 #pragma unroll
-                for (int c = 0; c < C; ++c)
-                    if (c == x.out(k)) zc[c] = fmaf(z[c], es[k], t);
-            }
-        }
-        // ActNorm: y = zc * exp(as) + at
-        float gz[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const float ea = tl[4 + c];
-            acc[2 * C + c] = g[c] * zc[c] * ea;
-            acc[3 * C + c] = g[c];
-            gz[c] = g[c] * ea;
-        }
-        // coupling
-        float dos[2] = {0.f, 0.f}, dot[2] = {0.f, 0.f}, gin[2] = {0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < C - 1; ++k) {
-            if (k < x.nout) {
-                const float gk = sel<C>(gz, x.out(k)), zk = sel<C>(z, x.out(k));
-                dos[k] = gk * zk * es[k] * dfs[k];
-                dot[k] = gk * dft[k];
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-                    if (c == x.out(k)) {
-                        gz[c] = gk * es[k];
-                        acc[c] = dos[k];
-                        acc[C + c] = dot[k];
+            for (int k = 0; k < C - 1; ++k) {
+                es[k] = dfs[k] = dft[k] = 0.f;
+                if (k < x.nout) {
+                    float s = o[q][k][0], t = o[q][k][1];
+                    dfs[k] = dft[k] = 1.f;
+                    if (a.m.out_fn) {
+                        const float ths = fast_tanh(s), tht = fast_tanh(t);
+                        s = ths * a.m.out_scale;
+                        t = tht * a.m.out_scale;
+                        dfs[k] = (1.f - ths * ths) * a.m.out_scale;
+                        dft[k] = (1.f - tht * tht) * a.m.out_scale;
                     }
+                    es[k] = fast_exp(s);
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        if (c == x.out(k)) zc[c] = fmaf(z[q][c], es[k], t);
+                }
+            }
+            // ActNorm: y = zc * exp(as) + at
+            float gz[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float ea = tl[4 + c];
+                acc[2 * C + c] += g[q][c] * zc[c] * ea;
+                acc[3 * C + c] += g[q][c];
+                gz[c] = g[q][c] * ea;
+            }
+            // coupling
+            float dos[2] = {0.f, 0.f}, dot[2] = {0.f, 0.f}, gin[2] = {0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < C - 1; ++k) {
+                if (k < x.nout) {
+                    const float gk = sel<C>(gz, x.out(k)), zk = sel<C>(z[q], x.out(k));
+                    dos[k] = gk * zk * es[k] * dfs[k];
+                    dot[k] = gk * dft[k];
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        if (c == x.out(k)) {
+                            gz[c] = gk * es[k];
+                            acc[c] += dos[k];
+                            acc[C + c] += dot[k];
+                        }
+#pragma unroll
+                    for (int mm = 0; mm < C - 1; ++mm)
+                        if (mm < x.nin) gin[mm] += dos[k] * J[q][k][mm][0] + dot[k] * J[q][k][mm][1];
+                }
+            }
+#pragma unroll
+            for (int mm = 0; mm < C - 1; ++mm) {
+                if (mm < x.nin) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        if (c == x.in(mm)) gz[c] += gin[mm];
+                }
+            }
+            if (valid[q]) {
+                float* pp = a.ps + (((size_t)img * F + f) * a.m.A) * N + p[q];
+                int r = 0;
 #pragma unroll
                 for (int mm = 0; mm < C - 1; ++mm)
-                    if (mm < x.nin) gin[mm] += dos[k] * J[k][mm][0] + dot[k] * J[k][mm][1];
+                    if (mm < x.nin) pp[(size_t)(r++) * N] = sel<C>(z[q], x.in(mm));
+#pragma unroll
+                for (int k = 0; k < C - 1; ++k)
+                    if (k < x.nout) pp[(size_t)(r++) * N] = dos[k];
+#pragma unroll
+                for (int k = 0; k < C - 1; ++k)
+                    if (k < x.nout) pp[(size_t)(r++) * N] = dot[k];
             }
+#pragma unroll
+            for (int c = 0; c < C; ++c) g[q][c] = gz[c];
         }
-#pragma unroll
-        for (int mm = 0; mm < C - 1; ++mm) {
-            if (mm < x.nin) {
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-                    if (c == x.in(mm)) gz[c] += gin[mm];
-            }
-        }
-        if (valid) {
-            float* pp = a.ps + (((size_t)img * F + f) * a.m.A) * N + p;
-            int q = 0;
-#pragma unroll
-            for (int mm = 0; mm < C - 1; ++mm)
-                if (mm < x.nin) pp[(size_t)(q++) * N] = sel<C>(z, x.in(mm));
-#pragma unroll
-            for (int k = 0; k < C - 1; ++k)
-                if (k < x.nout) pp[(size_t)(q++) * N] = dos[k];
-#pragma unroll
-            for (int k = 0; k < C - 1; ++k)
-                if (k < x.nout) pp[(size_t)(q++) * N] = dot[k];
-        }
-#pragma unroll
-        for (int c = 0; c < C; ++c) g[c] = gz[c];
 #pragma unroll
         for (int k = 0; k < 4 * C; ++k) {
             const float v = sum_over_groups(sum_over_points(acc[k]));
@@ -381,15 +460,26 @@ __global__ __launch_bounds__(256) void rnvp_bwd_points_kernel(const RnvpBwdArgs 
     }
     // MinMax.transform and the 1x1 "linear": z0 = ((a x + b) - min)/(max - min) * (nmax - nmin) + nmin
     {
-        float x[C];
-        load_coords<C>(a.grid, img, a.N, pc, x);
+        float da[C], db[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) da[c] = db[c] = 0.f;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            float x[C];
+            load_coords<C>(a.grid, img, a.N, pc[q], x);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float gv = g[q][c] * (a.m.nmax - a.m.nmin) / (a.m.vmax[c] - a.m.vmin[c]);
+                da[c] += gv * x[c];
+                db[c] += gv;
+            }
+        }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const float gv = g[c] * (a.m.nmax - a.m.nmin) / (a.m.vmax[c] - a.m.vmin[c]);
-            const float da = sum_over_groups(sum_over_points(gv * x[c])), db = sum_over_groups(sum_over_points(gv));
+            const float sa = sum_over_groups(sum_over_points(da[c])), sb = sum_over_groups(sum_over_points(db[c]));
             if (lane == 0) {
-                red[wave * a.S1 + F * 4 * C + c] = da;
-                red[wave * a.S1 + F * 4 * C + C + c] = db;
+                red[wave * a.S1 + F * 4 * C + c] = sa;
+                red[wave * a.S1 + F * 4 * C + C + c] = sb;
             }
         }
     }
@@ -410,125 +500,143 @@ struct RnvpUnitsArgs {
 
 // relu nets: with st = step(pre_j), S0[k] = sum_p do_k st and S1[k][m] = sum_p do_k zin_m st give
 //   db1_j = sum_k W2[k][j] S0[k];  dW1[j][m] = sum_k W2[k][j] S1[k][m];  dW2[k][j] = sum_m W1[j][m] S1[k][m] + b1_j S0[k]
-template <int C, int NIN, int NOUT>
-__device__ __forceinline__ void rnvp_units_body(const RnvpUnitsArgs& a, const FlowIdx& x, float (*red)[2 * 3 + 1][64]) {
-    const int img = blockIdx.z, chunk = blockIdx.x, fn = blockIdx.y;
-    const int f = fn >> 1, net = fn & 1;
+// Lane = point (4 points per lane and trip), the moment sums of a unit live in registers as packed (s-net, t-net) pairs:
+// per unit and point one packed fma (pre), one packed step and NOUT (1 + NIN) packed fmas for BOTH nets, no broadcasts.
+// The 4 waves of a block split the hidden units (UPW each) and all walk the block's points; one cross-lane reduction per
+// accumulator at the very end.
+template <int C, int NIN, int NOUT, int UPW>
+__device__ __forceinline__ void rnvp_units_body(const RnvpUnitsArgs& a, const FlowIdx& x, float* lds) {
+    constexpr int PPL = 4;
+    const int img = blockIdx.z, chunk = blockIdx.x, f = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = (int)a.N, HID = a.m.HID;
-    const bool on = lane < HID;
-    const float* __restrict__ pn = a.RP + (size_t)img * a.m.RP + 2 * C + (size_t)f * a.m.pf + net * a.m.net;
-    float w1[NIN], w2[NOUT], b1 = on ? pn[HID * C + lane] : 0.f;
-#pragma unroll
-    for (int mm = 0; mm < NIN; ++mm) w1[mm] = on ? pn[lane * C + x.in(mm)] : 0.f;
-#pragma unroll
-    for (int k = 0; k < NOUT; ++k) w2[k] = on ? pn[HID * C + HID + x.out(k) * HID + lane] : 0.f;
+    const float* __restrict__ rp = a.RP + (size_t)img * a.m.RP;
+    rnvp_params_to_lds<C>(rp, lds, a.m, f, f + 1);
+    const float* rec = lds + RNVP_HDR;
     const int per_chunk = (N + a.chunks - 1) / a.chunks;
-    const int per_wave = (per_chunk + 3) / 4;
-    const int p0 = chunk * per_chunk + wave * per_wave;
-    int p1 = p0 + per_wave;
-    const int cend = (chunk + 1) * per_chunk;
-    if (p1 > cend) p1 = cend;
+    const int p0 = chunk * per_chunk;
+    int p1 = p0 + per_chunk;
     if (p1 > N) p1 = N;
     const float* __restrict__ base = a.ps + (((size_t)img * a.m.F + f) * a.m.A) * N;
-    const float* __restrict__ pz[NIN];
-    const float* __restrict__ pd[NOUT];
+    f32x2 S0[UPW][NOUT], S1[UPW][NOUT][NIN];
 #pragma unroll
-    for (int mm = 0; mm < NIN; ++mm) pz[mm] = base + (size_t)mm * N;
-#pragma unroll
-    for (int k = 0; k < NOUT; ++k) pd[k] = base + (size_t)(NIN + net * NOUT + k) * N;
-    f32x2 S0[NOUT], S1[NOUT][NIN];
-#pragma unroll
-    for (int k = 0; k < NOUT; ++k) {
-        S0[k] = f32x2{0.f, 0.f};
-#pragma unroll
-        for (int mm = 0; mm < NIN; ++mm) S1[k][mm] = f32x2{0.f, 0.f};
-    }
-    auto bc = [](float v, int k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k)); };
-    float zn[NIN], dn[NOUT];
-    auto fetch = [&](int p) {
-        const bool in = p + lane < p1;
-#pragma unroll
-        for (int mm = 0; mm < NIN; ++mm) zn[mm] = in ? pz[mm][p + lane] : 0.f;
-#pragma unroll
-        for (int k = 0; k < NOUT; ++k) dn[k] = in ? pd[k][p + lane] : 0.f;   // do = 0 past p1: those points contribute nothing
-    };
-    fetch(p0);
-    for (int p = p0; p < p1; p += 64) {
-        float zc[NIN], dc[NOUT], pr[NOUT][NIN];
-#pragma unroll
-        for (int mm = 0; mm < NIN; ++mm) zc[mm] = zn[mm];
+    for (int u = 0; u < UPW; ++u)
 #pragma unroll
         for (int k = 0; k < NOUT; ++k) {
-            dc[k] = dn[k];
+            S0[u][k] = f32x2{0.f, 0.f};
 #pragma unroll
-            for (int mm = 0; mm < NIN; ++mm) pr[k][mm] = dn[k] * zn[mm];
+            for (int mm = 0; mm < NIN; ++mm) S1[u][k][mm] = f32x2{0.f, 0.f};
         }
-        fetch(p + 64);
+    for (int p = p0; p < p1; p += 64 * PPL) {
+        float zin[PPL][NIN];
+        f32x2 dd[PPL][NOUT], dz[PPL][NOUT][NIN];
 #pragma unroll
-        for (int q = 0; q < 64; q += 2) {
-            f32x2 pre = f32x2{b1, b1};
+        for (int q = 0; q < PPL; ++q) {
+            const int idx = p + q * 64 + lane;
+            const bool in = idx < p1;   // do = 0 past the end: those points contribute nothing
 #pragma unroll
-            for (int mm = 0; mm < NIN; ++mm) pre += f32x2{w1[mm], w1[mm]} * f32x2{bc(zc[mm], q), bc(zc[mm], q + 1)};
-            const f32x2 st = step01(pre);
+            for (int mm = 0; mm < NIN; ++mm) zin[q][mm] = in ? base[(size_t)mm * N + idx] : 0.f;
 #pragma unroll
             for (int k = 0; k < NOUT; ++k) {
-                S0[k] += f32x2{bc(dc[k], q), bc(dc[k], q + 1)} * st;
+                dd[q][k] = in ? f32x2{base[(size_t)(NIN + k) * N + idx], base[(size_t)(NIN + NOUT + k) * N + idx]} : f32x2{0.f, 0.f};
 #pragma unroll
-                for (int mm = 0; mm < NIN; ++mm) S1[k][mm] += f32x2{bc(pr[k][mm], q), bc(pr[k][mm], q + 1)} * st;
+                for (int mm = 0; mm < NIN; ++mm) dz[q][k][mm] = dd[q][k] * f32x2{zin[q][mm], zin[q][mm]};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UPW; ++u) {
+            const int j = wave * UPW + u;
+            if (j < HID) {   // wave-uniform
+                const f32x4 r0 = *(const f32x4*)(rec + RNVP_REC * j), r1 = *(const f32x4*)(rec + RNVP_REC * j + 4);
+                const float v[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) {
+                    f32x2 pre = f32x2{v[2 * NIN], v[2 * NIN + 1]};
+#pragma unroll
+                    for (int mm = 0; mm < NIN; ++mm) pre += f32x2{v[2 * mm], v[2 * mm + 1]} * f32x2{zin[q][mm], zin[q][mm]};
+                    const f32x2 st = step01(pre);
+#pragma unroll
+                    for (int k = 0; k < NOUT; ++k) {
+                        S0[u][k] += dd[q][k] * st;
+#pragma unroll
+                        for (int mm = 0; mm < NIN; ++mm) S1[u][k][mm] += dz[q][k][mm] * st;
+                    }
+                }
             }
         }
     }
+    // wave totals (in every lane), then lane l < 2 UPW keeps the sums of unit l >> 1, net l & 1
     float s0[NOUT], s1[NOUT][NIN];
 #pragma unroll
     for (int k = 0; k < NOUT; ++k) {
-        s0[k] = S0[k][0] + S0[k][1];
+        s0[k] = 0.f;
 #pragma unroll
-        for (int mm = 0; mm < NIN; ++mm) s1[k][mm] = S1[k][mm][0] + S1[k][mm][1];
-    }
-    float rows[2 * C + 1];
-#pragma unroll
-    for (int r = 0; r < 2 * C + 1; ++r) rows[r] = 0.f;
-    float db1 = 0.f;
-#pragma unroll
-    for (int k = 0; k < NOUT; ++k) {
-        db1 = fmaf(w2[k], s0[k], db1);
-        float dw2 = b1 * s0[k];
-#pragma unroll
-        for (int mm = 0; mm < NIN; ++mm) dw2 = fmaf(w1[mm], s1[k][mm], dw2);
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-            if (c == x.out(k)) rows[C + 1 + c] = dw2;
+        for (int mm = 0; mm < NIN; ++mm) s1[k][mm] = 0.f;
     }
 #pragma unroll
-    for (int mm = 0; mm < NIN; ++mm) {
-        float dw1 = 0.f;
+    for (int u = 0; u < UPW; ++u)
 #pragma unroll
-        for (int k = 0; k < NOUT; ++k) dw1 = fmaf(w2[k], s1[k][mm], dw1);
+        for (int n = 0; n < 2; ++n) {
+            const bool me = lane == 2 * u + n;
 #pragma unroll
-        for (int c = 0; c < C; ++c)
-            if (c == x.in(mm)) rows[c] = dw1;
-    }
-    rows[C] = db1;
+            for (int k = 0; k < NOUT; ++k) {
+                const float t0 = sum_over_groups(sum_over_points(S0[u][k][n]));
+                s0[k] = me ? t0 : s0[k];
 #pragma unroll
-    for (int r = 0; r < 2 * C + 1; ++r) red[wave][r][lane] = rows[r];
-    __syncthreads();
-    for (int t = threadIdx.x; t < (2 * C + 1) * 64; t += 256) {
-        const int r = t >> 6, l = t & 63;
-        a.slab2[((((size_t)img * a.chunks + chunk) * (a.m.F * 2) + fn) * (2 * C + 1) + r) * 64 + l] =
-            ((red[0][r][l] + red[1][r][l]) + red[2][r][l]) + red[3][r][l];
+                for (int mm = 0; mm < NIN; ++mm) {
+                    const float t1 = sum_over_groups(sum_over_points(S1[u][k][mm][n]));
+                    s1[k][mm] = me ? t1 : s1[k][mm];
+                }
+            }
+        }
+    const int j = wave * UPW + (lane >> 1), net = lane & 1;
+    if (lane < 2 * UPW && j < HID) {
+        const float* __restrict__ pn = rp + 2 * C + (size_t)f * a.m.pf + net * a.m.net;
+        float w1[NIN], w2[NOUT];
+        const float b1 = pn[HID * C + j];
+#pragma unroll
+        for (int mm = 0; mm < NIN; ++mm) w1[mm] = pn[j * C + x.in(mm)];
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) w2[k] = pn[HID * C + HID + x.out(k) * HID + j];
+        float rows[2 * C + 1];   // dW1[:, c] (C) | db1 | dW2[c, :] (C); rows of inactive channels stay 0
+#pragma unroll
+        for (int r = 0; r < 2 * C + 1; ++r) rows[r] = 0.f;
+        float db1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) {
+            db1 = fmaf(w2[k], s0[k], db1);
+            float dw2 = b1 * s0[k];
+#pragma unroll
+            for (int mm = 0; mm < NIN; ++mm) dw2 = fmaf(w1[mm], s1[k][mm], dw2);
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                if (c == x.out(k)) rows[C + 1 + c] = dw2;
+        }
+#pragma unroll
+        for (int mm = 0; mm < NIN; ++mm) {
+            float dw1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) dw1 = fmaf(w2[k], s1[k][mm], dw1);
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                if (c == x.in(mm)) rows[c] = dw1;
+        }
+        rows[C] = db1;
+        float* __restrict__ dst = a.slab2 + ((((size_t)img * a.chunks + chunk) * (a.m.F * 2) + f * 2 + net) * (2 * C + 1)) * 64 + j;
+#pragma unroll
+        for (int r = 0; r < 2 * C + 1; ++r) dst[r * 64] = rows[r];
     }
 }
 
-template <int C>
+template <int C, int UPW>
 __global__ __launch_bounds__(256) void rnvp_bwd_units_kernel(const RnvpUnitsArgs a) {
-    // grid: x = chunk, y = flow*2 + net, z = image; wave w of the block takes a quarter of the chunk
-    __shared__ float red[4][2 * 3 + 1][64];
-    const FlowIdx x = flow_idx<C>(a.m.masks[blockIdx.y >> 1]);
-    if (C == 2) rnvp_units_body<C, 1, 1>(a, x, red);
-    else if (x.nin == 1) rnvp_units_body<C, 1, C == 2 ? 1 : 2>(a, x, red);
-    else rnvp_units_body<C, C == 2 ? 1 : 2, 1>(a, x, red);
+    // grid: x = chunk of points, y = flow, z = image; wave w owns hidden units [w UPW, (w + 1) UPW)
+    extern __shared__ __attribute__((aligned(16))) float rsm[];
+    const FlowIdx x = flow_idx<C>(a.m.masks[blockIdx.y]);
+    if (C == 2) rnvp_units_body<C, 1, 1, UPW>(a, x, rsm);
+    else if (x.nin == 1) rnvp_units_body<C, 1, C == 2 ? 1 : 2, UPW>(a, x, rsm);
+    else rnvp_units_body<C, C == 2 ? 1 : 2, 1, UPW>(a, x, rsm);
 }
 
 // ---- reduction + optimizer --------------------------------------------------------------------------------------------------
@@ -668,14 +776,14 @@ __global__ __launch_bounds__(1024) void rnvp_actnorm_init_kernel(const RnvpInitA
 #pragma unroll
         for (int c = 0; c < C; ++c) s[c] = 0.0;
         for (int p = threadIdx.x; p < N; p += blockDim.x) {
-            float z[C];
+            float z[1][C];
 #pragma unroll
-            for (int c = 0; c < C; ++c) z[c] = zb[(size_t)c * N + p];
-            rnvp_flow_forward<C, false>(rsm + RNVP_HDR, a.m, x, z);
+            for (int c = 0; c < C; ++c) z[0][c] = zb[(size_t)c * N + p];
+            rnvp_flow_forward<C, false, 1>(rsm + RNVP_HDR, a.m, x, z);
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                zb[(size_t)c * N + p] = z[c];
-                s[c] += (double)z[c];
+                zb[(size_t)c * N + p] = z[0][c];
+                s[c] += (double)z[0][c];
             }
         }
 #pragma unroll

@@ -1,1 +1,2 @@
-from .synthetic import SyntheticUnariesDataset, convex_blob_mask, convex_blob_unaries, disc_unaries  # noqa: F401
+from .synthetic import (SyntheticSequenceDataset, SyntheticUnariesDataset, convex_blob_mask, convex_blob_unaries,  # noqa: F401
+                        disc_unaries, dumbbell_sequence_masks)

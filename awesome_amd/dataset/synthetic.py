@@ -81,3 +81,54 @@ class SyntheticUnariesDataset:
 
     def batch(self, indices) -> torch.Tensor:
         return torch.stack([self.unaries(int(i)).reshape(-1) for i in indices])
+
+
+def dumbbell_sequence_masks(size: int = 128, frames: int = 16, seed: int = 0) -> np.ndarray:
+    """C4 '(x,y,t) sequence' (SURVEY.md §8d): an object of two discs joined by a thin bar, translating 2 px per frame; in
+    every third frame the bar is missing (the object is only connected through time) - the case the path-connectedness
+    prior over (x, y, t) exists for.  Returns bool (frames, size, size), True = object."""
+    rng = np.random.RandomState(seed)
+    s = size / 128.0
+    cy, cx = rng.uniform(50.0, 78.0) * s, rng.uniform(40.0, 56.0) * s
+    r, d, bar = 14.0 * s, 26.0 * s, max(1.0, 1.5 * s)
+    ang = rng.uniform(-0.5, 0.5)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float64)
+    out = np.zeros((frames, size, size), dtype=bool)
+    for t in range(frames):
+        ox, oy = cx + 2.0 * t * s, cy + 0.5 * t * s
+        ax, ay = ox - d * np.cos(ang), oy - d * np.sin(ang)
+        bx, by = ox + d * np.cos(ang), oy + d * np.sin(ang)
+        m = ((xx - ax) ** 2 + (yy - ay) ** 2 <= r * r) | ((xx - bx) ** 2 + (yy - by) ** 2 <= r * r)
+        if t % 3 != 2:
+            # distance to the segment a-b
+            px, py = xx - ax, yy - ay
+            vx, vy = bx - ax, by - ay
+            u = np.clip((px * vx + py * vy) / (vx * vx + vy * vy), 0.0, 1.0)
+            m |= (px - u * vx) ** 2 + (py - u * vy) ** 2 <= bar * bar
+        out[t] = m
+    return out
+
+
+class SyntheticSequenceDataset:
+    """Item i = one (x, y, t) sequence for the spatio-temporal prior: `coords(i)` (3, T*H*W) = linspace(0,1) x linspace(0,1) x
+    t/t_max (awesome/dataset/transformator.py:25-61) and `unaries(i)` (T*H*W,) with fg = 0."""
+
+    def __init__(self, n_sequences: int = 1, size: int = 128, frames: int = 16, seed0: int = 0, **kwargs):
+        self.n_images, self.size, self.frames, self.seed0 = int(n_sequences), int(size), int(frames), int(seed0)
+
+    def __len__(self) -> int:
+        return self.n_images
+
+    def coords(self) -> torch.Tensor:
+        s, t = self.size, self.frames
+        lin = torch.linspace(0, 1, s)
+        ts = torch.arange(t).float() / float(max(t - 1, 1))
+        tt, yy, xx = torch.meshgrid(ts, lin, lin, indexing="ij")
+        return torch.stack([xx.reshape(-1), yy.reshape(-1), tt.reshape(-1)], 0)
+
+    def unaries(self, i: int) -> torch.Tensor:
+        m = dumbbell_sequence_masks(self.size, self.frames, self.seed0 + i)
+        return torch.from_numpy(1.0 - m.astype(np.float32)).reshape(-1)
+
+    def batch(self, indices) -> torch.Tensor:
+        return torch.stack([self.unaries(int(i)) for i in indices])

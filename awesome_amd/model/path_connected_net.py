@@ -1,0 +1,325 @@
+"""PathConnectedNet with the RealNVP deformation, with the reference's module surface and state_dict keys.
+
+Reference: PathConnectedNet (awesome/model/path_connected_net.py:53-133), built by real_nvp_path_connected_net
+(awesome/model/net_factory.py:124-175) as
+    convex_net = ConvexNextNet(...),  flow_net = NormNet(net=PixelizeNet(network=nf.NormalizingFlow(...)), norm=MinMax),
+    linear = Conv2d(C, C, 1, groups=C)
+with nf = normflows==1.7.3 (not part of the reference checkout; its MaskedAffineFlow / ActNorm / MLP definitions are
+restated by the HIP kernels, awesome_amd/csrc/rnvp.h - parity for this variant is UNPINNED).
+
+The sub-modules below are the containers of the parameters (same names, shapes and nesting as the reference's
+state_dict: `flow_net.net.network.flows.{2f}.{s,t}.net.{0,2}.{weight,bias}`, `flow_net.net.network.flows.{2f+1}.{s,t}`,
+`flow_net.norm.{min,max,new_min,new_max}`, `linear.{weight,bias}`, `convex_net.*`).  Evaluation - forward, autograd
+backward, get_deformation, the ActNorm data-dependent init and the fused fit - runs on the HIP path only.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import icnn as K
+from .. import rnvp as R
+from .convex_net import ConvexNextNet
+
+
+def _hip_only(name: str):
+    raise RuntimeError(f"{name} is a parameter container: it is evaluated through PathConnectedNet on the HIP path "
+                       "(awesome_amd has no torch/CPU fallback)")
+
+
+class MLP(nn.Module):
+    """nf.nets.MLP([C, hid, C], init_zeros=True, output_fn=...): `net` = Linear, LeakyReLU(0.0), Linear[, Tanh]."""
+
+    def __init__(self, layers, init_zeros: bool = True, output_fn: Optional[str] = None):
+        super().__init__()
+        mods = [nn.Linear(layers[0], layers[1]), nn.LeakyReLU(0.0), nn.Linear(layers[1], layers[2])]
+        if init_zeros:
+            nn.init.zeros_(mods[-1].weight)
+            nn.init.zeros_(mods[-1].bias)
+        if output_fn == "tanh":
+            mods.append(nn.Tanh())
+        self.net = nn.Sequential(*mods)
+
+    def forward(self, x):
+        _hip_only("MLP")
+
+
+class MaskedAffineFlow(nn.Module):
+    def __init__(self, b: torch.Tensor, t: nn.Module, s: nn.Module):
+        super().__init__()
+        self.register_buffer("b", b.view(1, *b.size()))
+        self.add_module("s", s)
+        self.add_module("t", t)
+
+    def forward(self, z):
+        _hip_only("MaskedAffineFlow")
+
+
+class ActNorm(nn.Module):
+    def __init__(self, channels: int):
+        super().__init__()
+        self.s = nn.Parameter(torch.zeros(channels)[None])
+        self.t = nn.Parameter(torch.zeros(channels)[None])
+        self.register_buffer("data_dep_init_done", torch.tensor(0.0))
+
+    def forward(self, z):
+        _hip_only("ActNorm")
+
+
+class NormalizingFlow(nn.Module):
+    def __init__(self, flows):
+        super().__init__()
+        self.flows = nn.ModuleList(flows)
+
+    def forward(self, z):
+        _hip_only("NormalizingFlow")
+
+
+class PixelizeNet(nn.Module):
+    def __init__(self, network: nn.Module):
+        super().__init__()
+        self.network = network
+
+    def reset_parameters(self) -> None:
+        # TensorUtil.reset_parameters (awesome/util/torch.py:160-194): every leaf with reset_parameters() is re-drawn - the
+        # nn.Linear layers (incl. the zero-initialised last ones); ActNorm has none and keeps its state
+        for m in self.network.modules():
+            if isinstance(m, nn.Linear):
+                m.reset_parameters()
+
+    def forward(self, x):
+        _hip_only("PixelizeNet")
+
+
+class MinMax(nn.Module):
+    """awesome/transforms/min_max.py:22-61 (buffers only; the transform itself is inside the HIP kernels)."""
+
+    def __init__(self, new_min: float = -1.0, new_max: float = 1.0, dim=None):
+        super().__init__()
+        self.register_buffer("min", torch.zeros(1))
+        self.register_buffer("max", torch.ones(1))
+        self.register_buffer("new_min", torch.tensor(float(new_min)))
+        self.register_buffer("new_max", torch.tensor(float(new_max)))
+        self.dim = dim
+        self.fitted = False
+
+    def fit(self, x: torch.Tensor) -> None:
+        dims = tuple(self.dim) if self.dim is not None and not isinstance(self.dim, int) else self.dim
+        self.min = torch.amin(x, dim=dims, keepdim=True) if dims is not None else x.min()
+        self.max = torch.amax(x, dim=dims, keepdim=True) if dims is not None else x.max()
+        self.fitted = True
+
+
+class NormNet(nn.Module):
+    def __init__(self, net: nn.Module, norm: nn.Module):
+        super().__init__()
+        self.net = net
+        self.norm = norm
+
+    def reset_parameters(self) -> None:
+        self.net.reset_parameters()
+
+    def forward(self, x):
+        _hip_only("NormNet")
+
+
+def init_realnvp(channels: int, hidden_units: int = 8, n_flows: int = 6, output_fn: Optional[str] = None,
+                 output_scale: Optional[float] = None, **kwargs) -> NormalizingFlow:
+    """awesome/model/net_factory.py:70-114 (same creation order of the layers, so a seeded build = the reference's init)."""
+    if output_scale is not None and output_fn is None:
+        raise ValueError("output_scale needs an output_fn")
+    masks = R.rnvp_masks(channels, n_flows)
+    flows = []
+    for i in range(n_flows):
+        s = MLP([channels, hidden_units, channels], init_zeros=True, output_fn=output_fn)
+        t = MLP([channels, hidden_units, channels], init_zeros=True, output_fn=output_fn)
+        b = torch.tensor([(masks[i] >> c) & 1 for c in range(channels)], dtype=torch.uint8)
+        flows += [MaskedAffineFlow(b, t, s), ActNorm(channels)]
+    nf = NormalizingFlow(flows)
+    nf.output_fn, nf.output_scale = output_fn, output_scale
+    return nf
+
+
+class _PcnFunction(torch.autograd.Function):
+    """logits = ICNN(flow_net(linear(x))) on the HIP path; backward = gradients w.r.t. every parameter for a given dL/dlogits."""
+
+    @staticmethod
+    def forward(ctx, coords: torch.Tensor, ispec, rspec, n_icnn: int, *params: torch.Tensor):
+        flat = lambda ps: torch.cat([p.reshape(-1) for p in ps]).to(torch.float32)[None].contiguous()  # noqa: E731
+        ip, fp = flat(params[:n_icnn]), flat(params[n_icnn:])
+        grid = K.Grid.explicit(coords)
+        ctx.ispec, ctx.rspec, ctx.grid = ispec, rspec, grid
+        ctx.shapes = [p.shape for p in params]
+        ctx.save_for_backward(ip, fp)
+        return R.pcn_forward(ispec, rspec, ip, fp, grid)[0]
+
+    @staticmethod
+    def backward(ctx, dlogits: torch.Tensor):
+        ip, fp = ctx.saved_tensors
+        _, gi, gf = R.pcn_loss_grad(ctx.ispec, ctx.rspec, ip, fp, ctx.grid, dlogits.contiguous()[None], loss="external")
+        g = torch.cat([gi[0], gf[0]])
+        outs, off = [], 0
+        for shp in ctx.shapes:
+            n = math.prod(shp) if len(shp) else 1
+            outs.append(g[off:off + n].reshape(shp))
+            off += n
+        return (None, None, None, None, *outs)
+
+
+class PathConnectedNet(nn.Module):
+    """convex_net(flow_net(linear(x)))  (path_connected_net.py:53-85)."""
+
+    def __init__(self, convex_net: ConvexNextNet, flow_net: NormNet, in_channels: int = 2, **kwargs):
+        super().__init__()
+        self.convex_net = convex_net
+        self.flow_net = flow_net
+        self.in_channels = in_channels
+        self.linear = nn.Conv2d(in_channels, in_channels, 1, groups=in_channels)   # per-channel scale + translation
+        self._init_linear()
+
+    def _init_linear(self) -> None:
+        self.linear.weight.data.fill_(1)
+        self.linear.bias.data.fill_(0)
+
+    def reset_parameters(self) -> None:
+        self.convex_net.reset_parameters()
+        self.flow_net.reset_parameters()
+        self._init_linear()
+
+    def enforce_convexity(self) -> None:
+        self.convex_net.enforce_convexity()
+
+    # ---- flat views ---------------------------------------------------------------------------------------------------
+    def _specs(self) -> Tuple[K.IcnnSpec, R.RnvpSpec]:
+        nf = self.flow_net.net.network
+        norm = self.flow_net.norm
+        C = self.in_channels
+        lin0 = nf.flows[0].s.net[0]
+        vmin = tuple(float(v) for v in norm.min.reshape(-1).expand(C).tolist()) if norm.min.numel() in (1, C) else None
+        vmax = tuple(float(v) for v in norm.max.reshape(-1).expand(C).tolist()) if norm.max.numel() in (1, C) else None
+        if vmin is None or vmax is None:
+            raise ValueError("MinMax must be fitted per channel (dim=(0, 2, 3)) or globally")
+        masks = tuple(int(sum(int(nf.flows[2 * f].b.reshape(-1)[c]) << c for c in range(C))) for f in range(len(nf.flows) // 2))
+        rspec = R.RnvpSpec(C, lin0.out_features, len(nf.flows) // 2, getattr(nf, "output_fn", None),
+                           getattr(nf, "output_scale", None), vmin, vmax, float(norm.new_min), float(norm.new_max), masks)
+        return self.convex_net.spec, rspec
+
+    def _ordered_params(self):
+        ispec, rspec = self._specs()
+        sd = dict(self.named_parameters())
+        icnn = [sd["convex_net." + k] for k, _ in ispec.keys_shapes()]
+        flow = [sd[k] for k, _ in rspec.keys_shapes()]
+        return ispec, rspec, icnn, flow
+
+    def _flat(self, ps) -> torch.Tensor:
+        return torch.cat([p.detach().reshape(-1) for p in ps]).to(torch.float32)[None].contiguous()
+
+    def _actnorm_init_if_needed(self, coords: torch.Tensor) -> None:
+        """nf.flows.ActNorm's data-dependent init happens inside its first forward; here: one HIP pass over the grid."""
+        acts = [m for m in self.flow_net.net.network.flows if isinstance(m, ActNorm)]
+        if all(float(a.data_dep_init_done) > 0 for a in acts):
+            return
+        ispec, rspec, _, flow = self._ordered_params()
+        fp = self._flat(flow)
+        R.actnorm_init(rspec, fp, K.Grid.explicit(coords))
+        new = R.unpack_rnvp_params(rspec, fp[0])
+        sd = dict(self.named_parameters())
+        with torch.no_grad():
+            for f, a in enumerate(acts):
+                if float(a.data_dep_init_done) > 0:
+                    continue
+                for nm in ("s", "t"):
+                    k = f"flow_net.net.network.flows.{2 * f + 1}.{nm}"
+                    sd[k].copy_(new[k].to(sd[k].device))
+                a.data_dep_init_done.fill_(1.0)
+
+    @staticmethod
+    def _planar(x: torch.Tensor):
+        """(B,C,H,W) -> list of (C, H*W); (N,C) -> [(C, N)]."""
+        if x.dim() == 4:
+            b, c, h, w = x.shape
+            return [x[i].reshape(c, h * w) for i in range(b)], (b, h, w)
+        return [x.t().contiguous()], None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(B,C,H,W) -> (B,1,H,W) or (N,C) -> (N,1), forward and backward on the HIP path."""
+        if not x.is_cuda:
+            raise RuntimeError("awesome_amd modules run on the MI355X only (no CPU fallback); move module and input to cuda")
+        planes, bhw = self._planar(x)
+        # the reference's ActNorm sees the whole pixelized batch at its first forward (pixelize_net.py:15-19)
+        self._actnorm_init_if_needed(torch.cat(planes, dim=1))
+        ispec, rspec, icnn, flow = self._ordered_params()
+        run = lambda coords: _PcnFunction.apply(coords, ispec, rspec, len(icnn), *icnn, *flow)  # noqa: E731
+        if bhw is not None:
+            b, h, w = bhw
+            return torch.stack([run(p).reshape(1, h, w) for p in planes], 0)
+        return run(planes[0])[:, None]
+
+    def get_deformation(self, x: torch.Tensor) -> torch.Tensor:
+        """path_connected_net.py:124-128: flow_net(linear(x)) in the layout of x (no autograd)."""
+        planes, bhw = self._planar(x)
+        self._actnorm_init_if_needed(torch.cat(planes, dim=1))
+        _, rspec, _, flow = self._ordered_params()
+        fp = self._flat(flow)
+        outs = [R.rnvp_forward(rspec, fp, K.Grid.explicit(p))[0] for p in planes]
+        if bhw is not None:
+            b, h, w = bhw
+            return torch.stack([o.reshape(-1, h, w) for o in outs], 0)
+        return outs[0].t()
+
+    def fit_images(self, grid: "K.Grid", unaries: torch.Tensor, num_epochs: int = 2000, lr: float = 1e-3,
+                   flow_weight_decay: float = 1e-5, loss: str = "se", weight_mode: str = "none", optimizer: str = "adamax",
+                   plateau=None):
+        """Fused device-resident form of _prior_based_pretrain's inner loop (path_connected_net.py:922-962) for a batch of
+        images: every image starts from this module's current parameters (ActNorm initialised on the first image's grid if it
+        is not yet); returns the PcnFitResult (flat parameters per image)."""
+        n, dev = unaries.shape[0], unaries.device
+        if grid.coords is not None:
+            c0 = grid.coords if grid.coords.dim() == 2 else grid.coords[0]
+        else:
+            xs, ys = grid.xs, grid.ys
+            chans = [xs[None, :].expand(ys.numel(), -1).reshape(-1), ys[:, None].expand(-1, xs.numel()).reshape(-1)]
+            if grid.ts is not None:
+                chans.append(grid.ts[0].expand(chans[0].numel()))
+            c0 = torch.stack(chans, 0)
+        self._actnorm_init_if_needed(c0)
+        ispec, rspec, icnn, flow = self._ordered_params()
+        ip = self._flat(icnn).repeat(n, 1).contiguous().to(dev)
+        fp = self._flat(flow).repeat(n, 1).contiguous().to(dev)
+        return R.pcn_fit(ispec, rspec, ip, fp, grid, unaries, num_epochs, lr=lr, optimizer=optimizer, loss=loss,
+                         weight_mode=weight_mode, flow_weight_decay=flow_weight_decay,
+                         plateau=dict(patience=200, factor=0.5) if plateau is None else (plateau or None))
+
+    def load_flat(self, icnn_flat: torch.Tensor, flow_flat: torch.Tensor) -> None:
+        """Write one row of a PcnFitResult back into the module (the PriorCache round trip)."""
+        ispec, rspec = self._specs()
+        sd = {"convex_net." + k: v for k, v in K.unpack_params(ispec, icnn_flat).items()}
+        sd.update(R.unpack_rnvp_params(rspec, flow_flat))
+        own = dict(self.named_parameters())
+        with torch.no_grad():
+            for k, v in sd.items():
+                own[k].copy_(v.to(own[k].device))
+
+
+def real_nvp_path_connected_net(channels: int = 2, hidden_units: int = 130, flow_n_flows: int = 6,
+                                flow_output_fn: Optional[str] = None, flow_output_scale: Optional[float] = None,
+                                norm: str = "minmax", spatial_shape: tuple = (1000, 1000), convex_net_hidden_units: int = 130,
+                                convex_net_hidden_layers: int = 2, network_args: Optional[Dict[str, Any]] = None,
+                                **kwargs) -> PathConnectedNet:
+    """awesome/model/net_factory.py:124-175.  The MinMax is fitted on create_normalized_grid (values in [0, 1] per channel,
+    path_connected_net.py:273-296), i.e. min = 0, max = 1 per channel whatever spatial_shape is."""
+    if norm != "minmax":
+        raise ValueError("only norm='minmax' is built (every reference config uses it)")
+    flow_net = init_realnvp(channels=channels, hidden_units=hidden_units, output_fn=flow_output_fn,
+                            output_scale=flow_output_scale, n_flows=flow_n_flows)
+    mm = MinMax(dim=(0, 2, 3))
+    mm.min = torch.zeros(1, channels, 1, 1)
+    mm.max = torch.ones(1, channels, 1, 1)
+    mm.fitted = True
+    norm_flow = NormNet(net=PixelizeNet(flow_net), norm=mm)
+    return PathConnectedNet(convex_net=ConvexNextNet(n_hidden=convex_net_hidden_units, n_hidden_layers=convex_net_hidden_layers,
+                                                     in_features=channels),
+                            flow_net=norm_flow, in_channels=channels, **(network_args or {}))

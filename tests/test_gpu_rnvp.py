@@ -199,3 +199,97 @@ def test_fresh_flow_is_identity_after_actnorm_init(dev):
         A_ = torch.stack([g[c], torch.ones_like(g[c])], 1)
         sol = torch.linalg.lstsq(A_, xd[c][:, None]).solution
         assert float((A_ @ sol - xd[c][:, None]).abs().max()) < 1e-4
+
+
+def test_module_surface_and_autograd(dev):
+    """real_nvp_path_connected_net(...) (net_factory.py:124-175): state_dict keys, ActNorm init on first forward, forward
+    and autograd backward through the HIP path vs the oracle on the module's own state_dict."""
+    from awesome_amd.model import real_nvp_path_connected_net
+    torch.manual_seed(3)
+    m = real_nvp_path_connected_net(channels=2, hidden_units=32, flow_n_flows=12, flow_output_fn="tanh",
+                                    convex_net_hidden_units=130, convex_net_hidden_layers=2).to(dev)
+    keys = set(m.state_dict().keys())
+    for k in ("linear.weight", "linear.bias", "convex_net.input.weight", "flow_net.norm.min", "flow_net.norm.new_max",
+              "flow_net.net.network.flows.0.b", "flow_net.net.network.flows.0.s.net.0.weight",
+              "flow_net.net.network.flows.0.t.net.2.bias", "flow_net.net.network.flows.1.s", "flow_net.net.network.flows.1.t",
+              "flow_net.net.network.flows.1.data_dep_init_done", "flow_net.net.network.flows.23.t"):
+        assert k in keys, k
+    with torch.no_grad():   # move off the identity so that every gradient is non-trivial
+        for k, p in m.named_parameters():
+            if k.endswith("net.2.weight") or k.endswith("net.2.bias"):
+                p.copy_(0.1 * torch.randn_like(p))
+    H, W = 12, 20
+    grid_t, rows = _rows(2, H, W)
+    un = torch.rand(1, 1, H, W)
+    out = torch.sigmoid(m(grid_t[None].to(dev)))
+    assert out.shape == (1, 1, H, W)
+    assert float(m.flow_net.net.network.flows[1].data_dep_init_done) == 1.0
+    loss = ((out - un.to(dev)) ** 2).mean()
+    loss.backward()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype == torch.float32 and not k.startswith("flow_net.norm")
+           and not k.endswith("data_dep_init_done")}
+    masks = O.rnvp_masks(2, 12)
+    yo = O.pcn_forward(sdo, rows, masks, torch.zeros(2), torch.ones(2))
+    lo = ((torch.sigmoid(yo).reshape(1, 1, H, W) - un) ** 2).mean()
+    lo.backward()
+    assert float(loss.detach()) == pytest.approx(float(lo.detach()), rel=3e-5)
+    for k, p in m.named_parameters():
+        ref = sdo[k].grad.numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-3, atol=3e-5 * float(np.abs(ref).max()) + 1e-7, err_msg=k)
+    xd = m.get_deformation(grid_t[None].to(dev))
+    xr = O.pcn_deformation(sd, rows, masks, torch.zeros(2), torch.ones(2))
+    np.testing.assert_allclose(xd[0].reshape(2, -1).cpu().numpy(), xr.t().numpy(), rtol=3e-5, atol=5e-6)
+
+
+def test_fit_images_path_connected_shape(dev):
+    """A non-convex but path-connected target (two discs joined by a bar): the convex prior alone cannot represent it, the
+    path-connected prior fits it (the point of PathConnectedNet)."""
+    import awesome_amd as A
+    from awesome_amd.model import real_nvp_path_connected_net, ConvexNextNet
+    torch.manual_seed(0)
+    S = 64
+    yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+    mask = (((yy - 20) ** 2 + (xx - 18) ** 2) < 100) | (((yy - 44) ** 2 + (xx - 46) ** 2) < 100) | \
+           (((yy - 20).abs() < 4) & (xx >= 18) & (xx <= 46)) | (((xx - 46).abs() < 4) & (yy >= 20) & (yy <= 44))
+    un = (1.0 - mask.float()).reshape(1, -1).to(dev)
+    grid = A.Grid.linspace(S, S, dev)
+    m = real_nvp_path_connected_net(channels=2, hidden_units=32, flow_n_flows=12, flow_output_fn="tanh",
+                                    convex_net_hidden_layers=2).to(dev)
+    res = m.fit_images(grid, un, num_epochs=1500, lr=2e-3)
+    iou_pc = float(A.miou(torch.sigmoid(res.logits), un)[0])
+    cn = ConvexNextNet(n_hidden=130, n_hidden_layers=2, in_features=2)
+    rc = A.fit(cn.spec, cn.flat_parameters()[None].to(dev), grid, un, 1500, lr=2e-3, optimizer="adamax")
+    iou_cvx = float(A.miou(torch.sigmoid(rc.logits), un)[0])
+    assert int(res.status[0]) == 0
+    assert iou_pc > 0.9, (iou_pc, iou_cvx)
+    assert iou_pc > iou_cvx + 0.1, (iou_pc, iou_cvx)
+
+
+@pytest.mark.parametrize("C", [2, 3])
+def test_large_grid_two_points_per_lane(dev, C):
+    """>= 262144 points switch the point kernels to two points per lane: same results (ragged tail included)."""
+    from awesome_amd import rnvp as R
+    import awesome_amd as A
+    F = 4 if C == 2 else 6
+    ispec, rspec, sd = _case(C, 32, F, 1, seed=21 + C, h=64)
+    H, W = 517, 509
+    grid_t, rows = _rows(C, H, W)
+    torch.manual_seed(1)
+    un = (torch.rand(H * W, 1) > 0.5).float()
+    masks = O.rnvp_masks(C, F)
+    vmin, vmax = torch.tensor(rspec.vmin), torch.tensor(rspec.vmax)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yo = O.pcn_forward(sdo, rows, masks, vmin, vmax)
+    lo = O.weighted_loss(torch.sigmoid(yo).reshape(1, 1, -1, 1), un.reshape(1, 1, -1, 1), "se")
+    lo.backward()
+    ip, fp = _split(ispec, rspec, sd, dev)
+    grid = A.Grid.from_image_grid(grid_t.to(dev))
+    y = R.pcn_forward(ispec, rspec, ip, fp, grid)
+    np.testing.assert_allclose(y[0].cpu().numpy(), yo.detach().reshape(-1).numpy(), rtol=1e-4, atol=5e-5)
+    loss, gi, gf = R.pcn_loss_grad(ispec, rspec, ip, fp, grid, un.reshape(1, -1).to(dev), loss="se")
+    assert float(loss[0]) == pytest.approx(float(lo.detach()), rel=3e-5)
+    got = _merge(ispec, rspec, gi[0].cpu(), gf[0].cpu())
+    for k in sdo:
+        ref = sdo[k].grad.numpy()
+        np.testing.assert_allclose(got[k].numpy(), ref, rtol=2e-3, atol=1e-4 * float(np.abs(ref).max()) + 1e-8, err_msg=k)
