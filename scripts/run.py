@@ -26,6 +26,9 @@ import yaml  # noqa: E402
 ALIASES = {
     "awesome.model.convex_net.ConvexNextNet": "awesome_amd.model.ConvexNextNet",
     "awesome.model.convex_net.ConvexNet": "awesome_amd.model.ConvexNet",
+    "awesome.model.convex_diffeomorphism_net.ConvexDiffeomorphismNet": "awesome_amd.model.ConvexDiffeomorphismNet",
+    "awesome.model.net_factory.real_nvp_path_connected_net": "awesome_amd.model.real_nvp_path_connected_net",
+    "awesome.model.path_connected_net.PathConnectedNet": "awesome_amd.model.PathConnectedNet",
     "awesome.measures.se.SE": "awesome_amd.measures.SE",
     "awesome.measures.unaries_weighted_loss.UnariesWeightedLoss": "awesome_amd.measures.UnariesWeightedLoss",
 }
@@ -103,31 +106,75 @@ def main(cfg):
     criterion = build_criterion(cfg.get("loss_type"), cfg.get("loss_args"))
     opt_type = cfg.get("optimizer_type", "torch.optim.Adamax").rsplit(".", 1)[-1].lower()
     opt_args = dict(cfg.get("optimizer_args") or {})
-    fitter = BatchedPriorFitter(lambda: model_type(**model_args), num_epochs=num_epochs, lr=float(opt_args.get("lr", pre.get("lr", 1e-3))),
-                                optimizer=opt_type, weight_decay=float(opt_args.get("weight_decay", 0.0)), criterion=criterion,
-                                plateau=pre.get("plateau", None if pre.get("use_plateau", True) else False),
-                                proper_prior_fit_threshold=float(pre.get("proper_prior_fit_threshold", 0.5)),
-                                proper_prior_fit_retrys=int(pre.get("proper_prior_fit_retrys", 1)),
-                                reuse_state=bool(pre.get("reuse_state", False)),
-                                reuse_state_epochs=int(pre.get("reuse_state_epochs", 200)))
     mine = list(parallel.shard_range(len(dataset), rank, world))
     size = dataset.size
-    grid = A.Grid.linspace(size, size, device)
     unaries = dataset.batch(mine).to(device)
+    probe = model_type(**model_args)
+    flow_prior = hasattr(probe, "fit_images")   # ConvexDiffeomorphismNet / PathConnectedNet: ICNN behind a learned deformation
+    if hasattr(dataset, "coords"):              # (x, y, t) sequence: one network over all frames
+        grid = A.Grid.explicit(dataset.coords().to(device))
+    else:
+        grid = A.Grid.linspace(size, size, device)
+    lr = float(opt_args.get("lr", pre.get("lr", 1e-3)))
+    thr, retrys = float(pre.get("proper_prior_fit_threshold", 0.5)), int(pre.get("proper_prior_fit_retrys", 1))
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rep = fitter.fit_batch(grid, unaries)
+    if not flow_prior:
+        fitter = BatchedPriorFitter(lambda: model_type(**model_args), num_epochs=num_epochs, lr=lr,
+                                    optimizer=opt_type, weight_decay=float(opt_args.get("weight_decay", 0.0)), criterion=criterion,
+                                    plateau=pre.get("plateau", None if pre.get("use_plateau", True) else False),
+                                    proper_prior_fit_threshold=thr, proper_prior_fit_retrys=retrys,
+                                    reuse_state=bool(pre.get("reuse_state", False)),
+                                    reuse_state_epochs=int(pre.get("reuse_state_epochs", 200)))
+        rep = fitter.fit_batch(grid, unaries)
+        iou, retries = rep.iou, rep.retries
+        cache_state = lambda: fitter.prior_cache_state(rep, indices=mine, model_args=model_args)  # noqa: E731
+    else:
+        # _prior_based_pretrain / ConvexDiffeomorphismNet.pretrain semantics (path_connected_net.py:897-985): fit, IoU gate,
+        # reset_parameters + full refit of the images that failed it
+        from awesome_amd.measures import criterion_to_desc
+        kind, wmode, _ = criterion_to_desc(criterion) if criterion is not None else ("se", "none", 1.0)
+        kw = dict(num_epochs=num_epochs, lr=lr, loss=kind)
+        if hasattr(probe, "flow_net"):
+            kw.update(weight_mode=wmode, flow_weight_decay=float(pre.get("flow_weight_decay", 1e-5)), optimizer=opt_type)
+        model = probe.to(device)
+        res = model.fit_images(grid, unaries, **kw)
+        iou = A.miou(torch.sigmoid(res.logits), unaries)
+        retries = [0] * len(mine)
+        for attempt in range(retrys):
+            bad = [i for i in range(len(mine)) if float(iou[i]) < thr]
+            if not bad:
+                break
+            model.reset_parameters()
+            sub = model.fit_images(grid, unaries[bad].contiguous(), **kw)
+            sub_iou = A.miou(torch.sigmoid(sub.logits), unaries[bad].contiguous())
+            for n, i in enumerate(bad):
+                res.icnn_params[i], res.flow_params[i] = sub.icnn_params[n], sub.flow_params[n]
+                iou[i] = sub_iou[n]
+                retries[i] += 1
+
+        def cache_state():
+            from awesome_amd import flow as FL, rnvp as R
+            cache = {}
+            for n, i in enumerate(mine):
+                ispec, fspec = model._specs()
+                sd = {"convex_net." + k: v for k, v in A.unpack_params(ispec, res.icnn_params[n].cpu()).items()}
+                un = R.unpack_rnvp_params if hasattr(model, "flow_net") else FL.unpack_flow_params
+                sd.update(un(fspec, res.flow_params[n].cpu()))
+                cache[str(i)] = sd
+            return {"model_type": cfg.get("prior_model_type"), "model_args": json.dumps(model_args), "store_device": "cpu",
+                    "cache": cache}
     torch.cuda.synchronize()
     dt = parallel.max_over_ranks(time.perf_counter() - t0, device)
-    iou_all = parallel.gather_per_image(rep.iou, len(dataset), rank, world)
+    iou_all = parallel.gather_per_image(iou, len(dataset), rank, world)
     if rank == 0:
         out_dir = os.path.join(cfg.get("output_folder", "runs"), cfg.get("name_experiment", "inr_fit"))
         os.makedirs(out_dir, exist_ok=True)
-        torch.save(fitter.prior_cache_state(rep, indices=mine, model_args=model_args), os.path.join(out_dir, "prior_cache_epoch_0.pth"))
+        torch.save(cache_state(), os.path.join(out_dir, "prior_cache_epoch_0.pth"))
         summary = {"images": len(dataset), "ranks": world, "epochs": num_epochs, "seconds": round(dt, 4),
                    "fits_per_s": round(len(dataset) / dt, 4), "ForegroundBinaryMIOU_vs_unaries": round(float(iou_all.mean()), 5),
-                   "retries": rep.retries, "output": out_dir}
+                   "retries": retries, "output": out_dir}
         with open(os.path.join(out_dir, "summary.json"), "w") as f:
             json.dump(summary, f, indent=1)
         print(json.dumps(summary))

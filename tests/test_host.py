@@ -107,3 +107,81 @@ def test_sharding_rules():
     assert sum(len(parallel.shard_range(512, r, 8)) for r in range(8)) == 512
     owners = [parallel.shard_sequences([30, 5, 12, 12, 7], r, 2) for r in range(2)]
     assert sorted(owners[0] + owners[1]) == [0, 1, 2, 3, 4] and not set(owners[0]) & set(owners[1])
+
+
+# ---- RealNVP / PathConnectedNet host logic (row a10; parity unpinned - see tests/test_gpu_rnvp.py) ---------------------
+def test_rnvp_spec_layout_and_masks():
+    import ctypes
+    from awesome_amd import _lib as L
+    from awesome_amd import rnvp as R
+    for C, hid, F in ((2, 32, 12), (3, 32, 18), (3, 20, 5), (2, 64, 3)):
+        spec = R.RnvpSpec(C, hid, F)
+        assert spec.n_params == sum(int(np.prod(s)) for _, s in spec.keys_shapes())
+        d = spec.desc()
+        assert L.load().inrfit_rnvp_param_count(ctypes.byref(d)) == spec.n_params   # host-only entry point
+        ref = O.rnvp_masks(C, F)   # net_factory.py:86-99
+        assert [int(sum(int(ref[f, c]) << c for c in range(C))) for f in range(F)] == list(spec.masks)
+        flat = torch.arange(spec.n_params, dtype=torch.float32)
+        sd = R.unpack_rnvp_params(spec, flat)
+        assert torch.equal(R.pack_rnvp_state_dict(spec, sd), flat)
+        for (a, b) in spec.actnorm_slices():
+            assert b - a == 2 * C
+    bad = R.RnvpSpec(2, 200, 12).desc()   # hidden_units > 64: not built
+    assert L.load().inrfit_rnvp_param_count(ctypes.byref(bad)) < 0
+
+
+def test_path_connected_net_module_surface():
+    from awesome_amd.model import PathConnectedNet, real_nvp_path_connected_net
+    torch.manual_seed(0)
+    m = real_nvp_path_connected_net(channels=3, hidden_units=32, flow_n_flows=18, flow_output_fn="tanh")
+    assert isinstance(m, PathConnectedNet)
+    sd = m.state_dict()
+    ispec, rspec = m._specs()
+    assert (rspec.channels, rspec.hidden_units, rspec.n_flows, rspec.output_fn) == (3, 32, 18, "tanh")
+    assert rspec.vmin == (0.0, 0.0, 0.0) and rspec.vmax == (1.0, 1.0, 1.0) and (rspec.new_min, rspec.new_max) == (-1.0, 1.0)
+    for k, shp in rspec.keys_shapes():
+        assert tuple(sd[k].shape) == shp, k
+    # init_zeros=True (net_factory.py:104-105): the last layer of every MLP starts at zero, ActNorm at s = t = 0
+    for f in range(18):
+        for net in "st":
+            assert float(sd[f"flow_net.net.network.flows.{2 * f}.{net}.net.2.weight"].abs().max()) == 0.0
+        assert float(sd[f"flow_net.net.network.flows.{2 * f + 1}.s"].abs().max()) == 0.0
+    assert torch.equal(sd["linear.weight"], torch.ones(3, 1, 1, 1)) and torch.equal(sd["linear.bias"], torch.zeros(3))
+    assert sd["flow_net.net.network.flows.4.b"].tolist() == [[1, 1, 0]]   # mask value 3
+    with pytest.raises(RuntimeError):   # no CPU path
+        m(torch.zeros(1, 3, 4, 4))
+    m.reset_parameters()                # TensorUtil.reset_parameters: every nn.Linear is re-drawn, ActNorm untouched
+    assert float(m.state_dict()["flow_net.net.network.flows.0.s.net.2.weight"].abs().max()) > 0.0
+
+
+def test_oracle_rnvp_restatement_properties():
+    """The RealNVP restatement has no golden vectors (normflows is absent); these are the properties its definition implies."""
+    torch.manual_seed(0)
+    C, F, hid = 3, 6, 8
+    masks = O.rnvp_masks(C, F)
+    assert masks.tolist() == [[1, 0, 0], [0, 1, 0], [1, 1, 0], [0, 0, 1], [1, 0, 1], [0, 1, 1]]
+    sd = {"linear.weight": torch.ones(C, 1, 1, 1), "linear.bias": torch.zeros(C)}
+    for f in range(F):
+        for n in "st":
+            b = f"flow_net.net.network.flows.{2 * f}.{n}.net."
+            sd[b + "0.weight"], sd[b + "0.bias"] = torch.randn(hid, C), torch.randn(hid)
+            sd[b + "2.weight"], sd[b + "2.bias"] = torch.zeros(C, hid), torch.zeros(C)
+        sd[f"flow_net.net.network.flows.{2 * f + 1}.s"] = torch.zeros(1, C)
+        sd[f"flow_net.net.network.flows.{2 * f + 1}.t"] = torch.zeros(1, C)
+    x = torch.rand(500, C)
+    vmin, vmax = torch.zeros(C), torch.ones(C)
+    # init_zeros: every coupling is the identity, ActNorm s = t = 0: the deformation is the identity
+    np.testing.assert_allclose(O.pcn_deformation(sd, x, masks, vmin, vmax).numpy(), x.numpy(), atol=1e-6)
+    # data-dependent init: the first ActNorm whitens its input, the following ones see whitened data
+    O.pcn_deformation(sd, x, masks, vmin, vmax, actnorm_init=True)
+    z0 = O.minmax(x, vmin, vmax, -1.0, 1.0)
+    np.testing.assert_allclose(sd["flow_net.net.network.flows.1.s"].numpy(), -torch.log(z0.std(0, keepdim=True) + 1e-6).numpy(), rtol=1e-5)
+    assert float(sd["flow_net.net.network.flows.3.s"].abs().max()) < 1e-4
+    # a masked channel passes through its coupling unchanged
+    for n in "st":
+        sd[f"flow_net.net.network.flows.0.{n}.net.2.weight"] = torch.randn(C, hid) * 0.3
+    z = torch.randn(50, C)
+    z1 = O.rnvp_flow_forward(sd, z, masks[:1], actnorm_init=False)
+    ea, at = torch.exp(sd["flow_net.net.network.flows.1.s"]), sd["flow_net.net.network.flows.1.t"]
+    np.testing.assert_allclose(z1[:, 0].numpy(), (z[:, 0] * ea[0, 0] + at[0, 0]).numpy(), rtol=1e-6, atol=1e-6)
+    assert float((z1[:, 1] - (z[:, 1] * ea[0, 1] + at[0, 1])).abs().max()) > 1e-3
