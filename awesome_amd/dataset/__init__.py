@@ -1,2 +1,2 @@
 from .synthetic import (SyntheticSequenceDataset, SyntheticUnariesDataset, convex_blob_mask, convex_blob_unaries,  # noqa: F401
-                        disc_unaries, dumbbell_sequence_masks)
+                        disc_unaries, dumbbell_sequence_masks, noisy_blob_unaries)

@@ -51,6 +51,21 @@ def convex_blob_unaries(size: int = 256, seed: int = 0) -> torch.Tensor:
     return torch.from_numpy(1.0 - convex_blob_mask(size, seed).astype(np.float32))
 
 
+def noisy_blob_unaries(size: int = 256, seed: int = 0, flip_p: float = 0.1, n_squares: int = 3, square: int = 8) -> torch.Tensor:
+    """C5 'UNet-logit refinement' input: the C2 blob as pseudo-labels with every pixel flipped w.p. flip_p plus
+    n_squares random false-positive squares, turned into synthetic segmentation logits `+-2 + N(0,1)` (object positive);
+    unaries = 1 - sigmoid(logit): soft values in (0,1), fg ~ 0 - what a segmentation backbone hands to the prior fit."""
+    rng = np.random.RandomState(10_000 + seed)
+    m = convex_blob_mask(size, seed)
+    lab = m ^ (rng.uniform(size=m.shape) < flip_p)
+    s = max(1, int(round(square * size / 256.0)))
+    for _ in range(n_squares):
+        y, x = rng.randint(0, size - s, 2)
+        lab[y:y + s, x:x + s] = True
+    logit = np.where(lab, 2.0, -2.0) + rng.normal(size=m.shape)
+    return torch.from_numpy((1.0 - 1.0 / (1.0 + np.exp(-logit))).astype(np.float32))
+
+
 def disc_unaries(h: int, w: int, cy: float, cx: float, r: float) -> torch.Tensor:
     """C1 disc: fg = 0 inside the disc, bg = 1."""
     yy, xx = np.mgrid[0:h, 0:w]
@@ -60,7 +75,8 @@ def disc_unaries(h: int, w: int, cy: float, cx: float, r: float) -> torch.Tensor
 
 class SyntheticUnariesDataset:
     """Minimal stand-in for the reference's prior datasets on the hot path: item i is `(grid_desc, unaries_i)` where
-    unaries follow the reference convention (fg = 0).  `kind`: 'disc' (C1) or 'blob' (C2/C3, seed = index + seed0)."""
+    unaries follow the reference convention (fg = 0).  `kind`: 'disc' (C1), 'blob' (C2/C3, seed = index + seed0) or
+    'noisy_blob' (C5: soft unaries from noisy synthetic logits)."""
 
     def __init__(self, n_images: int = 1, size: int = 256, kind: str = "blob", seed0: int = 0, **kwargs):
         self.n_images, self.size, self.kind, self.seed0 = int(n_images), int(size), kind, int(seed0)
@@ -74,7 +90,18 @@ class SyntheticUnariesDataset:
             return disc_unaries(s, s, s / 2, s / 2, 15.0 * s / 64.0)
         if self.kind == "blob":
             return convex_blob_unaries(self.size, self.seed0 + i)
+        if self.kind == "noisy_blob":
+            return noisy_blob_unaries(self.size, self.seed0 + i)
         raise ValueError(f"unknown kind {self.kind}")
+
+    def ground_truth(self, i: int) -> torch.Tensor:
+        """Clean unaries (fg = 0) of item i - what a refinement is scored against."""
+        if self.kind == "noisy_blob":
+            return convex_blob_unaries(self.size, self.seed0 + i)
+        return (self.unaries(i) > 0.5).float()
+
+    def ground_truth_batch(self, indices) -> torch.Tensor:
+        return torch.stack([self.ground_truth(int(i)).reshape(-1) for i in indices])
 
     def __getitem__(self, i: int):
         return (self.size, self.size), self.unaries(i)

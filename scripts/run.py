@@ -146,11 +146,14 @@ def main(cfg):
             bad = [i for i in range(len(mine)) if float(iou[i]) < thr]
             if not bad:
                 break
-            model.reset_parameters()
+            # the reference calls self.reset_parameters() here (path_connected_net.py:978), which re-draws the zero-initialised
+            # output layers of a RealNVP flow and keeps its ActNorm statistics; a freshly built model is the same retry with a
+            # well-defined start (identity deformation)
+            model = model_type(**model_args).to(device)
             sub = model.fit_images(grid, unaries[bad].contiguous(), **kw)
             sub_iou = A.miou(torch.sigmoid(sub.logits), unaries[bad].contiguous())
             for n, i in enumerate(bad):
-                res.icnn_params[i], res.flow_params[i] = sub.icnn_params[n], sub.flow_params[n]
+                res.icnn_params[i], res.flow_params[i], res.logits[i] = sub.icnn_params[n], sub.flow_params[n], sub.logits[n]
                 iou[i] = sub_iou[n]
                 retries[i] += 1
 
@@ -168,6 +171,13 @@ def main(cfg):
     torch.cuda.synchronize()
     dt = parallel.max_over_ranks(time.perf_counter() - t0, device)
     iou_all = parallel.gather_per_image(iou, len(dataset), rank, world)
+    gt_all = None
+    if hasattr(dataset, "ground_truth_batch"):   # refinement configs: score the fitted prior against the clean mask too
+        logits = rep.logits if not flow_prior else res.logits
+        if logits is not None:
+            gt = dataset.ground_truth_batch(mine).to(device)
+            gt_all = parallel.gather_per_image(A.miou(torch.sigmoid(logits), gt), len(dataset), rank, world)
+            noisy_all = parallel.gather_per_image(A.miou(unaries, gt), len(dataset), rank, world)
     if rank == 0:
         out_dir = os.path.join(cfg.get("output_folder", "runs"), cfg.get("name_experiment", "inr_fit"))
         os.makedirs(out_dir, exist_ok=True)
@@ -175,6 +185,9 @@ def main(cfg):
         summary = {"images": len(dataset), "ranks": world, "epochs": num_epochs, "seconds": round(dt, 4),
                    "fits_per_s": round(len(dataset) / dt, 4), "ForegroundBinaryMIOU_vs_unaries": round(float(iou_all.mean()), 5),
                    "retries": retries, "output": out_dir}
+        if gt_all is not None:
+            summary["ForegroundBinaryMIOU_vs_ground_truth"] = round(float(gt_all.mean()), 5)
+            summary["input_labels_MIOU_vs_ground_truth"] = round(float(noisy_all.mean()), 5)
         with open(os.path.join(out_dir, "summary.json"), "w") as f:
             json.dump(summary, f, indent=1)
         print(json.dumps(summary))
