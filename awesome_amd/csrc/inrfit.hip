@@ -895,7 +895,8 @@ namespace {
 
 struct PcnWs {
     Workspace icnn;
-    float *xd, *dxd, *zs, *ps, *slab1, *slab2, *RE;
+    float *xd, *dxd, *zs, *ps, *slab1, *slab2, *RE, *lossp;
+    int blocksL;
     int blocks1, chunks, S1, Q;   // Q = points per lane of the point kernels
     RnvpMap rm;
     long long bytes;
@@ -959,6 +960,8 @@ PcnWs carve_pcn(const KernelEntry* e, const InrRnvpDesc* r, const InrGridDesc* g
     w.slab1 = take((long long)n_images * w.blocks1 * w.S1 * 4);
     w.slab2 = take((long long)n_images * w.chunks * F * 2 * (2 * C + 1) * 64 * 4);
     w.RE = take((long long)n_images * w.rm.LDSF * 4);
+    w.blocksL = (int)((N + 255) / 256);
+    w.lossp = take((long long)n_images * w.blocksL * 4);
     w.dgrid = *grid;
     w.dgrid.mode = INR_GRID_EXPLICIT;
     w.dgrid.coords = w.xd;
@@ -1000,18 +1003,20 @@ int check_pcn(const InrModelDesc* model, const InrRnvpDesc* r, const InrGridDesc
 }
 
 // parameters -> packed image; once per parameter set, in front of the forward
-void launch_rnvp_pack(const PcnWs& w, const float* rp, int n_images, hipStream_t s) {
+void launch_rnvp_pack(const PcnWs& w, const float* rp, int n_images, hipStream_t s, bool unit_linear = false) {
     RnvpPackArgs a{};
     a.RP = rp;
     a.RE = w.RE;
     a.m = w.rm;
+    a.unit_linear = unit_linear ? 1 : 0;
     const dim3 g(w.rm.F, n_images);
     if (w.rm.C == 2) hipLaunchKernelGGL(rnvp_pack_kernel<2>, g, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(rnvp_pack_kernel<3>, g, dim3(256), 0, s, a);
 }
 
-void launch_rnvp_fwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, int n_images, float* out, bool keep, hipStream_t s) {
-    launch_rnvp_pack(w, rp, n_images, s);
+void launch_rnvp_fwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, int n_images, float* out, bool keep, hipStream_t s,
+                     bool unit_linear = false) {
+    launch_rnvp_pack(w, rp, n_images, s, unit_linear);
     RnvpFwdArgs a{};
     a.RE = w.RE;
     a.xd = out;
@@ -1068,8 +1073,8 @@ void launch_rnvp_bwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, i
     }
 }
 
-void launch_rnvp_update(const PcnWs& w, int n_images, int mode, float* rp, float* opt, float* grads_out, const InrOptDesc* od,
-                        float wd_flow, int t, const float* lr_hdr, long long hdr_stride, const int32_t* status, hipStream_t s) {
+RnvpUpdArgs make_rnvp_upd_args(const PcnWs& w, int n_images, int mode, float* rp, float* opt, float* grads_out, const InrOptDesc* od,
+                               float wd_flow, int t, const float* lr_hdr, long long hdr_stride, const int32_t* status) {
     RnvpUpdArgs u{};
     u.RP = rp;
     u.opt = opt;
@@ -1093,9 +1098,19 @@ void launch_rnvp_update(const PcnWs& w, int n_images, int mode, float* rp, float
     }
     u.wd_flow = wd_flow;
     u.mode = mode;
+    return u;
+}
+
+void launch_rnvp_update_args(const PcnWs& w, int n_images, const RnvpUpdArgs& u, hipStream_t s) {
     const dim3 g(w.rm.F + 1, n_images);
     if (w.rm.C == 2) hipLaunchKernelGGL(rnvp_update_kernel<2>, g, dim3(256), 0, s, u);
     else hipLaunchKernelGGL(rnvp_update_kernel<3>, g, dim3(256), 0, s, u);
+}
+
+void launch_rnvp_update(const PcnWs& w, int n_images, int mode, float* rp, float* opt, float* grads_out, const InrOptDesc* od,
+                        float wd_flow, int t, const float* lr_hdr, long long hdr_stride, const int32_t* status, hipStream_t s) {
+    launch_rnvp_update_args(w, n_images, make_rnvp_upd_args(w, n_images, mode, rp, opt, grads_out, od, wd_flow, t, lr_hdr,
+                                                             hdr_stride, status), s);
 }
 
 }  // namespace
@@ -1141,6 +1156,43 @@ int inrfit_rnvp_forward(const InrRnvpDesc* rnvp, const float* flow_params, const
     int rc = check_pcn(nullptr, rnvp, grid, n_images, workspace, workspace_bytes, false, &e, &w);
     if (rc) return rc;
     launch_rnvp_fwd(w, flow_params, grid, n_images, out_coords, false, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
+}
+
+int inrfit_rnvp_fit_identity(const InrRnvpDesc* rnvp, float* flow_params, float* flow_opt_state, const InrGridDesc* grid,
+                             const InrOptDesc* opt, int n_images, int steps, int step0, float* loss_hist, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+    const KernelEntry* e;
+    PcnWs w;
+    if (!flow_params || !flow_opt_state || !opt || steps < 0 || step0 < 0) return INR_EINVAL;
+    if (opt->kind != INR_OPT_ADAM && opt->kind != INR_OPT_ADAMAX) return INR_EINVAL;
+    int rc = check_pcn(nullptr, rnvp, grid, n_images, workspace, workspace_bytes, false, &e, &w);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int C = w.rm.C;
+    RnvpIdArgs ia{};
+    ia.xd = w.xd;
+    ia.dxd = w.dxd;
+    ia.lossp = w.lossp;
+    ia.grid = *grid;
+    ia.N = grid->n_points;
+    const dim3 gl(w.blocksL, n_images);
+    for (int it = 0; it < steps; ++it) {
+        launch_rnvp_fwd(w, flow_params, grid, n_images, w.xd, true, s, true);
+        if (C == 2) hipLaunchKernelGGL(rnvp_identity_loss_kernel<2>, gl, dim3(256), 0, s, ia);
+        else hipLaunchKernelGGL(rnvp_identity_loss_kernel<3>, gl, dim3(256), 0, s, ia);
+        launch_rnvp_bwd(w, flow_params, grid, n_images, s);
+        RnvpUpdArgs u = make_rnvp_upd_args(w, n_images, 0, flow_params, flow_opt_state, nullptr, opt, opt->weight_decay,
+                                           step0 + it + 1, nullptr, 0, nullptr);
+        u.skip_linear = 1;
+        u.lossp = w.lossp;
+        u.lossp_blocks = w.blocksL;
+        u.loss_scale = 1.f / ((float)C * (float)grid->n_points);
+        u.loss_hist = loss_hist;
+        u.hist_idx = it;
+        u.hist_stride = steps;
+        launch_rnvp_update_args(w, n_images, u, s);
+    }
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 

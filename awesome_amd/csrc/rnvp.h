@@ -132,6 +132,7 @@ struct RnvpPackArgs {
     const float* RP;
     float* RE;   // [n_images][LDSF]
     RnvpMap m;
+    int unit_linear;   // 1: a = 1, b = 0 (flow_net alone, learn_flow_identity)
 };
 
 template <int C>
@@ -139,7 +140,10 @@ __global__ __launch_bounds__(256) void rnvp_pack_kernel(const RnvpPackArgs a) {
     const int img = blockIdx.y, f = blockIdx.x;
     const float* __restrict__ rp = a.RP + (size_t)img * a.m.RP;
     float* dst = a.RE + (size_t)img * a.m.LDSF;
-    if (f == 0) rnvp_header_image<C>(rp, dst);
+    if (f == 0) {
+        rnvp_header_image<C>(rp, dst);
+        if (a.unit_linear && threadIdx.x < 6) dst[threadIdx.x] = threadIdx.x < 3 ? (threadIdx.x < C ? 1.f : 0.f) : 0.f;   // same threads wrote it
+    }
     rnvp_flow_image<C>(rp, dst + RNVP_HDR + f * a.m.fl, a.m, f);
 }
 
@@ -639,6 +643,36 @@ __global__ __launch_bounds__(256) void rnvp_bwd_units_kernel(const RnvpUnitsArgs
     else rnvp_units_body<C, C == 2 ? 1 : 2, 1, UPW>(a, x, rsm);
 }
 
+// ---- learn_flow_identity: SE('mean')(flow_net(x), x)  (path_connected_net.py:155-250) -------------------------------------
+struct RnvpIdArgs {
+    const float* xd;   // [n_images][C][N] flow output
+    float* dxd;        // [n_images][C][N] d loss / d xd = 2 (xd - x) / (C N)
+    float* lossp;      // [n_images][blocks] partial sums of (xd - x)^2
+    InrGridDesc grid;
+    long long N;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void rnvp_identity_loss_kernel(const RnvpIdArgs a) {
+    __shared__ float sm[4];
+    const int img = blockIdx.y, N = (int)a.N;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = p < N;
+    float x[C];
+    load_coords<C>(a.grid, img, a.N, valid ? p : N - 1, x);
+    const float sc = 2.f / ((float)C * (float)N);
+    float part = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const size_t o = ((size_t)img * C + c) * N + (valid ? p : 0);
+        const float d = valid ? a.xd[o] - x[c] : 0.f;
+        if (valid) a.dxd[o] = sc * d;
+        part = fmaf(d, d, part);
+    }
+    const float t = block_sum256(part, sm);
+    if (threadIdx.x == 0) a.lossp[(size_t)img * gridDim.x + blockIdx.x] = t;
+}
+
 // ---- reduction + optimizer --------------------------------------------------------------------------------------------------
 struct RnvpUpdArgs {
     float* RP;            // [n_images][RP] (in/out)
@@ -657,6 +691,13 @@ struct RnvpUpdArgs {
     float bc2_sqrt, one_minus_b1, one_minus_b2;
     float wd_flow;        // weight decay of the flow_net group (path_connected_net.py:925); the linear has none
     int mode;             // 0 = optimizer step, 1 = gradients only
+    // learn_flow_identity: the 1x1 linear is not part of the model; the loss comes as per-block partial sums
+    int skip_linear;
+    const float* lossp;
+    int lossp_blocks;
+    float loss_scale;
+    float* loss_hist;     // [n_images][hist_stride] or null
+    int hist_idx, hist_stride;
 };
 
 __device__ __forceinline__ float opt_apply(const RnvpUpdArgs& u, float p, float g, float lr, float wd, float* m_, float* v_) {
@@ -700,6 +741,13 @@ __global__ __launch_bounds__(256) void rnvp_update_kernel(const RnvpUpdArgs u) {
         if (tid == 0) tot[k] = t;
     }
     __syncthreads();
+    if (f == F && u.lossp != nullptr) {
+        float part = 0.f;
+        for (int b = tid; b < u.lossp_blocks; b += 256) part += u.lossp[(size_t)img * u.lossp_blocks + b];
+        const float t = block_sum256(part, sm);
+        if (tid == 0 && u.loss_hist) u.loss_hist[(size_t)img * u.hist_stride + u.hist_idx] = t * u.loss_scale;
+    }
+    if (f == F && u.skip_linear) return;
     const int base = f < F ? 2 * C + f * m.pf : 0;
     const int count = f < F ? m.pf : 2 * C;
     for (int i = tid; i < count; i += 256) {

@@ -270,25 +270,72 @@ class PathConnectedNet(nn.Module):
             return torch.stack([o.reshape(-1, h, w) for o in outs], 0)
         return outs[0].t()
 
+    @staticmethod
+    def _first_image_coords(grid: "K.Grid") -> torch.Tensor:
+        if grid.coords is not None:
+            return grid.coords if grid.coords.dim() == 2 else grid.coords[0]
+        xs, ys = grid.xs, grid.ys
+        chans = [xs[None, :].expand(ys.numel(), -1).reshape(-1), ys[:, None].expand(-1, xs.numel()).reshape(-1)]
+        if grid.ts is not None:
+            chans.append(grid.ts[0].expand(chans[0].numel()))
+        return torch.stack(chans, 0)
+
+    def learn_flow_identity(self, grid: "K.Grid", lr: float = 1e-2, weight_decay: float = 1e-5, max_iter: int = 1000) -> torch.Tensor:
+        """path_connected_net.py:155-250 on the HIP path: Adamax on the flow_net alone towards flow_net(x) = x; updates this
+        module's flow parameters in place and returns the loss history."""
+        self._actnorm_init_if_needed(self._first_image_coords(grid))
+        _, rspec, _, flow = self._ordered_params()
+        fp = self._flat(flow)
+        hist, _ = R.fit_identity(rspec, fp, grid, steps=max_iter, lr=lr, weight_decay=weight_decay)
+        new = R.unpack_rnvp_params(rspec, fp[0])
+        own = dict(self.named_parameters())
+        with torch.no_grad():
+            for k, v in new.items():
+                if not k.startswith("linear."):
+                    own[k].copy_(v.to(own[k].device))
+        return hist[0]
+
+    def learn_convex_net(self, grid: "K.Grid", unaries: torch.Tensor, lr: float = 1e-3, weight_decay: float = 0.0,
+                         max_iter: int = 1000, icnn_params: Optional[torch.Tensor] = None):
+        """path_connected_net.py:307-390 (mode 'unaries', use_deformed_grid): Adam on the convex_net alone on the grid deformed by
+        the current flow, SE('mean') on sigmoid(logits) vs. unaries [n_images, N], clamp after every step.  Returns the FitResult
+        (flat ICNN parameters per image; with one image they are also written back into the module)."""
+        self._actnorm_init_if_needed(self._first_image_coords(grid))
+        ispec, rspec, icnn, flow = self._ordered_params()
+        n, dev = unaries.shape[0], unaries.device
+        xd = R.rnvp_forward(rspec, self._flat(flow).to(dev), grid)[0]
+        ip = icnn_params if icnn_params is not None else self._flat(icnn).repeat(n, 1).contiguous().to(dev)
+        res = K.fit(ispec, ip, K.Grid.explicit(xd), unaries, max_iter, lr=lr, loss="se", optimizer="adam", weight_decay=weight_decay,
+                    plateau=None, want_logits=False)
+        if n == 1 and icnn_params is None:
+            own = dict(self.named_parameters())
+            with torch.no_grad():
+                for k, v in K.unpack_params(ispec, res.params[0]).items():
+                    own["convex_net." + k].copy_(v.to(own["convex_net." + k].device))
+        return res
+
     def fit_images(self, grid: "K.Grid", unaries: torch.Tensor, num_epochs: int = 2000, lr: float = 1e-3,
                    flow_weight_decay: float = 1e-5, loss: str = "se", weight_mode: str = "none", optimizer: str = "adamax",
-                   plateau=None):
-        """Fused device-resident form of _prior_based_pretrain's inner loop (path_connected_net.py:922-962) for a batch of
-        images: every image starts from this module's current parameters (ActNorm initialised on the first image's grid if it
-        is not yet); returns the PcnFitResult (flat parameters per image)."""
+                   plateau=None, prefit_flow_net_identity: bool = False, prefit_flow_net_identity_lr: float = 1e-2,
+                   prefit_flow_net_identity_weight_decay: float = 1e-5, prefit_flow_net_identity_num_epochs: int = 100,
+                   prefit_convex_net: bool = False, prefit_convex_net_lr: float = 1e-3, prefit_convex_net_weight_decay: float = 0.0,
+                   prefit_convex_net_num_epochs: int = 200):
+        """Fused device-resident form of _prior_based_pretrain (path_connected_net.py:871-962) for a batch of images: the
+        optional pre-fit stages (flow towards the identity - it only depends on the grid, so it runs once on this module -
+        then the convex net of every image on the deformed grid), then the joint inner loop.  Every image starts from this
+        module's current parameters (ActNorm initialised on the first image's grid if it is not yet); returns the PcnFitResult
+        (flat parameters per image)."""
         n, dev = unaries.shape[0], unaries.device
-        if grid.coords is not None:
-            c0 = grid.coords if grid.coords.dim() == 2 else grid.coords[0]
-        else:
-            xs, ys = grid.xs, grid.ys
-            chans = [xs[None, :].expand(ys.numel(), -1).reshape(-1), ys[:, None].expand(-1, xs.numel()).reshape(-1)]
-            if grid.ts is not None:
-                chans.append(grid.ts[0].expand(chans[0].numel()))
-            c0 = torch.stack(chans, 0)
-        self._actnorm_init_if_needed(c0)
+        self._actnorm_init_if_needed(self._first_image_coords(grid))
+        if prefit_flow_net_identity:
+            self.learn_flow_identity(grid, lr=prefit_flow_net_identity_lr, weight_decay=prefit_flow_net_identity_weight_decay,
+                                     max_iter=prefit_flow_net_identity_num_epochs)
         ispec, rspec, icnn, flow = self._ordered_params()
         ip = self._flat(icnn).repeat(n, 1).contiguous().to(dev)
         fp = self._flat(flow).repeat(n, 1).contiguous().to(dev)
+        if prefit_convex_net:
+            ip = self.learn_convex_net(grid, unaries, lr=prefit_convex_net_lr, weight_decay=prefit_convex_net_weight_decay,
+                                       max_iter=prefit_convex_net_num_epochs, icnn_params=ip).params
         return R.pcn_fit(ispec, rspec, ip, fp, grid, unaries, num_epochs, lr=lr, optimizer=optimizer, loss=loss,
                          weight_mode=weight_mode, flow_weight_decay=flow_weight_decay,
                          plateau=dict(patience=200, factor=0.5) if plateau is None else (plateau or None))

@@ -166,6 +166,27 @@ def rnvp_forward(rspec: RnvpSpec, flow_params: Tensor, grid: K.Grid) -> Tensor:
     return out
 
 
+def fit_identity(rspec: RnvpSpec, flow_params: Tensor, grid: K.Grid, steps: int = 100, lr: float = 1e-2, weight_decay: float = 1e-5,
+                 optimizer: str = "adamax", betas=(0.9, 0.999), eps: float = 1e-8, flow_opt_state: Optional[Tensor] = None,
+                 step0: int = 0) -> Tuple[Tensor, Tensor]:
+    """PathConnectedNet.learn_flow_identity (path_connected_net.py:155-250; defaults of the prefit kwargs :771-774): the flow_net
+    alone is trained towards the identity on the grid, in place on flow_params [n_images, RP].  Returns (loss_hist, opt_state)."""
+    fp = K._check_dev(flow_params, "flow_params")
+    n, dev = fp.shape[0], fp.device
+    if flow_opt_state is None:
+        flow_opt_state = torch.zeros(n, 2 * rspec.n_params, dtype=torch.float32, device=dev)
+    hist = torch.empty(n, max(steps, 1), dtype=torch.float32, device=dev)
+    od = L.InrOptDesc(L.OPT_KINDS[optimizer], float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), 0, 0,
+                      0, 0.0, 0.0, 0.0, 0.0)
+    ws = _ws(None, rspec, grid, n)
+    rd, gd = rspec.desc(), grid.desc()
+    rc = L.load().inrfit_rnvp_fit_identity(C.byref(rd), fp.data_ptr(), flow_opt_state.data_ptr(), C.byref(gd), C.byref(od), n,
+                                           int(steps), int(step0), hist.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                                           K._stream_ptr(dev))
+    L.check(rc, "inrfit_rnvp_fit_identity")
+    return hist[:, :steps], flow_opt_state
+
+
 def pcn_forward(ispec: K.IcnnSpec, rspec: RnvpSpec, icnn_params: Tensor, flow_params: Tensor, grid: K.Grid) -> Tensor:
     ip, fp = K._check_dev(icnn_params, "icnn_params"), K._check_dev(flow_params, "flow_params")
     n = ip.shape[0]

@@ -225,6 +225,12 @@ int inrfit_rnvp_actnorm_init(const InrRnvpDesc* rnvp, float* flow_params, const 
 /* out_coords[n_images][C][n_points]: PathConnectedNet.get_deformation (path_connected_net.py:124-128). */
 int inrfit_rnvp_forward(const InrRnvpDesc* rnvp, const float* flow_params, const InrGridDesc* grid, int n_images,
                         float* out_coords, void* workspace, int64_t workspace_bytes, void* stream);
+/* `steps` steps of PathConnectedNet.learn_flow_identity (path_connected_net.py:155-250): Adamax/Adam on the flow_net parameters
+ * only (weight decay opt->weight_decay, constant lr; the 1x1 linear is not part of this model) for the loss
+ * SE('mean')(flow_net(x), x) on the grid x.  loss_hist (optional) [n_images][steps]. */
+int inrfit_rnvp_fit_identity(const InrRnvpDesc* rnvp, float* flow_params, float* flow_opt_state, const InrGridDesc* grid,
+                             const InrOptDesc* opt, int n_images, int steps, int step0, float* loss_hist, void* workspace,
+                             int64_t workspace_bytes, void* stream);
 /* logits[n_images][n_points]: PathConnectedNet.forward (:79-85). */
 int inrfit_pcn_forward(const InrModelDesc* model, const InrRnvpDesc* rnvp, const float* icnn_params, const float* flow_params,
                        const InrGridDesc* grid, int n_images, float* logits, void* workspace, int64_t workspace_bytes,

@@ -532,3 +532,27 @@ def fit_pcn(sd0: Dict[str, Tensor], rows: Tensor, unaries_rows: Tensor, steps: i
     with torch.no_grad():
         logits = pcn_forward(p, rows, masks, vmin, vmax, **kw)
     return {k: v.detach() for k, v in p.items()}, losses, logits
+
+
+def fit_flow_identity(sd0: Dict[str, Tensor], rows: Tensor, steps: int, masks: Tensor, vmin: Tensor, vmax: Tensor, lr: float = 1e-2,
+                      weight_decay: float = 1e-5, optimizer: str = "adamax", new_min: float = -1.0, new_max: float = 1.0, **kw
+                      ) -> Tuple[Dict[str, Tensor], List[float]]:
+    """PathConnectedNet.learn_flow_identity (path_connected_net.py:155-250): Adamax(flow_net.parameters(), lr, weight_decay) on
+    SE('mean')(flow_net(x), x); flow_net = NormNet (MinMax, flow, MinMax^-1) WITHOUT the 1x1 linear.  rows (N, C)."""
+    p = {k: v.detach().clone().requires_grad_(k.startswith("flow_net.")) for k, v in sd0.items()}
+    keys = [k for k in p if k.startswith("flow_net.")]
+    sub = {k: p[k] for k in keys}
+    st = AdamState(sub)
+    step_fn = adamax_step if optimizer == "adamax" else adam_step
+    losses: List[float] = []
+    for _ in range(steps):
+        for k in keys:
+            p[k].grad = None
+        z = minmax(rows, vmin.view(1, -1), vmax.view(1, -1), new_min, new_max)
+        z = rnvp_flow_forward(p, z, masks, **kw)
+        y = minmax(z, new_min, new_max, vmin.view(1, -1), vmax.view(1, -1))
+        loss = ((rows - y) ** 2).mean()
+        loss.backward()
+        step_fn(sub, {k: p[k].grad for k in keys}, st, lr, weight_decay=weight_decay)
+        losses.append(float(loss.item()))
+    return {k: v.detach() for k, v in p.items()}, losses

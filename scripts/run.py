@@ -138,6 +138,7 @@ def main(cfg):
         kw = dict(num_epochs=num_epochs, lr=lr, loss=kind)
         if hasattr(probe, "flow_net"):
             kw.update(weight_mode=wmode, flow_weight_decay=float(pre.get("flow_weight_decay", 1e-5)), optimizer=opt_type)
+            kw.update({k: v for k, v in pre.items() if k.startswith("prefit_")})   # the reference's pre-fit stage kwargs
         model = probe.to(device)
         res = model.fit_images(grid, unaries, **kw)
         iou = A.miou(torch.sigmoid(res.logits), unaries)

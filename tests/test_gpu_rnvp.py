@@ -293,3 +293,46 @@ def test_large_grid_two_points_per_lane(dev, C):
     for k in sdo:
         ref = sdo[k].grad.numpy()
         np.testing.assert_allclose(got[k].numpy(), ref, rtol=2e-3, atol=1e-4 * float(np.abs(ref).max()) + 1e-8, err_msg=k)
+
+
+@pytest.mark.parametrize("C", [2, 3])
+def test_learn_flow_identity(dev, C):
+    """inrfit_rnvp_fit_identity vs the oracle's learn_flow_identity loop (Adamax on the flow_net alone, weight decay; the
+    trained 1x1 linear must be ignored)."""
+    from awesome_amd import rnvp as R
+    import awesome_amd as A
+    F = 12 if C == 2 else 6
+    ispec, rspec, sd = _case(C, 32, F, 1, seed=31 + C)
+    H, W = 16, 24
+    grid_t, rows = _rows(C, H, W, 0.6)
+    masks = O.rnvp_masks(C, F)
+    steps = 12
+    pf, losses = O.fit_flow_identity(sd, rows, steps, masks, torch.tensor(rspec.vmin), torch.tensor(rspec.vmax), lr=1e-2, weight_decay=1e-3)
+    _, fp = _split(ispec, rspec, sd, dev)
+    hist, _ = R.fit_identity(rspec, fp, A.Grid.from_image_grid(grid_t.to(dev)), steps=steps, lr=1e-2, weight_decay=1e-3)
+    np.testing.assert_allclose(hist[0].cpu().numpy(), np.asarray(losses, np.float32), rtol=5e-4)
+    got = R.unpack_rnvp_params(rspec, fp[0].cpu())
+    for k in got:
+        np.testing.assert_allclose(got[k].numpy(), pf[k].numpy(), rtol=5e-3, atol=3e-4, err_msg=k)
+    assert torch.equal(got["linear.weight"], sd["linear.weight"]) and torch.equal(got["linear.bias"], sd["linear.bias"])
+
+
+def test_prefit_stages_through_the_module(dev):
+    """fit_images with the reference's prefit kwargs (prefit_flow_net_identity, prefit_convex_net): after the identity stage the
+    deformation is close to the identity, and the whole pipeline fits the two-disc shape."""
+    import awesome_amd as A
+    from awesome_amd.model import real_nvp_path_connected_net
+    torch.manual_seed(0)
+    S = 64
+    yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+    mask = (((yy - 20) ** 2 + (xx - 18) ** 2) < 100) | (((yy - 44) ** 2 + (xx - 46) ** 2) < 100) | \
+           (((yy - 20).abs() < 4) & (xx >= 18) & (xx <= 46)) | (((xx - 46).abs() < 4) & (yy >= 20) & (yy <= 44))
+    un = (1.0 - mask.float()).reshape(1, -1).to(dev)
+    grid = A.Grid.linspace(S, S, dev)
+    m = real_nvp_path_connected_net(channels=2, hidden_units=32, flow_n_flows=12, flow_output_fn="tanh").to(dev)
+    g = O.positional_grid(S, S)[None].to(dev)
+    hist = m.learn_flow_identity(grid, lr=1e-2, weight_decay=1e-5, max_iter=100)
+    assert float(hist[-1]) < 0.05 * float(hist[0])
+    assert float((m.get_deformation(g) - g).abs().max()) < 0.1
+    res = m.fit_images(grid, un, num_epochs=1200, lr=2e-3, prefit_flow_net_identity=True, prefit_convex_net=True)
+    assert float(A.miou(torch.sigmoid(res.logits), un)[0]) > 0.9
