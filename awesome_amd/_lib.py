@@ -94,6 +94,9 @@ EXPORTS = {
                                            C.c_int64, C.c_void_p]),
     "inrfit_rnvp_forward": (C.c_int, [C.POINTER(InrRnvpDesc), C.c_void_p, C.POINTER(InrGridDesc), C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_rnvp_inverse": (C.c_int, [C.POINTER(InrRnvpDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_pack_masks": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "inrfit_rnvp_fit_identity": (C.c_int, [C.POINTER(InrRnvpDesc), C.c_void_p, C.c_void_p, C.POINTER(InrGridDesc),
                                            C.POINTER(InrOptDesc), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                            C.c_void_p]),

@@ -239,6 +239,21 @@ __global__ __launch_bounds__(256) void opt_init_kernel(float* opt_state, int P, 
     }
 }
 
+// (value > threshold) (or its complement) as one bit per point, 64 points per word, LSB = lowest index: the PNG-ready mask
+__global__ __launch_bounds__(256) void pack_masks_kernel(const float* __restrict__ values, long long N, float thr, int invert,
+                                                         unsigned long long* __restrict__ bits) {
+    const int img = blockIdx.y;
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    bool b = false;
+    if (p < N) {
+        b = values[(size_t)img * N + p] > thr;
+        if (invert) b = !b;
+    }
+    const unsigned long long m = __ballot(b);
+    const long long words = (N + 63) / 64;
+    if ((threadIdx.x & 63) == 0 && p < N) bits[(size_t)img * words + (p >> 6)] = m;
+}
+
 __global__ __launch_bounds__(256) void miou_kernel(const float* __restrict__ out, const float* __restrict__ tgt, long long N,
                                                    float thr_out, float thr_tgt, int invert, float* __restrict__ iou) {
     const int img = blockIdx.x;
@@ -1159,6 +1174,34 @@ int inrfit_rnvp_forward(const InrRnvpDesc* rnvp, const float* flow_params, const
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 
+int inrfit_rnvp_inverse(const InrRnvpDesc* rnvp, const float* flow_params, const float* in_coords, int64_t in_image_stride,
+                        int64_t n_points, int n_images, float* out_coords, void* workspace, int64_t workspace_bytes, void* stream) {
+    const KernelEntry* e;
+    PcnWs w;
+    if (!flow_params || !in_coords || !out_coords || n_points <= 0) return INR_EINVAL;
+    InrGridDesc g{};
+    g.mode = INR_GRID_EXPLICIT;
+    g.n_points = n_points;
+    g.coords = in_coords;
+    g.coords_image_stride = in_image_stride;
+    int rc = check_pcn(nullptr, rnvp, &g, n_images, workspace, workspace_bytes, false, &e, &w);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    launch_rnvp_pack(w, flow_params, n_images, s);
+    RnvpInvArgs a{};
+    a.RE = w.RE;
+    a.in = in_coords;
+    a.out = out_coords;
+    a.N = n_points;
+    a.in_image_stride = in_image_stride;
+    a.m = w.rm;
+    const dim3 gr((unsigned)((n_points + 255) / 256), n_images);
+    const size_t lds = (size_t)w.rm.LDSF * sizeof(float);
+    if (w.rm.C == 2) hipLaunchKernelGGL(rnvp_inverse_kernel<2>, gr, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(rnvp_inverse_kernel<3>, gr, dim3(256), lds, s, a);
+    return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
+}
+
 int inrfit_rnvp_fit_identity(const InrRnvpDesc* rnvp, float* flow_params, float* flow_opt_state, const InrGridDesc* grid,
                              const InrOptDesc* opt, int n_images, int steps, int step0, float* loss_hist, void* workspace,
                              int64_t workspace_bytes, void* stream) {
@@ -1279,6 +1322,15 @@ int inrfit_miou(const float* out, const float* tgt, int n_images, int64_t n_poin
     if (!out || !tgt || !iou || n_images <= 0 || n_points <= 0) return INR_EINVAL;
     hipLaunchKernelGGL(miou_kernel, dim3(n_images), dim3(256), 0, (hipStream_t)stream, out, tgt, (long long)n_points, thr_out,
                        thr_tgt, invert, iou);
+    return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
+}
+
+int inrfit_pack_masks(const float* values, int n_images, int64_t n_points, float threshold, int invert, uint64_t* bits,
+                      void* stream) {
+    if (!values || !bits || n_images <= 0 || n_points <= 0) return INR_EINVAL;
+    const long long words = (n_points + 63) / 64;
+    hipLaunchKernelGGL(pack_masks_kernel, dim3((unsigned)((words + 3) / 4), n_images), dim3(256), 0, (hipStream_t)stream, values,
+                       (long long)n_points, threshold, invert, (unsigned long long*)bits);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 

@@ -328,6 +328,62 @@ __global__ __launch_bounds__(256) void rnvp_fwd_kernel(const RnvpFwdArgs a) {
         }
 }
 
+// ---- inverse: PathConnectedNet.inverse (path_connected_net.py:107-122): NormNet.inverse (MinMax, flows reversed, MinMax^-1),
+// then the inverse of the 1x1 linear.  MaskedAffineFlow.inverse: z = zm + (1 - b)(z - t(zm)) exp(-s(zm)); ActNorm.inverse:
+// z = (z - t) exp(-s) -----------------------------------------------------------------------------------------------------
+struct RnvpInvArgs {
+    const float* RE;    // packed image
+    const float* in;    // [n_images][C][N] deformed coordinates
+    float* out;         // [n_images][C][N]
+    long long N;
+    long long in_image_stride;   // 0 = one input shared by all images
+    RnvpMap m;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void rnvp_inverse_kernel(const RnvpInvArgs a) {
+    const int img = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int N = (int)a.N;
+    extern __shared__ __attribute__((aligned(16))) float rsm[];
+    flow_weights_to_lds(a.RE + (size_t)img * a.m.LDSF, rsm, a.m.LDSF);
+    const int pc = p < N ? p : N - 1;
+    float z[1][C];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+        z[0][c] = minmax_fwd(a.in[(size_t)img * a.in_image_stride + (size_t)c * N + pc], a.m.vmin[c], a.m.vmax[c], a.m.nmin, a.m.nmax);
+    for (int f = a.m.F - 1; f >= 0; --f) {
+        const float* rec = rsm + RNVP_HDR + f * a.m.fl;
+        const float* tl = rec + a.m.HID * RNVP_REC;
+        const FlowIdx x = flow_idx<C>(a.m.masks[f]);
+#pragma unroll
+        for (int c = 0; c < C; ++c) z[0][c] = (z[0][c] - tl[7 + c]) / tl[4 + c];   // ActNorm^-1
+        f32x2 o[1][2], J[1][2][2];
+        rnvp_nets_any<C, false, 1>(rec, a.m.HID, x, z, o, J);   // the masked channels are unchanged by the coupling
+#pragma unroll
+        for (int k = 0; k < C - 1; ++k) {
+            if (k < x.nout) {
+                float s = o[0][k][0], t = o[0][k][1];
+                if (a.m.out_fn) {
+                    s = tanhf(s) * a.m.out_scale;
+                    t = tanhf(t) * a.m.out_scale;
+                }
+                const float e = expf(-s);
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (c == x.out(k)) z[0][c] = (z[0][c] - t) * e;
+            }
+        }
+    }
+    if (p < N) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float v = minmax_fwd(z[0][c], a.m.nmin, a.m.nmax, a.m.vmin[c], a.m.vmax[c]);
+            a.out[((size_t)img * C + c) * N + p] = (1.f / rsm[c]) * (v - rsm[3 + c]);   // inverse_1b1_linear (:87-104)
+        }
+    }
+}
+
 // ---- backward, lane = point ----------------------------------------------------------------------------------------------
 struct RnvpBwdArgs {
     const float* RE;

@@ -327,3 +327,17 @@ def miou(out: Tensor, tgt: Tensor, thr_out: float = 0.5, thr_tgt: float = 0.5, i
                               int(bool(invert)), res.data_ptr(), _stream_ptr(out.device))
     L.check(rc, "inrfit_miou")
     return res
+
+
+def pack_masks(values: Tensor, threshold: float = 0.5, invert: bool = False) -> Tensor:
+    """[n_images, N] floats -> [n_images, ceil(N/64)] int64 words, bit i of word w = (values[w*64+i] > threshold) (complemented
+    with `invert`): the bit-packed form of the mask the reference writes after evaluation (awesome/run/functions.py:2315-2361)."""
+    values = _check_dev(values, "values")
+    n = values.shape[0] if values.dim() > 1 else 1
+    values = values.reshape(n, -1)
+    words = (values.shape[1] + 63) // 64
+    bits = torch.zeros(n, words, dtype=torch.int64, device=values.device)
+    rc = L.load().inrfit_pack_masks(values.data_ptr(), n, values.shape[1], float(threshold), int(bool(invert)), bits.data_ptr(),
+                                    _stream_ptr(values.device))
+    L.check(rc, "inrfit_pack_masks")
+    return bits

@@ -270,6 +270,17 @@ class PathConnectedNet(nn.Module):
             return torch.stack([o.reshape(-1, h, w) for o in outs], 0)
         return outs[0].t()
 
+    def inverse(self, x: torch.Tensor) -> torch.Tensor:
+        """path_connected_net.py:107-122: the inverse of get_deformation, in the layout of x (no autograd)."""
+        planes, bhw = self._planar(x)
+        _, rspec, _, flow = self._ordered_params()
+        fp = self._flat(flow)
+        outs = [R.rnvp_inverse(rspec, fp, p.contiguous())[0] for p in planes]
+        if bhw is not None:
+            b, h, w = bhw
+            return torch.stack([o.reshape(-1, h, w) for o in outs], 0)
+        return outs[0].t()
+
     @staticmethod
     def _first_image_coords(grid: "K.Grid") -> torch.Tensor:
         if grid.coords is not None:

@@ -166,6 +166,22 @@ def rnvp_forward(rspec: RnvpSpec, flow_params: Tensor, grid: K.Grid) -> Tensor:
     return out
 
 
+def rnvp_inverse(rspec: RnvpSpec, flow_params: Tensor, coords: Tensor) -> Tensor:
+    """PathConnectedNet.inverse (path_connected_net.py:107-122): coords (C, N) shared or (n_images, C, N) -> [n_images, C, N]."""
+    fp = K._check_dev(flow_params, "flow_params")
+    coords = K._check_dev(coords, "coords")
+    n = fp.shape[0]
+    stride = 0 if coords.dim() == 2 else coords.shape[1] * coords.shape[2]
+    N = coords.shape[-1]
+    out = torch.empty(n, rspec.channels, N, dtype=torch.float32, device=fp.device)
+    ws = _ws(None, rspec, K.Grid.explicit(coords), n)
+    rd = rspec.desc()
+    rc = L.load().inrfit_rnvp_inverse(C.byref(rd), fp.data_ptr(), coords.data_ptr(), stride, N, n, out.data_ptr(), ws.data_ptr(),
+                                      ws.numel() * 4, K._stream_ptr(fp.device))
+    L.check(rc, "inrfit_rnvp_inverse")
+    return out
+
+
 def fit_identity(rspec: RnvpSpec, flow_params: Tensor, grid: K.Grid, steps: int = 100, lr: float = 1e-2, weight_decay: float = 1e-5,
                  optimizer: str = "adamax", betas=(0.9, 0.999), eps: float = 1e-8, flow_opt_state: Optional[Tensor] = None,
                  step0: int = 0) -> Tuple[Tensor, Tensor]:

@@ -156,6 +156,12 @@ int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const
 int inrfit_miou(const float* out, const float* tgt, int n_images, int64_t n_points, float thr_out, float thr_tgt, int invert,
                 float* iou, void* stream);
 
+/* bits[n_images][ceil(n_points/64)]: (values > threshold) - or its complement with `invert` - one bit per point, LSB = lowest
+ * index.  The on-device form of the mask export after evaluation (awesome/run/functions.py:2315-2361 save_result_mask writes
+ * `prior > 0.5` as an image): 8 KB instead of 256 KB leave the device per 256x256 mask. */
+int inrfit_pack_masks(const float* values, int n_images, int64_t n_points, float threshold, int invert, uint64_t* bits,
+                      void* stream);
+
 /* ---- path-connected prior: ICNN(flow(Ax + b)), ConvexDiffeomorphismNet (awesome/model/convex_diffeomorphism_net.py:130-188)
  * with the weight-normalised coupling flow NormalizingFlow1D(backbone='normal_block') of awesome/model/diffeomorphism_net.py:
  * 169-302 (2-D grids only, like the reference).  Flat flow parameter vector (W = width, K = num_coupling):
@@ -225,6 +231,10 @@ int inrfit_rnvp_actnorm_init(const InrRnvpDesc* rnvp, float* flow_params, const 
 /* out_coords[n_images][C][n_points]: PathConnectedNet.get_deformation (path_connected_net.py:124-128). */
 int inrfit_rnvp_forward(const InrRnvpDesc* rnvp, const float* flow_params, const InrGridDesc* grid, int n_images,
                         float* out_coords, void* workspace, int64_t workspace_bytes, void* stream);
+/* out_coords[n_images][C][n_points] = linear^-1(flow_net^-1(in_coords)): PathConnectedNet.inverse (path_connected_net.py:87-122).
+ * in_coords is channel-planar [C][n_points] per image; in_image_stride (floats) = 0 shares one input among all images. */
+int inrfit_rnvp_inverse(const InrRnvpDesc* rnvp, const float* flow_params, const float* in_coords, int64_t in_image_stride,
+                        int64_t n_points, int n_images, float* out_coords, void* workspace, int64_t workspace_bytes, void* stream);
 /* `steps` steps of PathConnectedNet.learn_flow_identity (path_connected_net.py:155-250): Adamax/Adam on the flow_net parameters
  * only (weight decay opt->weight_decay, constant lr; the 1x1 linear is not part of this model) for the loss
  * SE('mean')(flow_net(x), x) on the grid x.  loss_hist (optional) [n_images][steps]. */

@@ -556,3 +556,21 @@ def fit_flow_identity(sd0: Dict[str, Tensor], rows: Tensor, steps: int, masks: T
         step_fn(sub, {k: p[k].grad for k in keys}, st, lr, weight_decay=weight_decay)
         losses.append(float(loss.item()))
     return {k: v.detach() for k, v in p.items()}, losses
+
+
+def pcn_inverse(sd: Dict[str, Tensor], xd: Tensor, masks: Tensor, vmin: Tensor, vmax: Tensor, new_min: float = -1.0,
+                new_max: float = 1.0, output_fn: Optional[str] = "tanh", output_scale: Optional[float] = None,
+                prefix: str = "flow_net.net.network.") -> Tensor:
+    """PathConnectedNet.inverse (path_connected_net.py:87-122) on rows (N, C): NormNet.inverse (MinMax.transform, the flows'
+    inverses in reverse order - ActNorm: (z - t) exp(-s); MaskedAffineFlow: zm + (1 - b)(z - t(zm)) exp(-s(zm)) - then
+    MinMax.inverse_transform), then inverse_1b1_linear: (x - bias) / weight."""
+    z = minmax(xd, vmin.view(1, -1), vmax.view(1, -1), new_min, new_max)
+    for f in reversed(range(masks.shape[0])):
+        z = (z - sd[f"{prefix}flows.{2 * f + 1}.t"]) * torch.exp(-sd[f"{prefix}flows.{2 * f + 1}.s"])
+        b = masks[f].to(z.dtype).view(1, -1)
+        zm = b * z
+        s = rnvp_mlp(sd, f"{prefix}flows.{2 * f}.s.", zm, output_fn, output_scale)
+        t = rnvp_mlp(sd, f"{prefix}flows.{2 * f}.t.", zm, output_fn, output_scale)
+        z = zm + (1 - b) * (z - t) * torch.exp(-s)
+    v = minmax(z, new_min, new_max, vmin.view(1, -1), vmax.view(1, -1))
+    return (1.0 / sd["linear.weight"].view(1, -1)) * (v - sd["linear.bias"].view(1, -1))

@@ -271,3 +271,17 @@ def test_spatio_temporal_grid_c4(amd):
                   plateau=dict(patience=200, factor=0.5))
     h = res.loss_hist[0].cpu().numpy()
     assert np.isfinite(h).all() and h[-1] < h[0] and int(res.status[0]) == 0
+
+
+def test_pack_masks(amd):
+    """Bit-packed masks: bit i of word w = values[w*64+i] > thr (ragged tail zero-filled), both polarities."""
+    A = amd
+    torch.manual_seed(0)
+    v = torch.rand(3, 1000).to("cuda:0")
+    for invert in (False, True):
+        bits = A.pack_masks(v, 0.5, invert=invert).cpu().numpy().view(np.uint64)
+        ref = (v.cpu().numpy() > 0.5) ^ invert
+        pad = np.zeros((3, 1024), dtype=bool)
+        pad[:, :1000] = ref
+        want = (pad.reshape(3, 16, 64).astype(np.uint64) << np.arange(64, dtype=np.uint64)).sum(-1, dtype=np.uint64)
+        np.testing.assert_array_equal(bits, want)

@@ -336,3 +336,24 @@ def test_prefit_stages_through_the_module(dev):
     assert float((m.get_deformation(g) - g).abs().max()) < 0.1
     res = m.fit_images(grid, un, num_epochs=1200, lr=2e-3, prefit_flow_net_identity=True, prefit_convex_net=True)
     assert float(A.miou(torch.sigmoid(res.logits), un)[0]) > 0.9
+
+
+@pytest.mark.parametrize("C", [2, 3])
+def test_inverse(dev, C):
+    """inrfit_rnvp_inverse vs the oracle's inverse, and the round trip inverse(get_deformation(x)) = x."""
+    from awesome_amd import rnvp as R
+    import awesome_amd as A
+    F = 12 if C == 2 else 6
+    ispec, rspec, sd = _case(C, 32, F, 1, seed=41 + C)
+    H, W = 13, 17
+    grid_t, rows = _rows(C, H, W, 0.4)
+    masks = O.rnvp_masks(C, F)
+    vmin, vmax = torch.tensor(rspec.vmin), torch.tensor(rspec.vmax)
+    _, fp = _split(ispec, rspec, sd, dev)
+    xd = R.rnvp_forward(rspec, fp, A.Grid.from_image_grid(grid_t.to(dev)))
+    back = R.rnvp_inverse(rspec, fp, xd[0].contiguous())
+    np.testing.assert_allclose(back[0].cpu().numpy(), rows.t().numpy(), rtol=2e-4, atol=2e-5)
+    pts = torch.rand(200, C) * 0.8 + 0.1
+    ref = O.pcn_inverse(sd, pts, masks, vmin, vmax)
+    got = R.rnvp_inverse(rspec, fp, pts.t().contiguous().to(dev))
+    np.testing.assert_allclose(got[0].cpu().numpy(), ref.t().numpy(), rtol=2e-4, atol=2e-5)
