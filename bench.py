@@ -38,6 +38,7 @@ def parse_args():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--images-per-gpu", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra 'variants' timings (other priors of the same path)")
     ap.add_argument("--cpu-sample-steps", type=int, default=60)
     ap.add_argument("--kernel-iters", type=int, default=200, help="step-kernel launches for the roofline timing")
     ap.add_argument("--throughput-images", type=int, default=64,
@@ -189,6 +190,8 @@ def main():
         }
         if thr is not None:
             out["throughput_mode"] = thr
+        if world == 1 and not args.no_variants:
+            out["variants"] = path_variants(dev, S)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, init[0].cpu(), unaries[0].cpu(), spec)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
@@ -196,6 +199,40 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def path_variants(dev, S, steps=300):
+    """Extra, never part of `value`: microseconds per optimizer step of the other priors on the same path (one image /
+    sequence on this GPU): ICNN L=2, ConvexDiffeomorphismNet, PathConnectedNet (RealNVP) on (x, y) and on (x, y, t)."""
+    import torch
+    import awesome_amd as A
+    from awesome_amd.dataset import SyntheticSequenceDataset, convex_blob_unaries
+    from awesome_amd.model import ConvexDiffeomorphismNet, ConvexNextNet, real_nvp_path_connected_net
+
+    def timed(fn):
+        fn(10)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(steps)
+        torch.cuda.synchronize()
+        return round((time.perf_counter() - t0) / steps * 1e6, 1)
+
+    torch.manual_seed(0)
+    un = convex_blob_unaries(S, 0).reshape(1, -1).to(dev)
+    grid = A.Grid.linspace(S, S, dev)
+    out = {"unit": "us per optimizer step", "steps": steps}
+    m2 = ConvexNextNet(n_hidden=130, n_hidden_layers=2, in_features=2)
+    p2 = m2.flat_parameters()[None].to(dev)
+    out[f"ConvexNextNet_L2_{S}x{S}"] = timed(lambda n: A.fit(m2.spec, p2.clone(), grid, un, n, lr=2e-3, record_loss=False, want_logits=False))
+    cdn = ConvexDiffeomorphismNet(n_hidden=130, n_hidden_layers=2, nf_layers=6, nf_hidden=130).to(dev)
+    out[f"ConvexDiffeomorphismNet_K6_w130_L2_{S}x{S}"] = timed(lambda n: cdn.fit_images(grid, un, num_epochs=n))
+    pc2 = real_nvp_path_connected_net(channels=2, hidden_units=32, flow_n_flows=12, flow_output_fn="tanh").to(dev)
+    out[f"PathConnectedNet_RealNVP_C2_F12_L2_{S}x{S}"] = timed(lambda n: pc2.fit_images(grid, un, num_epochs=n))
+    ds = SyntheticSequenceDataset(1, 128, 16)
+    g3, u3 = A.Grid.explicit(ds.coords().to(dev)), ds.batch([0]).to(dev)
+    pc3 = real_nvp_path_connected_net(channels=3, hidden_units=32, flow_n_flows=18, flow_output_fn="tanh").to(dev)
+    out["PathConnectedNet_RealNVP_C3_F18_L2_128x128x16"] = timed(lambda n: pc3.fit_images(g3, u3, num_epochs=n))
+    return out
 
 
 def cpu_baseline(args, flat0, unaries0, spec):
