@@ -128,3 +128,17 @@ def test_fit_disc64_end_to_end(golden_dir):
     miou = O.miou_binary(mask.float(), (un > 0.5).float(), invert=True)
     assert abs(miou - float(z["final_miou"])) <= 1e-3
     assert (mask.numpy() != z["final_mask"]).mean() < 2e-3
+
+
+def test_minmax_transform(golden_dir):
+    """MinMax around the RealNVP flow (awesome/transforms/min_max.py:8-58) - the one piece of the a10 path that is the
+    reference's own code besides the ICNN."""
+    z = np.load(os.path.join(golden_dir, "minmax.npz"))
+    for C in (2, 3):
+        vmin, vmax = torch.from_numpy(z[f"c{C}.min"]), torch.from_numpy(z[f"c{C}.max"])
+        fit_x = torch.from_numpy(z[f"c{C}.fit_x"])
+        np.testing.assert_array_equal(vmin.numpy(), fit_x.amin(dim=(0, 2, 3), keepdim=True).numpy())
+        np.testing.assert_array_equal(vmax.numpy(), fit_x.amax(dim=(0, 2, 3), keepdim=True).numpy())
+        x = torch.from_numpy(z[f"c{C}.x"])
+        np.testing.assert_array_equal(O.minmax(x, vmin, vmax, -1.0, 1.0).numpy(), z[f"c{C}.transform"])
+        np.testing.assert_array_equal(O.minmax(x, -1.0, 1.0, vmin, vmax).numpy(), z[f"c{C}.inverse"])

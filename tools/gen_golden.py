@@ -297,6 +297,24 @@ def gen_flow(ref, out):
     print("wrote flow")
 
 
+def gen_minmax(ref, out):
+    """MinMax as NormNet uses it around the RealNVP flow of PathConnectedNet (awesome/transforms/min_max.py:22-61;
+    net_factory.py:160-162: MinMax(dim=(0, 2, 3)) fitted on the normalized grid, new range [-1, 1])."""
+    rec = {}
+    for C, (H, W) in ((2, (9, 13)), (3, (7, 11))):
+        seed_all(5 + C)
+        fit_x = torch.rand(2, C, H, W) * torch.tensor([1.3, 0.7, 2.0][:C]).view(1, C, 1, 1) + torch.tensor([-0.2, 0.1, 0.5][:C]).view(1, C, 1, 1)
+        mm = ref.min_max.MinMax(new_min=-1.0, new_max=1.0, dim=(0, 2, 3))
+        mm.fit(fit_x)
+        x = torch.randn(1, C, H, W)
+        y = mm.transform(x)
+        rec[f"c{C}.fit_x"], rec[f"c{C}.x"] = fit_x.numpy(), x.numpy()
+        rec[f"c{C}.min"], rec[f"c{C}.max"] = mm.min.numpy(), mm.max.numpy()
+        rec[f"c{C}.transform"], rec[f"c{C}.inverse"] = y.numpy(), mm.inverse_transform(x).numpy()
+    np.savez_compressed(os.path.join(out, "minmax.npz"), **rec)
+    print("wrote minmax")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden"))
@@ -312,6 +330,7 @@ def main():
     gen_adamax(ref, out)
     gen_flow(ref, out)
     gen_fit_disc(ref, out)
+    gen_minmax(ref, out)
     with open(os.path.join(out, "PROVENANCE.txt"), "w") as f:
         f.write("Generated by tools/gen_golden.py from jp-schneider/awesome @ 2024_08_07 (reference classes imported on CPU),\n")
         f.write(f"torch {torch.__version__}, numpy {np.__version__}.\n")
