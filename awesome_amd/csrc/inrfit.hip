@@ -920,7 +920,7 @@ struct PcnWs {
 
 bool rnvp_ok(const InrRnvpDesc* r) {
     if (!r || (r->channels != 2 && r->channels != 3)) return false;
-    if (r->hidden_units < 1 || r->hidden_units > 64 || r->n_flows < 1 || r->n_flows > INR_RNVP_MAX_FLOWS) return false;
+    if (r->hidden_units < 1 || r->hidden_units > 256 || r->n_flows < 1 || r->n_flows > INR_RNVP_MAX_FLOWS) return false;
     if (r->output_fn != 0 && r->output_fn != 1) return false;
     for (int f = 0; f < r->n_flows; ++f)
         if (r->masks[f] < 1u || r->masks[f] > (1u << r->channels) - 2u) return false;   // at least one input and one output
@@ -928,7 +928,7 @@ bool rnvp_ok(const InrRnvpDesc* r) {
         if (!(r->vmax[c] > r->vmin[c])) return false;
     if (!(r->new_max > r->new_min)) return false;
     const int ldsf = RNVP_HDR + r->n_flows * (r->hidden_units * RNVP_REC + RNVP_TAIL);
-    return (ldsf + 4 * (r->n_flows * 4 * r->channels + 2 * r->channels)) * 4 <= 64 * 1024;
+    return (ldsf + 4 * (r->n_flows * 4 * r->channels + 2 * r->channels)) * 4 <= 160 * 1024;   // all flows' records live in LDS
 }
 
 RnvpMap make_rnvp_map(const InrRnvpDesc* r) {
@@ -941,6 +941,7 @@ RnvpMap make_rnvp_map(const InrRnvpDesc* r) {
     m.RP = 2 * m.C + m.F * m.pf;
     m.fl = m.HID * RNVP_REC + RNVP_TAIL;
     m.LDSF = RNVP_HDR + m.F * m.fl;
+    m.HIDp = (m.HID + 63) / 64 * 64;
     m.A = 2 * m.C - 1;
     m.out_fn = r->output_fn;
     m.out_scale = r->output_fn ? (r->output_scale != 0.f ? r->output_scale : 1.f) : 1.f;
@@ -973,7 +974,7 @@ PcnWs carve_pcn(const KernelEntry* e, const InrRnvpDesc* r, const InrGridDesc* g
     w.zs = take((long long)n_images * F * C * N * 4);
     w.ps = take((long long)n_images * F * w.rm.A * N * 4);
     w.slab1 = take((long long)n_images * w.blocks1 * w.S1 * 4);
-    w.slab2 = take((long long)n_images * w.chunks * F * 2 * (2 * C + 1) * 64 * 4);
+    w.slab2 = take((long long)n_images * w.chunks * F * 2 * (2 * C + 1) * w.rm.HIDp * 4);
     w.RE = take((long long)n_images * w.rm.LDSF * 4);
     w.blocksL = (int)((N + 255) / 256);
     w.lossp = take((long long)n_images * w.blocksL * 4);
@@ -987,6 +988,26 @@ PcnWs carve_pcn(const KernelEntry* e, const InrRnvpDesc* r, const InrGridDesc* g
     }
     w.bytes = off;
     return w;
+}
+
+// the point kernels keep every flow's records in LDS: allow more than the default 64 KB of dynamic LDS (once per process)
+int rnvp_set_lds() {
+    static int rc = -1;
+    if (rc >= 0) return rc;
+    const int lim = 160 * 1024;
+    bool ok = true;
+    ok &= hipFuncSetAttribute((const void*)rnvp_fwd_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)rnvp_fwd_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)rnvp_fwd_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)rnvp_fwd_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)rnvp_bwd_points_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)rnvp_bwd_points_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)rnvp_bwd_points_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)rnvp_bwd_points_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)rnvp_inverse_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)rnvp_inverse_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    rc = ok ? INR_OK : INR_ENODEVICE;
+    return rc;
 }
 
 int check_pcn(const InrModelDesc* model, const InrRnvpDesc* r, const InrGridDesc* grid, int n_images, void* workspace,
@@ -1077,13 +1098,15 @@ void launch_rnvp_bwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, i
     ua.N = grid->n_points;
     ua.m = w.rm;
     ua.chunks = w.chunks;
-    const dim3 g2(w.chunks, w.rm.F, n_images);
+    // hidden units in blocks of 32 (8 per wave) - or 64 (16 per wave) when that needs no second block
+    const int upw = (w.rm.HID > 32 && w.rm.HID <= 64) ? 16 : 8;
+    const dim3 g2(w.chunks, w.rm.F * ((w.rm.HID + 4 * upw - 1) / (4 * upw)), n_images);
     const size_t lds2 = (size_t)(RNVP_HDR + w.rm.fl) * sizeof(float);
     if (w.rm.C == 2) {
-        if (w.rm.HID <= 32) hipLaunchKernelGGL((rnvp_bwd_units_kernel<2, 8>), g2, dim3(256), lds2, s, ua);
+        if (upw == 8) hipLaunchKernelGGL((rnvp_bwd_units_kernel<2, 8>), g2, dim3(256), lds2, s, ua);
         else hipLaunchKernelGGL((rnvp_bwd_units_kernel<2, 16>), g2, dim3(256), lds2, s, ua);
     } else {
-        if (w.rm.HID <= 32) hipLaunchKernelGGL((rnvp_bwd_units_kernel<3, 8>), g2, dim3(256), lds2, s, ua);
+        if (upw == 8) hipLaunchKernelGGL((rnvp_bwd_units_kernel<3, 8>), g2, dim3(256), lds2, s, ua);
         else hipLaunchKernelGGL((rnvp_bwd_units_kernel<3, 16>), g2, dim3(256), lds2, s, ua);
     }
 }

@@ -40,6 +40,7 @@ struct RnvpMap {
     int RP;     // lin.weight [C] | lin.bias [C] | flows
     int fl;     // LDS floats per flow
     int LDSF;   // LDS floats of the whole image
+    int HIDp;   // hidden units rounded up to 64 (row stride of the unit-gradient slabs)
     int A;      // per-point arrays per flow in ps: zin [NIN] | do_s [NOUT] | do_t [NOUT]  (<= 2C - 1)
     int out_fn; // 0 = none, 1 = tanh
     float out_scale;
@@ -75,10 +76,11 @@ __device__ __forceinline__ float sel(const float (&z)[C], int idx) {   // unifor
     return v;
 }
 
-// tanh / exp of the coupling outputs on the hardware exp2 / rcp (v_exp_f32, v_rcp_f32: 1 ulp each): tanh x = 1 - 2/(1 + e^2x),
-// absolute error <= 2e-7 - the libm calls were a third of the point kernels' instructions
-__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
-__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
+// tanh / exp of the coupling outputs: libm.  (v_exp_f32 / v_rcp_f32 forms - tanh x = 1 - 2/(1 + e^2x), abs. error 2e-7 - made
+// the point kernels 3 % faster but the deformation ~10x noisier than fp32 libm, which then switches relus near 0 differently
+// from the reference arithmetic: single gradient entries off by 1e-3 of the tensor maximum.  Not worth it.)
+__device__ __forceinline__ float fast_exp(float x) { return expf(x); }
+__device__ __forceinline__ float fast_tanh(float x) { return tanhf(x); }
 
 __device__ __forceinline__ float minmax_fwd(float v, float lo, float hi, float nlo, float nhi) {   // transforms/min_max.py:8-19
     return (v - lo) / (hi - lo) * (nhi - nlo) + nlo;
@@ -567,7 +569,8 @@ struct RnvpUnitsArgs {
 template <int C, int NIN, int NOUT, int UPW>
 __device__ __forceinline__ void rnvp_units_body(const RnvpUnitsArgs& a, const FlowIdx& x, float* lds) {
     constexpr int PPL = 4;
-    const int img = blockIdx.z, chunk = blockIdx.x, f = blockIdx.y;
+    const int UB = (a.m.HID + 4 * UPW - 1) / (4 * UPW);   // unit blocks of 4 UPW units
+    const int img = blockIdx.z, chunk = blockIdx.x, f = blockIdx.y / UB, ub = blockIdx.y - f * UB;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = (int)a.N, HID = a.m.HID;
@@ -606,7 +609,7 @@ __device__ __forceinline__ void rnvp_units_body(const RnvpUnitsArgs& a, const Fl
         }
 #pragma unroll
         for (int u = 0; u < UPW; ++u) {
-            const int j = wave * UPW + u;
+            const int j = (ub * 4 + wave) * UPW + u;
             if (j < HID) {   // wave-uniform
                 const f32x4 r0 = *(const f32x4*)(rec + RNVP_REC * j), r1 = *(const f32x4*)(rec + RNVP_REC * j + 4);
                 const float v[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
@@ -650,7 +653,7 @@ __device__ __forceinline__ void rnvp_units_body(const RnvpUnitsArgs& a, const Fl
                 }
             }
         }
-    const int j = wave * UPW + (lane >> 1), net = lane & 1;
+    const int j = (ub * 4 + wave) * UPW + (lane >> 1), net = lane & 1;
     if (lane < 2 * UPW && j < HID) {
         const float* __restrict__ pn = rp + 2 * C + (size_t)f * a.m.pf + net * a.m.net;
         float w1[NIN], w2[NOUT];
@@ -683,17 +686,19 @@ __device__ __forceinline__ void rnvp_units_body(const RnvpUnitsArgs& a, const Fl
                 if (c == x.in(mm)) rows[c] = dw1;
         }
         rows[C] = db1;
-        float* __restrict__ dst = a.slab2 + ((((size_t)img * a.chunks + chunk) * (a.m.F * 2) + f * 2 + net) * (2 * C + 1)) * 64 + j;
+        float* __restrict__ dst = a.slab2 + ((((size_t)img * a.chunks + chunk) * (a.m.F * 2) + f * 2 + net) * (2 * C + 1)) * a.m.HIDp + j;
 #pragma unroll
-        for (int r = 0; r < 2 * C + 1; ++r) dst[r * 64] = rows[r];
+        for (int r = 0; r < 2 * C + 1; ++r) dst[r * a.m.HIDp] = rows[r];
     }
 }
 
 template <int C, int UPW>
 __global__ __launch_bounds__(256) void rnvp_bwd_units_kernel(const RnvpUnitsArgs a) {
-    // grid: x = chunk of points, y = flow, z = image; wave w owns hidden units [w UPW, (w + 1) UPW)
+    // grid: x = chunk of points, y = flow * unit blocks + unit block, z = image; wave w of unit block ub owns hidden units
+    // [(4 ub + w) UPW, (4 ub + w + 1) UPW)
     extern __shared__ __attribute__((aligned(16))) float rsm[];
-    const FlowIdx x = flow_idx<C>(a.m.masks[blockIdx.y]);
+    const int UBk = (a.m.HID + 4 * UPW - 1) / (4 * UPW);
+    const FlowIdx x = flow_idx<C>(a.m.masks[blockIdx.y / UBk]);
     if (C == 2) rnvp_units_body<C, 1, 1, UPW>(a, x, rsm);
     else if (x.nin == 1) rnvp_units_body<C, 1, C == 2 ? 1 : 2, UPW>(a, x, rsm);
     else rnvp_units_body<C, C == 2 ? 1 : 2, 1, UPW>(a, x, rsm);
@@ -823,9 +828,9 @@ __global__ __launch_bounds__(256) void rnvp_update_kernel(const RnvpUpdArgs u) {
                 g = tot[net * C + j];
             } else {
                 g = 0.f;
-                const float* s2 = u.slab2 + ((((size_t)img * u.chunks) * (F * 2) + f * 2 + net) * (2 * C + 1) + row) * 64 + j;
+                const float* s2 = u.slab2 + ((((size_t)img * u.chunks) * (F * 2) + f * 2 + net) * (2 * C + 1) + row) * m.HIDp + j;
 #pragma unroll 8
-                for (int c = 0; c < u.chunks; ++c) g += s2[(size_t)c * (F * 2) * (2 * C + 1) * 64];
+                for (int c = 0; c < u.chunks; ++c) g += s2[(size_t)c * (F * 2) * (2 * C + 1) * m.HIDp];
             }
         }
         if (u.mode == 1) {

@@ -213,7 +213,7 @@ int inrfit_cdn_fit(const InrModelDesc* model, const InrFlowDesc* flow, float* ic
 #define INR_RNVP_MAX_FLOWS 32
 typedef struct InrRnvpDesc {
     int32_t channels;      /* C in {2, 3}; equals the ICNN's in_features */
-    int32_t hidden_units;  /* hid <= 64 */
+    int32_t hidden_units;  /* hid <= 256 (and F * (8 hid + 12) floats must fit the 160 KB of LDS) */
     int32_t n_flows;       /* F <= 32 */
     int32_t output_fn;     /* 0 = none, 1 = tanh (flow_output_fn) */
     float output_scale;    /* flow_output_scale; 0 or 1 = none */

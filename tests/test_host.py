@@ -114,7 +114,7 @@ def test_rnvp_spec_layout_and_masks():
     import ctypes
     from awesome_amd import _lib as L
     from awesome_amd import rnvp as R
-    for C, hid, F in ((2, 32, 12), (3, 32, 18), (3, 20, 5), (2, 64, 3)):
+    for C, hid, F in ((2, 32, 12), (3, 32, 18), (3, 20, 5), (2, 64, 3), (2, 130, 6), (3, 130, 18)):
         spec = R.RnvpSpec(C, hid, F)
         assert spec.n_params == sum(int(np.prod(s)) for _, s in spec.keys_shapes())
         d = spec.desc()
@@ -126,7 +126,7 @@ def test_rnvp_spec_layout_and_masks():
         assert torch.equal(R.pack_rnvp_state_dict(spec, sd), flat)
         for (a, b) in spec.actnorm_slices():
             assert b - a == 2 * C
-    bad = R.RnvpSpec(2, 200, 12).desc()   # hidden_units > 64: not built
+    bad = R.RnvpSpec(2, 300, 12).desc()   # hidden_units > 256: not built
     assert L.load().inrfit_rnvp_param_count(ctypes.byref(bad)) < 0
 
 
