@@ -285,3 +285,30 @@ def test_pack_masks(amd):
         pad[:, :1000] = ref
         want = (pad.reshape(3, 16, 64).astype(np.uint64) << np.arange(64, dtype=np.uint64)).sum(-1, dtype=np.uint64)
         np.testing.assert_array_equal(bits, want)
+
+
+@pytest.mark.parametrize("layers,C", [(1, 2), (2, 2), (2, 3)])
+def test_gradient_accuracy_against_float64(amd, layers, C):
+    """How exact is the MFMA path?  The same loss/gradient in float64 is the yardstick; the fp32 torch restatement is the
+    competitor.  v_mfma_f32_16x16x4_f32 is an exact-fp32 FMA chain, so the HIP gradients must be as close to the float64 result
+    as fp32 torch is (x3 + floor) - at the BASELINE grid size of 256x256 for the headline model."""
+    A = amd
+    from awesome_amd.model import ConvexNextNet
+    S = 256 if (layers, C) == (1, 2) else 96
+    torch.manual_seed(5)
+    m = ConvexNextNet(n_hidden=130, n_hidden_layers=layers, in_features=C)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    grid = O.positional_grid(S, S) if C == 2 else O.positional_grid(S, S, 0.3, 1.0)
+    un = torch.from_numpy(np.random.RandomState(0).rand(1, 1, S, S).astype(np.float32))
+    _, g32 = O.loss_and_grads(sd, grid[None], un, "bce")
+    _, g64 = O.loss_and_grads({k: v.double() for k, v in sd.items()}, grid[None].double(), un.double(), "bce")
+    spec = A.IcnnSpec(130, C, layers)
+    params = A.pack_state_dict(spec, sd, "cuda:0")[None].contiguous()
+    _, g = A.loss_grad(spec, params, A.Grid.from_image_grid(grid.to("cuda:0")), un.reshape(1, -1).to("cuda:0"), loss="bce")
+    got = A.unpack_params(spec, g[0].cpu())
+    e_hip, e_ref = [], []
+    for k in g64:
+        sc = float(g64[k].abs().max()) + 1e-30
+        e_hip.append(float((got[k].double() - g64[k]).abs().max()) / sc)
+        e_ref.append(float((g32[k].double() - g64[k]).abs().max()) / sc)
+    assert max(e_hip) <= 3.0 * max(e_ref) + 1e-6, (max(e_hip), max(e_ref))
