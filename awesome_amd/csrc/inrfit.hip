@@ -52,28 +52,63 @@ struct UpdArgs {
     int clamp_lo[3], clamp_hi[3];  // flat ranges projected onto >= 0 (ln.weight of every hidden layer, out.ln.weight)
 };
 
-constexpr int UPD_PARAMS = 64;   // parameters per block (one 256-B line per slab row)
-constexpr int UPD_GROUPS = 16;   // slab groups summed in parallel, then combined in fixed order
+constexpr int UPD_MAX_PARAMS = 256;  // most parameters per block
+constexpr int UPD_GROUPS = 16;       // slab groups summed in parallel, then combined in fixed order
 
-// block = (16 lanes x float4 = 64 parameters) x 16 slab groups
-__global__ __launch_bounds__(UPD_PARAMS / 4 * UPD_GROUPS) void icnn_update_kernel(const UpdArgs u) {
+// Parameters per block: a CU pulls ~10 B/clock from memory whatever runs on it, so the reduction is as fast as its busiest
+// CU: one block per CU, all equally long (17 814 parameters -> 248 blocks of 72), instead of 279 blocks of 64 with 23 CUs
+// doing double duty.  Multiple of 4 (float4 loads), x n_images blocks when there are many images.
+inline int upd_params_per_block(int P) {
+    int ppb = ((P + 1 + 255) / 256 + 3) / 4 * 4;
+    if (ppb < 16) ppb = 16;
+    if (ppb > UPD_MAX_PARAMS) ppb = UPD_MAX_PARAMS;
+    return ppb;
+}
+inline dim3 upd_grid(int P, int n_images) { const int ppb = upd_params_per_block(P); return dim3((P + 1 + ppb - 1) / ppb, n_images); }
+inline dim3 upd_block(int P) { return dim3(upd_params_per_block(P) / 4, UPD_GROUPS); }
+
+// block = (blockDim.x lanes x float4 = ppb parameters) x 16 slab groups
+__global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_kernel(const UpdArgs u) {
     const int img = blockIdx.y;
     const int tx = threadIdx.x, grp = threadIdx.y;
-    __shared__ float red[UPD_GROUPS][UPD_PARAMS];
+    const int ppb = 4 * blockDim.x;
+    __shared__ float red[UPD_GROUPS][UPD_MAX_PARAMS];
+    const int jl = grp * blockDim.x + tx;  // the first ppb threads finish one parameter each
+    const int j = blockIdx.x * ppb + jl;
+    // The kernel is one dependent chain (slabs -> LDS -> optimizer -> stores) and at one image it is latency, not bandwidth,
+    // that it pays for: everything the tail needs is requested up front, and all slab rows of a thread are in flight at once.
+    float* __restrict__ st = u.opt_state + (size_t)img * (2 * (size_t)u.P + INR_OPT_HEADER_FLOATS);
+    float* __restrict__ hdr = st + 2 * (size_t)u.P;
+    float p_old = 0.f, m_old = 0.f, v_old = 0.f, lr_now = 0.f;
+    bool bad_before = false;
+    if (u.mode == 0 && jl < ppb && j <= u.P) {
+        bad_before = u.status != nullptr && u.status[img] != INR_STATUS_OK;
+        lr_now = hdr[u.t & 1];
+        if (j < u.P) {
+            p_old = u.params[(size_t)img * u.P + j];
+            m_old = st[j];
+            v_old = st[u.P + j];
+        }
+    }
     {
-        const int j4 = blockIdx.x * UPD_PARAMS + 4 * tx;
+        const int j4 = blockIdx.x * ppb + 4 * tx;
         f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
         if (j4 < u.PS) {
             const float* __restrict__ sl = u.slabs + (size_t)img * u.wgs * u.PS + j4;
-#pragma unroll 4
-            for (int w = grp; w < u.wgs; w += UPD_GROUPS) part += *(const f32x4*)(sl + (size_t)w * u.PS);
+            int w = grp;
+            for (; w + 15 * UPD_GROUPS < u.wgs; w += 16 * UPD_GROUPS) {   // 256 slabs: one trip, 16 loads in flight
+                f32x4 q[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) q[k] = *(const f32x4*)(sl + (size_t)(w + k * UPD_GROUPS) * u.PS);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) part += q[k];
+            }
+            for (; w < u.wgs; w += UPD_GROUPS) part += *(const f32x4*)(sl + (size_t)w * u.PS);
         }
         *(f32x4*)&red[grp][4 * tx] = part;
     }
     __syncthreads();
-    const int jl = grp * (UPD_PARAMS / 4) + tx;  // the first 64 threads finish one parameter each
-    const int j = blockIdx.x * UPD_PARAMS + jl;
-    if (jl >= UPD_PARAMS || j > u.P) return;
+    if (jl >= ppb || j > u.P) return;
     float gsum = 0.f;
 #pragma unroll
     for (int k = 0; k < UPD_GROUPS; ++k) gsum += red[k][jl];  // fixed order: reproducible
@@ -83,14 +118,11 @@ __global__ __launch_bounds__(UPD_PARAMS / 4 * UPD_GROUPS) void icnn_update_kerne
         else u.loss_out[img] = gsum;
         return;
     }
-    float* __restrict__ st = u.opt_state + (size_t)img * (2 * (size_t)u.P + INR_OPT_HEADER_FLOATS);
-    float* __restrict__ hdr = st + 2 * (size_t)u.P;
-    const bool bad_before = u.status != nullptr && u.status[img] != INR_STATUS_OK;
     if (j == u.P) {
         // loss bookkeeping + ReduceLROnPlateau (torch semantics, mode 'min', relative threshold)
         const float loss = gsum;
         if (u.loss_hist) u.loss_hist[(size_t)img * u.hist_stride + u.hist_idx] = loss;
-        float lr = hdr[u.t & 1];
+        float lr = lr_now;
         if (!isfinite(loss)) {
             if (u.status) u.status[img] = INR_STATUS_NONFINITE;
         } else if (u.opt.plateau) {
@@ -117,9 +149,8 @@ __global__ __launch_bounds__(UPD_PARAMS / 4 * UPD_GROUPS) void icnn_update_kerne
     }
     if (bad_before || !isfinite(gsum)) return;
 
-    const float lr = hdr[u.t & 1];
-    float p = u.params[(size_t)img * u.P + j];
-    float m = st[j], v = st[u.P + j];
+    const float lr = lr_now;
+    float p = p_old, m = m_old, v = v_old;
     float grad = gsum;
     if (u.opt.weight_decay != 0.f) grad = __fadd_rn(grad, __fmul_rn(u.opt.weight_decay, p));
     const double bc1 = u.bc1;  // 1 - beta1^t, computed on the host in double like torch does
@@ -546,8 +577,7 @@ static void launch_reduce(const KernelEntry* e, const Workspace& w, int n_images
     u.wgs = w.wgs;
     u.n_images = n_images;
     u.mode = 1;
-    hipLaunchKernelGGL(icnn_update_kernel, dim3((e->P + 1 + UPD_PARAMS - 1) / UPD_PARAMS, n_images),
-                       dim3(UPD_PARAMS / 4, UPD_GROUPS), 0, s, u);
+    hipLaunchKernelGGL(icnn_update_kernel, upd_grid(e->P, n_images), upd_block(e->P), 0, s, u);
 }
 
 int inrfit_forward(const InrModelDesc* model, const float* params, const InrGridDesc* grid, int n_images, float* logits,
@@ -629,14 +659,14 @@ int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const
     }
     if ((rc = launch_pack(e, w, params, n_images, s))) return rc;
     UpdArgs u = make_upd_args(e, w, params, opt_state, loss_hist, status, opt, n_images, steps);
-    const dim3 ugrid((e->P + 1 + UPD_PARAMS - 1) / UPD_PARAMS, n_images);
+    const dim3 ugrid = upd_grid(e->P, n_images), ublock = upd_block(e->P);
     for (int it = 0; it < steps; ++it) {
         if ((rc = launch_step(e, w, true, grid, targets, loss->kind, n_images, nullptr, s))) return rc;
         u.t = step0 + it + 1;
         u.bc1 = 1.0 - pow((double)opt->beta1, (double)u.t);
         u.bc2_sqrt = (float)sqrt(1.0 - pow((double)opt->beta2, (double)u.t));
         u.hist_idx = it;
-        hipLaunchKernelGGL(icnn_update_kernel, ugrid, dim3(UPD_PARAMS / 4, UPD_GROUPS), 0, s, u);
+        hipLaunchKernelGGL(icnn_update_kernel, ugrid, ublock, 0, s, u);
     }
     if (hipGetLastError() != hipSuccess) return INR_ELAUNCH;
     if (final_logits) return launch_step(e, w, false, grid, nullptr, 0, n_images, final_logits, s);
@@ -880,7 +910,7 @@ int inrfit_cdn_fit(const InrModelDesc* model, const InrFlowDesc* flow, float* ic
     if ((rc = launch_pack(e, w.icnn, icnn_params, n_images, s))) return rc;
     launch_flow_update(w, flow, n_images, 2, flow_params, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0, s);  // effective weights
     UpdArgs u = make_upd_args(e, w.icnn, icnn_params, icnn_opt_state, loss_hist, status, opt, n_images, steps);
-    const dim3 ugrid((e->P + 1 + UPD_PARAMS - 1) / UPD_PARAMS, n_images);
+    const dim3 ugrid = upd_grid(e->P, n_images), ublock = upd_block(e->P);
     const long long hdr_stride = 2 * (long long)e->P + INR_OPT_HEADER_FLOATS;
     for (int it = 0; it < steps; ++it) {
         launch_flow_fwd(w, grid, n_images, w.xd, s);
@@ -889,7 +919,7 @@ int inrfit_cdn_fit(const InrModelDesc* model, const InrFlowDesc* flow, float* ic
         u.bc1 = 1.0 - pow((double)opt->beta1, (double)u.t);
         u.bc2_sqrt = (float)sqrt(1.0 - pow((double)opt->beta2, (double)u.t));
         u.hist_idx = it;
-        hipLaunchKernelGGL(icnn_update_kernel, ugrid, dim3(UPD_PARAMS / 4, UPD_GROUPS), 0, s, u);
+        hipLaunchKernelGGL(icnn_update_kernel, ugrid, ublock, 0, s, u);
         launch_flow_bwd(w, flow, grid, n_images, s);
         // the learning rate of THIS step sits in header[t & 1] (the plateau thread wrote the next one into the other slot)
         launch_flow_update(w, flow, n_images, 0, flow_params, flow_opt_state, nullptr, opt, wd_on_weight_g, u.t,
@@ -1317,7 +1347,7 @@ int inrfit_pcn_fit(const InrModelDesc* model, const InrRnvpDesc* rnvp, float* ic
     if (status && hipMemsetAsync(status, 0, sizeof(int32_t) * n_images, s) != hipSuccess) return INR_ELAUNCH;
     if ((rc = launch_pack(e, w.icnn, icnn_params, n_images, s))) return rc;
     UpdArgs u = make_upd_args(e, w.icnn, icnn_params, icnn_opt_state, loss_hist, status, opt, n_images, steps);
-    const dim3 ugrid((e->P + 1 + UPD_PARAMS - 1) / UPD_PARAMS, n_images);
+    const dim3 ugrid = upd_grid(e->P, n_images), ublock = upd_block(e->P);
     const long long hdr_stride = 2 * (long long)e->P + INR_OPT_HEADER_FLOATS;
     for (int it = 0; it < steps; ++it) {
         launch_rnvp_fwd(w, flow_params, grid, n_images, w.xd, true, s);
@@ -1326,7 +1356,7 @@ int inrfit_pcn_fit(const InrModelDesc* model, const InrRnvpDesc* rnvp, float* ic
         u.bc1 = 1.0 - pow((double)opt->beta1, (double)u.t);
         u.bc2_sqrt = (float)sqrt(1.0 - pow((double)opt->beta2, (double)u.t));
         u.hist_idx = it;
-        hipLaunchKernelGGL(icnn_update_kernel, ugrid, dim3(UPD_PARAMS / 4, UPD_GROUPS), 0, s, u);
+        hipLaunchKernelGGL(icnn_update_kernel, ugrid, ublock, 0, s, u);
         launch_rnvp_bwd(w, flow_params, grid, n_images, s);
         // the learning rate of THIS step sits in header[t & 1] (the plateau thread wrote the next one into the other slot)
         launch_rnvp_update(w, n_images, 0, flow_params, flow_opt_state, nullptr, opt, flow_weight_decay, u.t,
