@@ -107,6 +107,32 @@ class AwesomeImageLoss:
         return self.name or type(self).__name__
 
 
+class AwesomeLoss:
+    """awesome/measures/awesome_loss.py:45-65 (pixel mode): output (..., n_pixels, 2) = (segmentation, prior) per pixel, the
+    first floor(n * scribble_percentage) pixels are scribbles with targets, the rest random pixels for the align term:
+    crit(seg, t) + alpha*crit(prior, t)  [ -> 0.1*loss + 100*mean((prior_rand - (seg_rand > .5))^2) with extra_penalty ]."""
+
+    def __init__(self, criterion=None, alpha: float = 1.0, name=None, scribble_percentage: float = 1.0, **kwargs):
+        self.criterion = criterion or torch.nn.BCELoss()
+        self.alpha, self.name, self.scribble_percentage = alpha, name, scribble_percentage
+        self.extra_penalty = False
+
+    def __call__(self, output: torch.Tensor, target: torch.Tensor, **kwargs) -> torch.Tensor:
+        total = output.shape[-2]
+        n_scr = int(total * self.scribble_percentage // 1)
+        n_rand = total - n_scr
+        seg, prior = output[..., :n_scr, 0:1], output[..., :n_scr, 1:2]
+        loss = self.criterion(seg, target) + self.alpha * self.criterion(prior, target)
+        if self.extra_penalty and n_rand > 0:
+            # the reference slices [random:] (its count of random pixels used as a start index, awesome_loss.py:58-59)
+            seg_r, prior_r = output[..., n_rand:, 0:1], output[..., n_rand:, 1:2]
+            loss = 0.1 * loss + 100.0 * torch.mean((prior_r - (seg_r > 0.5).float()) ** 2)
+        return loss
+
+    def get_name(self) -> str:
+        return self.name or type(self).__name__
+
+
 class FBMSJointLoss:
     """awesome/measures/fbms_joint_loss.py:35-59: alpha*crit(seg,t) + clip(beta*SE(prior, seg))."""
 

@@ -574,3 +574,20 @@ def pcn_inverse(sd: Dict[str, Tensor], xd: Tensor, masks: Tensor, vmin: Tensor, 
         z = zm + (1 - b) * (z - t) * torch.exp(-s)
     v = minmax(z, new_min, new_max, vmin.view(1, -1), vmax.view(1, -1))
     return (1.0 / sd["linear.weight"].view(1, -1)) * (v - sd["linear.bias"].view(1, -1))
+
+
+def awesome_loss(output: Tensor, target: Tensor, alpha: float = 1.0, scribble_percentage: float = 1.0, extra_penalty: bool = False
+                 ) -> Tensor:
+    """AwesomeLoss.__call__ with the default BCE criterion (awesome/measures/awesome_loss.py:39-65): output (..., n, 2) =
+    (seg, prior) per pixel; the first floor(n * scribble_percentage) pixels carry targets; with extra_penalty the loss becomes
+    0.1 * loss + 100 * mean((prior - (seg > .5))^2) over output[..., random:, :] (the reference uses its COUNT of random
+    pixels as the start index, :58-59)."""
+    total = output.shape[-2]
+    n_scr = int(math.floor(total * scribble_percentage))
+    rnd = total - n_scr
+    seg, prior = output[..., :n_scr, 0][..., None], output[..., :n_scr, 1][..., None]
+    loss = F.binary_cross_entropy(seg, target) + alpha * F.binary_cross_entropy(prior, target)
+    if extra_penalty and rnd > 0:
+        seg_r, prior_r = output[..., rnd:, 0][..., None], output[..., rnd:, 1][..., None]
+        loss = 0.1 * loss + 100 * torch.mean((prior_r - (seg_r > 0.5).float()) ** 2)
+    return loss

@@ -142,3 +142,15 @@ def test_minmax_transform(golden_dir):
         x = torch.from_numpy(z[f"c{C}.x"])
         np.testing.assert_array_equal(O.minmax(x, vmin, vmax, -1.0, 1.0).numpy(), z[f"c{C}.transform"])
         np.testing.assert_array_equal(O.minmax(x, -1.0, 1.0, vmin, vmax).numpy(), z[f"c{C}.inverse"])
+
+
+def test_awesome_loss_pixel_mode(golden_dir):
+    z = np.load(os.path.join(golden_dir, "pixel_losses.npz"))
+    out, tgt = torch.from_numpy(z["al.output"]), torch.from_numpy(z["al.target"])
+    assert float(O.awesome_loss(out, tgt, 0.6, 0.75)) == pytest.approx(float(z["al.plain"]), rel=1e-6)
+    assert float(O.awesome_loss(out, tgt, 0.6, 0.75, extra_penalty=True)) == pytest.approx(float(z["al.penalty"]), rel=1e-6)
+    from awesome_amd.measures import AwesomeLoss
+    crit = AwesomeLoss(alpha=0.6, scribble_percentage=0.75)
+    assert float(crit(out, tgt)) == pytest.approx(float(z["al.plain"]), rel=1e-6)
+    crit.extra_penalty = True
+    assert float(crit(out, tgt)) == pytest.approx(float(z["al.penalty"]), rel=1e-6)

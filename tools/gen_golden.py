@@ -39,10 +39,11 @@ def _import_reference():
     import awesome.measures.unaries_weighted_loss as uwl
     import awesome.measures.miou as miou
     import awesome.measures.awesome_image_loss as ail
+    import awesome.measures.awesome_loss as al
     import awesome.dataset.transformator as transformator
     import awesome.transforms.min_max as min_max
     return types.SimpleNamespace(convex_net=convex_net, diffeo=diffeo, resnet_1d=resnet_1d, se=se, uwl=uwl,
-                                 miou=miou, ail=ail, transformator=transformator, min_max=min_max)
+                                 miou=miou, ail=ail, al=al, transformator=transformator, min_max=min_max)
 
 
 def seed_all(seed: int) -> None:
@@ -297,6 +298,22 @@ def gen_flow(ref, out):
     print("wrote flow")
 
 
+def gen_pixel_losses(ref, out):
+    """AwesomeLoss (pixel mode, awesome/measures/awesome_loss.py:45-65)."""
+    rec = {}
+    seed_all(11)
+    out_px = torch.rand(3, 40, 2)
+    tgt_px = (torch.rand(3, 30, 1) > 0.5).float()
+    crit = ref.al.AwesomeLoss(alpha=0.6, scribble_percentage=0.75)
+    rec["al.output"], rec["al.target"] = out_px.numpy(), tgt_px.numpy()
+    rec["al.plain"] = crit(out_px, tgt_px).numpy()
+    crit.extra_penalty = True
+    rec["al.penalty"] = crit(out_px, tgt_px).numpy()
+    # (FBMSJointLoss is not importable here: fbms_joint_loss.py -> tracker_loss -> ... -> package_tools needs `toml`)
+    np.savez_compressed(os.path.join(out, "pixel_losses.npz"), **rec)
+    print("wrote pixel_losses", sorted(rec))
+
+
 def gen_minmax(ref, out):
     """MinMax as NormNet uses it around the RealNVP flow of PathConnectedNet (awesome/transforms/min_max.py:22-61;
     net_factory.py:160-162: MinMax(dim=(0, 2, 3)) fitted on the normalized grid, new range [-1, 1])."""
@@ -331,6 +348,7 @@ def main():
     gen_flow(ref, out)
     gen_fit_disc(ref, out)
     gen_minmax(ref, out)
+    gen_pixel_losses(ref, out)
     with open(os.path.join(out, "PROVENANCE.txt"), "w") as f:
         f.write("Generated by tools/gen_golden.py from jp-schneider/awesome @ 2024_08_07 (reference classes imported on CPU),\n")
         f.write(f"torch {torch.__version__}, numpy {np.__version__}.\n")
