@@ -351,6 +351,54 @@ class PathConnectedNet(nn.Module):
                          weight_mode=weight_mode, flow_weight_decay=flow_weight_decay,
                          plateau=dict(patience=200, factor=0.5) if plateau is None else (plateau or None))
 
+    def fit_sequence(self, frame_coords: torch.Tensor, frame_unaries: torch.Tensor, num_epochs: int = 2000, lr: float = 1e-3,
+                     flow_weight_decay: float = 1e-5, batch_size: int = 1, dataloader_shuffle: bool = False, loss: str = "se",
+                     weight_mode: str = "none", optimizer: str = "adamax", plateau=None, generator=None):
+        """_non_prior_based_pretrain (path_connected_net.py:511-728): ONE network over all frames of a sequence, trained in
+        mini-batches of `batch_size` frames - one optimizer step per batch on the mean loss of the batch's pixels, Adamax over the
+        same parameter groups, enforce_convexity after every step, ReduceLROnPlateau stepped once per EPOCH with the mean of the
+        batch losses (:700-713).  frame_coords (T, C, H*W), frame_unaries (T, H*W).  Every step is one `inrfit_pcn_fit(steps=1)`
+        call that continues the optimizer state; the epoch loss and the learning rate live on the host.  With
+        batch_size == T this is `fit_images` on the whole (x, y, t) grid (full batch), which is the fast form.
+        Updates this module's parameters in place; returns the list of epoch losses."""
+        T, dev = frame_coords.shape[0], frame_coords.device
+        self._actnorm_init_if_needed(frame_coords[:batch_size].permute(1, 0, 2).reshape(frame_coords.shape[1], -1))
+        ispec, rspec, icnn, flow = self._ordered_params()
+        ip, fp = self._flat(icnn).to(dev), self._flat(flow).to(dev)
+        iopt = K.new_opt_state(ispec, 1, dev)
+        fopt = torch.zeros(1, 2 * rspec.n_params, dtype=torch.float32, device=dev)
+        pl = dict(patience=200, factor=0.5) if plateau is None else (plateau or None)
+        cur_lr, best, num_bad = float(lr), float("inf"), 0
+        epoch_losses, k = [], 0
+        for _ in range(num_epochs):
+            order = torch.randperm(T, generator=generator).tolist() if dataloader_shuffle else list(range(T))
+            batches = [order[i:i + batch_size] for i in range(0, T, batch_size)]
+            acc = torch.zeros((), device=dev)
+            for b in batches:
+                coords = frame_coords[b].permute(1, 0, 2).reshape(frame_coords.shape[1], -1).contiguous()
+                un = frame_unaries[b].reshape(1, -1).contiguous()
+                if k > 0:
+                    iopt[:, 2 * ispec.n_params + 2] = cur_lr   # header[2]: the learning rate a continued fit starts from
+                res = R.pcn_fit(ispec, rspec, ip, fp, K.Grid.explicit(coords), un, 1, lr=cur_lr, optimizer=optimizer, loss=loss,
+                                weight_mode=weight_mode, flow_weight_decay=flow_weight_decay, plateau=None, icnn_opt_state=iopt,
+                                flow_opt_state=fopt, step0=k, want_logits=False)
+                acc = acc + res.loss_hist[0, 0] / len(batches)
+                k += 1
+            el = float(acc)
+            epoch_losses.append(el)
+            if pl is not None:   # torch ReduceLROnPlateau(mode='min', threshold=1e-4 rel), stepped with the epoch loss
+                if el < best * (1.0 - pl.get("threshold", 1e-4)):
+                    best, num_bad = el, 0
+                else:
+                    num_bad += 1
+                if num_bad > pl.get("patience", 200):
+                    new_lr = max(cur_lr * pl.get("factor", 0.5), pl.get("min_lr", 0.0))
+                    if cur_lr - new_lr > pl.get("eps", 1e-8):
+                        cur_lr = new_lr
+                    num_bad = 0
+        self.load_flat(ip[0], fp[0])
+        return epoch_losses
+
     def load_flat(self, icnn_flat: torch.Tensor, flow_flat: torch.Tensor) -> None:
         """Write one row of a PcnFitResult back into the module (the PriorCache round trip)."""
         ispec, rspec = self._specs()

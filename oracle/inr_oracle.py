@@ -591,3 +591,45 @@ def awesome_loss(output: Tensor, target: Tensor, alpha: float = 1.0, scribble_pe
         seg_r, prior_r = output[..., rnd:, 0][..., None], output[..., rnd:, 1][..., None]
         loss = 0.1 * loss + 100 * torch.mean((prior_r - (seg_r > 0.5).float()) ** 2)
     return loss
+
+
+def fit_pcn_minibatch(sd0: Dict[str, Tensor], frame_rows: Sequence[Tensor], frame_unaries: Sequence[Tensor], num_epochs: int,
+                      batch_size: int, masks: Tensor, vmin: Tensor, vmax: Tensor, lr: float = 1e-3, flow_weight_decay: float = 1e-5,
+                      plateau: Optional[dict] = None, **kw) -> Tuple[Dict[str, Tensor], List[float]]:
+    """_non_prior_based_pretrain (path_connected_net.py:631-713): one network over all frames, one Adamax step per mini-batch of
+    frames (DataLoader without shuffle), enforce_convexity after every step, ReduceLROnPlateau stepped per epoch with the mean
+    batch loss.  frame_rows[t] (HW, C), frame_unaries[t] (HW, 1).  Returns (params, epoch losses)."""
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in sd0.items()}
+    st = AdamState(p)
+    sched = PlateauState(lr, **plateau) if plateau is not None else None
+    cur_lr = lr
+    flow_keys = [k for k in p if k.startswith("flow_net.")]
+    other_keys = [k for k in p if not k.startswith("flow_net.")]
+    T = len(frame_rows)
+    epoch_losses: List[float] = []
+    for _ in range(num_epochs):
+        batches = [list(range(i, min(i + batch_size, T))) for i in range(0, T, batch_size)]
+        el = 0.0
+        for b in batches:
+            rows = torch.cat([frame_rows[t] for t in b], 0)
+            un = torch.cat([frame_unaries[t] for t in b], 0)
+            for v in p.values():
+                v.grad = None
+            out = torch.sigmoid(pcn_forward(p, rows, masks, vmin, vmax, **kw))
+            loss = weighted_loss(out.reshape(1, 1, -1, 1), un.reshape(1, 1, -1, 1), "se", "none")
+            loss.backward()
+            st.step += 1
+            for keys, wd in ((flow_keys, flow_weight_decay), (other_keys, 0.0)):
+                sub, g = {k: p[k] for k in keys}, {k: p[k].grad for k in keys}
+                sst = AdamState.__new__(AdamState)
+                sst.step, sst.m, sst.v = st.step - 1, st.m, st.v
+                adamax_step(sub, g, sst, cur_lr, weight_decay=wd)
+            with torch.no_grad():
+                for k in p:
+                    if k.startswith("convex_net.") and k.endswith("ln.weight") and not k.startswith("convex_net.input"):
+                        p[k].copy_(F.relu(p[k]))
+            el += float(loss.item()) / len(batches)
+        epoch_losses.append(el)
+        if sched is not None:
+            cur_lr = sched.step(el)
+    return {k: v.detach() for k, v in p.items()}, epoch_losses

@@ -395,3 +395,37 @@ def test_accuracy_against_float64(dev, C, hid, F):
         e_ref.append(np.abs(g32[k] - g64[k]).max() / sc)
     assert max(e_hip) <= 4.0 * max(e_ref) + 2e-6, (max(e_hip), max(e_ref))
     assert np.median(e_hip) <= 4.0 * np.median(e_ref) + 5e-7, (np.median(e_hip), np.median(e_ref))
+
+
+def test_fit_sequence_minibatches(dev):
+    """_non_prior_based_pretrain semantics: one (x, y, t) network, one optimizer step per mini-batch of frames, plateau per
+    epoch - the host loop over `inrfit_pcn_fit(steps=1)` against the oracle's loop."""
+    from awesome_amd.model import real_nvp_path_connected_net
+    torch.manual_seed(2)
+    C, F, T, H, W = 3, 6, 4, 8, 10
+    m = real_nvp_path_connected_net(channels=3, hidden_units=32, flow_n_flows=F, flow_output_fn="tanh",
+                                    convex_net_hidden_units=130, convex_net_hidden_layers=1).to(dev)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith("net.2.weight") or k.endswith("net.2.bias"):
+                p.copy_(0.1 * torch.randn_like(p))
+        for a in m.flow_net.net.network.flows:
+            if hasattr(a, "data_dep_init_done"):
+                a.data_dep_init_done.fill_(1.0)   # keep s = t = 0: the ActNorm init is tested elsewhere
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()
+           if v.dtype == torch.float32 and not k.startswith("flow_net.norm") and not k.endswith("data_dep_init_done")}
+    frames = [O.positional_grid(W, H, float(t), float(T - 1)) for t in range(T)]
+    rows = [O.pixelize(g[None]) for g in frames]
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    uns = [(((yy - 4) ** 2 + (xx - 3 - t) ** 2) > 6).float().reshape(-1, 1) for t in range(T)]
+    masks = O.rnvp_masks(C, F)
+    pf, ref_losses = O.fit_pcn_minibatch(sd0, rows, uns, 3, 2, masks, torch.zeros(3), torch.ones(3), lr=2e-3, flow_weight_decay=1e-2,
+                                        plateau=dict(patience=0, factor=0.5))
+    coords = torch.stack([g.reshape(3, -1) for g in frames]).to(dev)
+    un_t = torch.stack([u.reshape(-1) for u in uns]).to(dev)
+    losses = m.fit_sequence(coords, un_t, num_epochs=3, lr=2e-3, flow_weight_decay=1e-2, batch_size=2,
+                            plateau=dict(patience=0, factor=0.5))
+    np.testing.assert_allclose(np.asarray(losses), np.asarray(ref_losses), rtol=5e-4)
+    got = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    for k in pf:
+        np.testing.assert_allclose(got[k].numpy(), pf[k].numpy(), rtol=5e-3, atol=3e-4, err_msg=k)
