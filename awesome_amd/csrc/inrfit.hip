@@ -972,7 +972,7 @@ RnvpMap make_rnvp_map(const InrRnvpDesc* r) {
     m.fl = m.HID * RNVP_REC + RNVP_TAIL;
     m.LDSF = RNVP_HDR + m.F * m.fl;
     m.HIDp = (m.HID + 63) / 64 * 64;
-    m.A = 2 * m.C - 1;
+    m.A = 2 * (m.C - 1);
     m.out_fn = r->output_fn;
     m.out_scale = r->output_fn ? (r->output_scale != 0.f ? r->output_scale : 1.f) : 1.f;
     for (int c = 0; c < 3; ++c) {
@@ -1123,6 +1123,7 @@ void launch_rnvp_bwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, i
     }
     RnvpUnitsArgs ua{};
     ua.RP = rp;
+    ua.zs = w.zs;
     ua.ps = w.ps;
     ua.slab2 = w.slab2;
     ua.N = grid->n_points;

@@ -41,7 +41,7 @@ struct RnvpMap {
     int fl;     // LDS floats per flow
     int LDSF;   // LDS floats of the whole image
     int HIDp;   // hidden units rounded up to 64 (row stride of the unit-gradient slabs)
-    int A;      // per-point arrays per flow in ps: zin [NIN] | do_s [NOUT] | do_t [NOUT]  (<= 2C - 1)
+    int A;      // per-point arrays per flow in ps: do_s [NOUT] | do_t [NOUT]  (<= 2(C - 1))
     int out_fn; // 0 = none, 1 = tanh
     float out_scale;
     float vmin[3], vmax[3], nmin, nmax;
@@ -391,7 +391,7 @@ struct RnvpBwdArgs {
     const float* RE;
     const float* dxd;   // [n_images][C][N]
     const float* zs;    // [n_images][F][C][N]
-    float* ps;          // [n_images][F][A][N]
+    float* ps;          // [n_images][F][A][N]: gradients at the MLP outputs (do_s | do_t) per point and flow
     float* slab1;       // [n_images][blocks][S1]; S1 = F*4C (b2s[C] b2t[C] as[C] at[C] per flow) + 2C (a, b)
     InrGridDesc grid;
     long long N;
@@ -500,10 +500,7 @@ __global__ __launch_bounds__(256) void rnvp_bwd_points_kernel(const RnvpBwdArgs 
             }
             if (valid[q]) {
                 float* pp = a.ps + (((size_t)img * F + f) * a.m.A) * N + p[q];
-                int r = 0;
-#pragma unroll
-                for (int mm = 0; mm < C - 1; ++mm)
-                    if (mm < x.nin) pp[(size_t)(r++) * N] = sel<C>(z[q], x.in(mm));
+                int r = 0;   // (the MLP inputs are not stored again: the unit kernel reads them from zs)
 #pragma unroll
                 for (int k = 0; k < C - 1; ++k)
                     if (k < x.nout) pp[(size_t)(r++) * N] = dos[k];
@@ -553,7 +550,8 @@ __global__ __launch_bounds__(256) void rnvp_bwd_points_kernel(const RnvpBwdArgs 
 // ---- backward, lane = hidden unit -----------------------------------------------------------------------------------------
 struct RnvpUnitsArgs {
     const float* RP;
-    const float* ps;     // [n_images][F][A][N]
+    const float* zs;     // [n_images][F][C][N] state in front of every flow (the MLP inputs are its masked channels)
+    const float* ps;     // [n_images][F][A][N] gradients at the MLP outputs: do_s [NOUT] | do_t [NOUT]
     float* slab2;        // [n_images][chunks][F*2][2C+1][64]  rows: dW1[:, c] (C) | db1 | dW2[c, :] (C)
     long long N;
     RnvpMap m;
@@ -582,6 +580,7 @@ __device__ __forceinline__ void rnvp_units_body(const RnvpUnitsArgs& a, const Fl
     int p1 = p0 + per_chunk;
     if (p1 > N) p1 = N;
     const float* __restrict__ base = a.ps + (((size_t)img * a.m.F + f) * a.m.A) * N;
+    const float* __restrict__ zbase = a.zs + (((size_t)img * a.m.F + f) * C) * N;
     f32x2 S0[UPW][NOUT], S1[UPW][NOUT][NIN];
 #pragma unroll
     for (int u = 0; u < UPW; ++u)
@@ -599,10 +598,10 @@ __device__ __forceinline__ void rnvp_units_body(const RnvpUnitsArgs& a, const Fl
             const int idx = p + q * 64 + lane;
             const bool in = idx < p1;   // do = 0 past the end: those points contribute nothing
 #pragma unroll
-            for (int mm = 0; mm < NIN; ++mm) zin[q][mm] = in ? base[(size_t)mm * N + idx] : 0.f;
+            for (int mm = 0; mm < NIN; ++mm) zin[q][mm] = in ? zbase[(size_t)x.in(mm) * N + idx] : 0.f;
 #pragma unroll
             for (int k = 0; k < NOUT; ++k) {
-                dd[q][k] = in ? f32x2{base[(size_t)(NIN + k) * N + idx], base[(size_t)(NIN + NOUT + k) * N + idx]} : f32x2{0.f, 0.f};
+                dd[q][k] = in ? f32x2{base[(size_t)k * N + idx], base[(size_t)(NOUT + k) * N + idx]} : f32x2{0.f, 0.f};
 #pragma unroll
                 for (int mm = 0; mm < NIN; ++mm) dz[q][k][mm] = dd[q][k] * f32x2{zin[q][mm], zin[q][mm]};
             }
