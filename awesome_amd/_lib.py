@@ -114,6 +114,8 @@ EXPORTS = {
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "inrfit_miou": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_void_p,
                               C.c_void_p]),
+    "inrfit_timing_begin": (C.c_int, [C.c_int]),
+    "inrfit_timing_end": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "inrfit_strerror": (C.c_char_p, [C.c_int]),
 }
 

@@ -26,6 +26,8 @@
 #include "flow.h"
 #include "rnvp.h"
 
+#include <vector>
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -515,6 +517,29 @@ static int launch_step(const KernelEntry* e, const Workspace& w, bool train, con
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 
+// ---- measurement hook: HIP events around single step-kernel launches while it is armed (bench.py) -------------------------
+struct StepTiming {
+    bool on = false;
+    int max_samples = 0;
+    std::vector<hipEvent_t> ev;   // pairs (before, after) around step-kernel launches
+    std::vector<hipEvent_t> evu;  // ... around update-kernel launches (inrfit_fit only)
+};
+static thread_local StepTiming g_timing;
+
+static int launch_step_timed(const KernelEntry* e, const Workspace& w, const InrGridDesc* grid, const float* targets, int loss_kind,
+                             int n_images, hipStream_t s) {
+    if (!g_timing.on || (int)g_timing.ev.size() >= 2 * g_timing.max_samples)
+        return launch_step(e, w, true, grid, targets, loss_kind, n_images, nullptr, s);
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return INR_ELAUNCH;
+    hipEventRecord(a, s);
+    const int rc = launch_step(e, w, true, grid, targets, loss_kind, n_images, nullptr, s);
+    hipEventRecord(b, s);
+    g_timing.ev.push_back(a);
+    g_timing.ev.push_back(b);
+    return rc;
+}
+
 static int check_loss(const InrLossDesc* l) {
     if (!l) return INR_EINVAL;
     if (l->kind != INR_LOSS_SE && l->kind != INR_LOSS_BCE && l->kind != INR_LOSS_EXTERNAL) return INR_EINVAL;
@@ -636,7 +661,47 @@ int inrfit_step_only(const InrModelDesc* model, const float* params, const InrGr
     hipLaunchKernelGGL(loss_coef_kernel, dim3(n_images), dim3(256), 0, s, targets, (long long)grid->n_points, *loss, w.coef);
     if ((rc = launch_pack(e, w, params, n_images, s))) return rc;
     for (int it = 0; it < iters; ++it)
-        if ((rc = launch_step(e, w, true, grid, targets, loss->kind, n_images, nullptr, s))) return rc;
+        if ((rc = launch_step_timed(e, w, grid, targets, loss->kind, n_images, s))) return rc;
+    return INR_OK;
+}
+
+static void timing_clear() {
+    for (hipEvent_t e : g_timing.ev) hipEventDestroy(e);
+    for (hipEvent_t e : g_timing.evu) hipEventDestroy(e);
+    g_timing.ev.clear();
+    g_timing.evu.clear();
+}
+
+static float timing_avg_us(const std::vector<hipEvent_t>& ev, int* n_out) {
+    double sum = 0.0;
+    int n = 0;
+    for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+        float ms = 0.f;
+        if (hipEventSynchronize(ev[i + 1]) == hipSuccess && hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) {
+            sum += ms;
+            ++n;
+        }
+    }
+    if (n_out) *n_out = n;
+    return n ? (float)(sum / n * 1e3) : 0.f;
+}
+
+int inrfit_timing_begin(int max_samples) {
+    if (max_samples <= 0) return INR_EINVAL;
+    timing_clear();
+    g_timing.on = true;
+    g_timing.max_samples = max_samples;
+    return INR_OK;
+}
+
+int inrfit_timing_end(float* avg_step_bracket_us, float* avg_update_bracket_us, int* n_samples) {
+    g_timing.on = false;
+    int n = 0;
+    const float su = timing_avg_us(g_timing.ev, &n), uu = timing_avg_us(g_timing.evu, nullptr);
+    timing_clear();
+    if (avg_step_bracket_us) *avg_step_bracket_us = su;
+    if (avg_update_bracket_us) *avg_update_bracket_us = uu;
+    if (n_samples) *n_samples = n;
     return INR_OK;
 }
 
@@ -661,12 +726,22 @@ int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const
     UpdArgs u = make_upd_args(e, w, params, opt_state, loss_hist, status, opt, n_images, steps);
     const dim3 ugrid = upd_grid(e->P, n_images), ublock = upd_block(e->P);
     for (int it = 0; it < steps; ++it) {
-        if ((rc = launch_step(e, w, true, grid, targets, loss->kind, n_images, nullptr, s))) return rc;
+        if ((rc = launch_step_timed(e, w, grid, targets, loss->kind, n_images, s))) return rc;
         u.t = step0 + it + 1;
         u.bc1 = 1.0 - pow((double)opt->beta1, (double)u.t);
         u.bc2_sqrt = (float)sqrt(1.0 - pow((double)opt->beta2, (double)u.t));
         u.hist_idx = it;
-        hipLaunchKernelGGL(icnn_update_kernel, ugrid, ublock, 0, s, u);
+        if (g_timing.on && (int)g_timing.evu.size() < 2 * g_timing.max_samples) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return INR_ELAUNCH;
+            hipEventRecord(a, s);
+            hipLaunchKernelGGL(icnn_update_kernel, ugrid, ublock, 0, s, u);
+            hipEventRecord(b, s);
+            g_timing.evu.push_back(a);
+            g_timing.evu.push_back(b);
+        } else {
+            hipLaunchKernelGGL(icnn_update_kernel, ugrid, ublock, 0, s, u);
+        }
     }
     if (hipGetLastError() != hipSuccess) return INR_ELAUNCH;
     if (final_logits) return launch_step(e, w, false, grid, nullptr, 0, n_images, final_logits, s);

@@ -329,6 +329,25 @@ def miou(out: Tensor, tgt: Tensor, thr_out: float = 0.5, thr_tgt: float = 0.5, i
     return res
 
 
+class step_kernel_brackets:
+    """Measurement hook (context manager): while active, `fit` and `step_only` bracket every step-kernel launch with HIP
+    events (`fit` also every update-kernel launch); `.avg_us` / `.update_avg_us` / `.samples` afterwards = average elapsed
+    time of a bracket (kernel + what the two event packets add)."""
+
+    def __init__(self, max_samples: int):
+        self.max_samples, self.avg_us, self.update_avg_us, self.samples = int(max_samples), 0.0, 0.0, 0
+
+    def __enter__(self):
+        L.check(L.load().inrfit_timing_begin(self.max_samples), "inrfit_timing_begin")
+        return self
+
+    def __exit__(self, *exc):
+        us, uu, n = C.c_float(0.0), C.c_float(0.0), C.c_int(0)
+        L.check(L.load().inrfit_timing_end(C.byref(us), C.byref(uu), C.byref(n)), "inrfit_timing_end")
+        self.avg_us, self.update_avg_us, self.samples = float(us.value), float(uu.value), int(n.value)
+        return False
+
+
 def pack_masks(values: Tensor, threshold: float = 0.5, invert: bool = False) -> Tensor:
     """[n_images, N] floats -> [n_images, ceil(N/64)] int64 words, bit i of word w = (values[w*64+i] > threshold) (complemented
     with `invert`): the bit-packed form of the mask the reference writes after evaluation (awesome/run/functions.py:2315-2361)."""

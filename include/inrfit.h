@@ -264,6 +264,14 @@ int inrfit_step_only(const InrModelDesc* model, const float* params, const InrGr
                      const InrLossDesc* loss, int n_images, int iters, void* workspace, int64_t workspace_bytes,
                      void* stream);
 
+/* Measurement hook (bench.py): between begin and end, inrfit_fit and inrfit_step_only calls of this thread bracket each of
+ * their (first max_samples) step-kernel launches - inrfit_fit also its update-kernel launches - with a pair of HIP events on
+ * the launch stream; end waits for them and returns the average elapsed time of a bracket in microseconds (0 if none).
+ * A bracket = the kernel + what the two event packets add to the sequence; bench.py removes that excess by comparing the sum
+ * of the two brackets with the un-instrumented time per optimizer step. */
+int inrfit_timing_begin(int max_samples);
+int inrfit_timing_end(float* avg_step_bracket_us, float* avg_update_bracket_us, int* n_samples);
+
 const char* inrfit_strerror(int code);
 
 #ifdef __cplusplus
