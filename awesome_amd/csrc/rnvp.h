@@ -794,11 +794,25 @@ __global__ __launch_bounds__(256) void rnvp_update_kernel(const RnvpUpdArgs u) {
     const float lr = u.lr_hdr ? u.lr_hdr[(size_t)img * u.hdr_stride + (u.t & 1)] : u.opt_desc.lr;
     // per-point-scalar gradients of this block: fixed-order sums over the point blocks
     const int k0 = f < F ? f * 4 * C : F * 4 * C, nk = f < F ? 4 * C : 2 * C;
-    for (int k = 0; k < nk; ++k) {
-        float part = 0.f;
-        for (int b = tid; b < u.blocks1; b += 256) part += u.slab1[((size_t)img * u.blocks1 + b) * u.S1 + k0 + k];
-        const float t = block_sum256(part, sm);
-        if (tid == 0) tot[k] = t;
+    {   // all nk sums at once: every thread walks its share of the point blocks for all scalars (their nk slots are adjacent
+        // in a slab row), then one wave reduction per scalar and a single pass through LDS - instead of nk block reductions
+        __shared__ float wsum[4][4 * 3];
+        float part[4 * C];
+#pragma unroll
+        for (int k = 0; k < 4 * C; ++k) part[k] = 0.f;
+        for (int b = tid; b < u.blocks1; b += 256) {
+            const float* __restrict__ row = u.slab1 + ((size_t)img * u.blocks1 + b) * u.S1 + k0;
+#pragma unroll
+            for (int k = 0; k < 4 * C; ++k)
+                if (k < nk) part[k] += row[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4 * C; ++k) {
+            const float v = sum_over_groups(sum_over_points(part[k]));
+            if ((tid & 63) == 0) wsum[tid >> 6][k] = v;
+        }
+        __syncthreads();
+        if (tid < nk) tot[tid] = ((wsum[0][tid] + wsum[1][tid]) + wsum[2][tid]) + wsum[3][tid];
     }
     __syncthreads();
     if (f == F && u.lossp != nullptr) {
