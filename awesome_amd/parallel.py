@@ -23,9 +23,18 @@ def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank,
-                                world_size=world)
+        # INRFIT_DIST_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, the
+        # few bytes of collectives travel over CPU tensors); the real run is "nccl" (= RCCL over xGMI), one rank per GPU
+        backend = backend or os.environ.get("INRFIT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def _coll_device(device):
+    """Where collective payloads must live: the caller's device under nccl, the CPU under gloo."""
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo":
+        return torch.device("cpu")
+    return device
 
 
 def shard_range(n_items: int, rank: int, world: int) -> range:
@@ -56,7 +65,7 @@ def barrier() -> None:
 def max_over_ranks(value: float, device=None) -> float:
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -67,8 +76,8 @@ def gather_per_image(local: torch.Tensor, n_total: int, rank: int, world: int) -
         return local
     sizes = [len(shard_range(n_total, r, world)) for r in range(world)]
     pad = max(sizes)
-    buf = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    buf = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=_coll_device(local.device))
     buf[: local.shape[0]] = local
     out = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(out, buf)
-    return torch.cat([o[:s] for o, s in zip(out, sizes)], 0)
+    return torch.cat([o[:s] for o, s in zip(out, sizes)], 0).to(local.device)

@@ -93,7 +93,7 @@ def main(cfg):
     if device.type != "cuda" or not torch.cuda.is_available():
         raise SystemExit("this entrypoint drives the MI355X path; no CPU fallback exists (use the reference for CPU runs)")
     if device.index is None:
-        device = torch.device("cuda", local)
+        device = torch.device("cuda", local % torch.cuda.device_count())   # (% only matters for a gloo rehearsal on one GPU)
     torch.cuda.set_device(device)
     seed = int(cfg.get("seed", 42))
     torch.manual_seed(seed)
