@@ -463,7 +463,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
                 for (int r = 0; r < 4; ++r) {
                     const float z2 = acc2[t][r];
                     const float dw = sum_over_points(dy * z2);   // over this wave's 16 points; one owner lane per row
-                    if (l15 == 0) accW[wave * PT + 16 * t + 4 * g + r] += dw;
+                    // ds_add_f32 without return: fire and forget (a read-modify-write here costs an LDS round trip per row);
+                    // the array is private to the wave and each row has one owner lane, so the sum order stays fixed
+                    if (l15 == 0) __hip_atomic_fetch_add(&accW[wave * PT + 16 * t + 4 * g + r], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     acc2[t][r] = z2 > 0.f ? dy * wo[t][r] : 0.f;  // dz2
                 }
             // ---- backward through layer 2 (W2 image): dz1 in the B-operand layout, masked by z1 -----------------------------
