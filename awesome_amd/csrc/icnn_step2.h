@@ -562,14 +562,22 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
 #pragma unroll
                             for (int r = 0; r < 4; ++r) part[r][c] = fmaf(w, dz0[t][r], part[r][c]);
                         }
+                    // lane (g, l15 = r) keeps the value of point 4g + r: C coalesced stores per wave instead of 4C masked ones
+                    float dxv[C];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int pp = chunk * SP + wave * 16 + 4 * g + r;
+                    for (int c = 0; c < C; ++c) dxv[c] = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int c = 0; c < C; ++c) {
-                            const float v = sum_over_points(part[r][c]) + __shfl(hx[c], 4 * g + r);
-                            if (l15 == 0 && pp < (int)N) a.dcoords[((size_t)img * C + c) * N + pp] = v;
+                            const float v = sum_over_points(part[r][c]);   // in every lane of the lane group
+                            dxv[c] = l15 == r ? v : dxv[c];
                         }
+                    const int pp = chunk * SP + wave * 16 + 4 * g + l15;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const float v = dxv[c] + __shfl(hx[c], 4 * g + l15);   // hx lives on lane (0, point)
+                        if (l15 < 4 && pp < (int)N) a.dcoords[((size_t)img * C + c) * N + pp] = v;
                     }
                 }
             }
