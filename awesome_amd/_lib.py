@@ -56,7 +56,7 @@ class InrOptDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("weight_decay", C.c_float), ("clamp", C.c_int32), ("plateau", C.c_int32), ("plateau_patience", C.c_int32),
                 ("plateau_factor", C.c_float), ("plateau_threshold", C.c_float), ("plateau_min_lr", C.c_float),
-                ("plateau_eps", C.c_float)]
+                ("plateau_eps", C.c_float), ("freeze_skips", C.c_int32)]
 
 
 EXPORTS = {

@@ -52,6 +52,7 @@ struct UpdArgs {
     int hist_idx, hist_stride;
     int mode;             // 0 = optimizer step, 1 = write reduced grads + loss only
     int clamp_lo[3], clamp_hi[3];  // flat ranges projected onto >= 0 (ln.weight of every hidden layer, out.ln.weight)
+    int freeze_lo[3], freeze_hi[3];  // flat ranges that are never updated (the skip weights when opt.freeze_skips)
 };
 
 constexpr int UPD_MAX_PARAMS = 256;  // most parameters per block
@@ -150,6 +151,11 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
         return;
     }
     if (bad_before || !isfinite(gsum)) return;
+    if (u.opt.freeze_skips) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (j >= u.freeze_lo[k] && j < u.freeze_hi[k]) return;
+    }
 
     const float lr = lr_now;
     float p = p_old, m = m_old, v = v_old;
@@ -574,6 +580,13 @@ static UpdArgs make_upd_args(const KernelEntry* e, const Workspace& w, float* pa
     }
     u.clamp_lo[2] = e->img.p_wo;
     u.clamp_hi[2] = e->img.p_wo + e->img.H;
+    for (int k = 0; k < 3; ++k) u.freeze_lo[k] = u.freeze_hi[k] = 0;
+    for (int k = 0; k < e->img.L; ++k) {
+        u.freeze_lo[k] = e->img.p_s[k];
+        u.freeze_hi[k] = e->img.p_s[k] + e->img.H * e->img.C;
+    }
+    u.freeze_lo[2] = e->img.p_so;
+    u.freeze_hi[2] = e->img.p_so + e->img.C;
     return u;
 }
 

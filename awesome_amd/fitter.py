@@ -49,6 +49,7 @@ class BatchedPriorFitter:
         probe = model_factory()
         self.spec: K.IcnnSpec = probe.spec
         self._convexnet_keys = hasattr(probe, "W0y")
+        self._fit_options = dict(getattr(probe, "fit_options", None) or dict(clamp=True))   # FCNet: no clamp, skips frozen at 0
 
     # -- helpers --------------------------------------------------------------------------------------------------
     def fresh_params(self, n: int, device) -> torch.Tensor:
@@ -58,7 +59,7 @@ class BatchedPriorFitter:
     def _run(self, params, grid, unaries, epochs):
         return K.fit(self.spec, params, grid, unaries, epochs, lr=self.lr, loss=self.loss_kind, weight_mode=self.weight_mode,
                      ratio=self.ratio, optimizer=self.optimizer, betas=self.betas, eps=self.eps,
-                     weight_decay=self.weight_decay, clamp=True, plateau=self.plateau, record_loss=True, want_logits=True)
+                     weight_decay=self.weight_decay, plateau=self.plateau, record_loss=True, want_logits=True, **self._fit_options)
 
     # -- independent images (no warm-start chain): one batched device fit + batched retries ---------------------------
     def fit_batch(self, grid: K.Grid, unaries: torch.Tensor, init_params: Optional[torch.Tensor] = None,
@@ -136,7 +137,10 @@ class BatchedPriorFitter:
         for k in range(report.params.shape[0]):
             if report.skipped[k]:
                 continue
-            sd = K.unpack_params(self.spec, report.params[k].cpu(), convexnet_keys=self._convexnet_keys)
+            if hasattr(probe, "unpack_flat"):
+                sd = probe.unpack_flat(report.params[k].cpu())
+            else:
+                sd = K.unpack_params(self.spec, report.params[k].cpu(), convexnet_keys=self._convexnet_keys)
             cache[str(indices[k] if indices is not None else k)] = sd
         return {"model_type": model_type or f"{type(probe).__module__}.{type(probe).__name__}",
                 "model_args": json.dumps(model_args or {}), "store_device": "cpu", "cache": cache}

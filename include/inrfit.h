@@ -98,6 +98,9 @@ typedef struct InrOptDesc {
     int32_t plateau;
     int32_t plateau_patience;
     float plateau_factor, plateau_threshold, plateau_min_lr, plateau_eps;
+    int32_t freeze_skips; /* 1: no skp.weight (incl. out.skp) is ever updated.  With zero skips and clamp = 0 the ICNN is the plain
+                             relu MLP Linear(C,h) [Linear(h,h)]xL Linear(h,1) = FCNet(in_type='xy') (awesome/model/fc_net.py:10-59),
+                             the "no prior" coordinate network of configs[0]. */
 } InrOptDesc;
 
 /* Per-image optimizer state, `opt_state` = n_images * inrfit_opt_state_floats(model) floats:

@@ -633,3 +633,26 @@ def fit_pcn_minibatch(sd0: Dict[str, Tensor], frame_rows: Sequence[Tensor], fram
         if sched is not None:
             cur_lr = sched.step(el)
     return {k: v.detach() for k, v in p.items()}, epoch_losses
+
+
+def fcnet_forward(sd: Dict[str, Tensor], rows: Tensor) -> Tensor:
+    """FCNet(in_type='xy').forward (awesome/model/fc_net.py:44-59): Linear, ReLU, depth x [Linear, ReLU], Linear on rows (N, C).
+    Keys: model.0.*, model.{2+k}.0.*, model.{2+depth}.*."""
+    depth = sum(1 for k in sd if k.endswith(".0.weight") and k.count(".") == 3)
+    h = F.relu(F.linear(rows, sd["model.0.weight"], sd["model.0.bias"]))
+    for k in range(depth):
+        h = F.relu(F.linear(h, sd[f"model.{2 + k}.0.weight"], sd[f"model.{2 + k}.0.bias"]))
+    return F.linear(h, sd[f"model.{2 + depth}.weight"], sd[f"model.{2 + depth}.bias"])
+
+
+def fcnet_as_icnn(sd: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """The same network in ConvexNextNet keys with zero skip weights (what the HIP kernels evaluate)."""
+    depth = sum(1 for k in sd if k.endswith(".0.weight") and k.count(".") == 3)
+    h, c = sd["model.0.weight"].shape
+    out = {"input.weight": sd["model.0.weight"], "input.bias": sd["model.0.bias"]}
+    for k in range(depth):
+        out[f"skip.{k}.ln.weight"], out[f"skip.{k}.ln.bias"] = sd[f"model.{2 + k}.0.weight"], sd[f"model.{2 + k}.0.bias"]
+        out[f"skip.{k}.skp.weight"] = torch.zeros(h, c)
+    out["out.ln.weight"], out["out.ln.bias"] = sd[f"model.{2 + depth}.weight"], sd[f"model.{2 + depth}.bias"]
+    out["out.skp.weight"] = torch.zeros(1, c)
+    return out

@@ -29,6 +29,7 @@ ALIASES = {
     "awesome.model.convex_diffeomorphism_net.ConvexDiffeomorphismNet": "awesome_amd.model.ConvexDiffeomorphismNet",
     "awesome.model.net_factory.real_nvp_path_connected_net": "awesome_amd.model.real_nvp_path_connected_net",
     "awesome.model.path_connected_net.PathConnectedNet": "awesome_amd.model.PathConnectedNet",
+    "awesome.model.fc_net.FCNet": "awesome_amd.model.FCNet",
     "awesome.measures.se.SE": "awesome_amd.measures.SE",
     "awesome.measures.unaries_weighted_loss.UnariesWeightedLoss": "awesome_amd.measures.UnariesWeightedLoss",
 }

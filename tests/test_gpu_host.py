@@ -134,3 +134,35 @@ def test_wrapper_module_joint_step(dev):
     assert seg.shape == (1, H, W) and pr.shape == (1, H, W)
     w.evaluate_prior = False
     assert w(seg_logits.to(dev), torch.zeros(1, 1, H, W, device=dev), grid.to(dev)).shape == (1, 1, H, W)
+
+
+@pytest.mark.parametrize("name,width,depth", [("fcnet_w130_d1", 130, 1), ("fcnet_w64_d2", 64, 2)])
+def test_fcnet_no_prior_network_on_hip(golden_dir, name, width, depth):
+    """FCNet(in_type='xy') on the ICNN kernels (zero skips, frozen; no clamp): forward, autograd gradients and a 10-step Adam
+    trajectory against the reference class' golden vectors."""
+    import awesome_amd as A
+    from awesome_amd.model import FCNet
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    m = FCNet(in_chn=2, out_chn=1, width=width, depth=depth, in_type="xy")
+    m.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")})
+    m = m.to(dev)
+    rows, un = torch.from_numpy(z["rows"]).to(dev), torch.from_numpy(z["unaries"]).to(dev)
+    y = m(None, rows)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), z["logits"], rtol=1e-4, atol=5e-6)
+    loss = ((un - torch.sigmoid(y)) ** 2).mean()
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(z["loss"]), rel=1e-5)
+    for k, p in m.named_parameters():
+        ref = z["grad." + k]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * float(np.abs(ref).max()) + 1e-9, err_msg=k)
+    # the fused fit with the skips frozen at zero and no clamp = the reference's Adam loop
+    res = A.fit(m.spec, m.flat_parameters()[None].to(dev), A.Grid.explicit(rows.t().contiguous()), un.reshape(1, -1), 10, lr=2e-3,
+                loss="se", optimizer="adam", **FCNet.fit_options)
+    np.testing.assert_allclose(res.loss_hist[0].cpu().numpy(), z["adam10.losses"], rtol=2e-4)
+    got = m.unpack_flat(res.params[0].cpu())
+    for k, v in got.items():
+        np.testing.assert_allclose(v.numpy(), z["adam10." + k], rtol=2e-4, atol=2e-6, err_msg=k)
+    flat = res.params[0].cpu()
+    sd_i = A.unpack_params(m.spec, flat)
+    assert all(float(sd_i[k].abs().max()) == 0.0 for k in sd_i if k.endswith("skp.weight"))   # never moved

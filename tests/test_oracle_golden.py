@@ -154,3 +154,32 @@ def test_awesome_loss_pixel_mode(golden_dir):
     assert float(crit(out, tgt)) == pytest.approx(float(z["al.plain"]), rel=1e-6)
     crit.extra_penalty = True
     assert float(crit(out, tgt)) == pytest.approx(float(z["al.penalty"]), rel=1e-6)
+
+
+@pytest.mark.parametrize("name", ["fcnet_w130_d1", "fcnet_w64_d2"])
+def test_fcnet_no_prior_network(golden_dir, name):
+    """FCNet(in_type='xy'): the oracle's forward, its ICNN-with-zero-skips form, gradients and a 10-step Adam trajectory
+    (no clamp) against the reference class."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    sd = O.load_npz_state(z, "sd.")
+    rows, un = torch.from_numpy(z["rows"]), torch.from_numpy(z["unaries"])
+    np.testing.assert_allclose(O.fcnet_forward(sd, rows).numpy(), z["logits"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(O.icnn_forward(O.fcnet_as_icnn(sd), rows).numpy(), z["logits"], rtol=1e-5, atol=1e-6)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss = ((un - torch.sigmoid(O.fcnet_forward(p, rows))) ** 2).mean()
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(z["loss"]), rel=1e-6)
+    for k in p:
+        np.testing.assert_allclose(p[k].grad.numpy(), z["grad." + k], rtol=1e-4, atol=1e-7, err_msg=k)
+    st = O.AdamState(p)
+    losses = []
+    for _ in range(10):
+        for v in p.values():
+            v.grad = None
+        l = ((un - torch.sigmoid(O.fcnet_forward(p, rows))) ** 2).mean()
+        l.backward()
+        O.adam_step(p, {k: v.grad for k, v in p.items()}, st, 2e-3)
+        losses.append(float(l.detach()))
+    np.testing.assert_allclose(np.asarray(losses, np.float32), z["adam10.losses"], rtol=1e-5)
+    for k in p:
+        np.testing.assert_allclose(p[k].detach().numpy(), z["adam10." + k], rtol=1e-4, atol=1e-6, err_msg=k)

@@ -34,6 +34,7 @@ def _import_reference():
         sys.modules[f"awesome.{sub}"] = pkg
     import awesome.model.convex_net as convex_net
     import awesome.model.diffeomorphism_net as diffeo
+    import awesome.model.fc_net as fc_net
     import awesome.model.real_nvp.resnet_1d as resnet_1d
     import awesome.measures.se as se
     import awesome.measures.unaries_weighted_loss as uwl
@@ -42,7 +43,7 @@ def _import_reference():
     import awesome.measures.awesome_loss as al
     import awesome.dataset.transformator as transformator
     import awesome.transforms.min_max as min_max
-    return types.SimpleNamespace(convex_net=convex_net, diffeo=diffeo, resnet_1d=resnet_1d, se=se, uwl=uwl,
+    return types.SimpleNamespace(convex_net=convex_net, diffeo=diffeo, fc_net=fc_net, resnet_1d=resnet_1d, se=se, uwl=uwl,
                                  miou=miou, ail=ail, al=al, transformator=transformator, min_max=min_max)
 
 
@@ -314,6 +315,37 @@ def gen_pixel_losses(ref, out):
     print("wrote pixel_losses", sorted(rec))
 
 
+def gen_fcnet(ref, out):
+    """FCNet(in_type='xy') (awesome/model/fc_net.py:10-59), the "no prior" coordinate network: logits on a 16x16 grid, loss +
+    gradients of SE(sigmoid(f), u), parameters after 10 Adam steps (lr 2e-3, no clamp)."""
+    for width, depth in ((130, 1), (64, 2)):
+        seed_all(21 + depth)
+        net = ref.fc_net.FCNet(in_chn=2, out_chn=1, width=width, depth=depth, in_type="xy")
+        rec = sd_np(net)
+        ys, xs = torch.meshgrid(torch.linspace(0, 1, 16), torch.linspace(0, 1, 16), indexing="ij")
+        rows = torch.stack((xs, ys), -1).reshape(-1, 2).float()
+        un = torch.from_numpy(blob_unaries(16, 16, 3)).reshape(-1, 1)
+        rec["rows"], rec["unaries"] = rows.numpy(), un.numpy()
+        y = net(None, rows)
+        rec["logits"] = y.detach().numpy()
+        loss = ((un - torch.sigmoid(y)) ** 2).mean()
+        loss.backward()
+        rec["loss"] = loss.detach().numpy()
+        rec.update(grads_np(net))
+        opt = torch.optim.Adam(net.parameters(), lr=2e-3)
+        losses = []
+        for _ in range(10):
+            opt.zero_grad()
+            l = ((un - torch.sigmoid(net(None, rows))) ** 2).mean()
+            l.backward()
+            opt.step()
+            losses.append(float(l.item()))
+        rec["adam10.losses"] = np.asarray(losses, np.float32)
+        rec.update(sd_np(net, prefix="adam10."))
+        np.savez_compressed(os.path.join(out, f"fcnet_w{width}_d{depth}.npz"), **rec)
+    print("wrote fcnet")
+
+
 def gen_minmax(ref, out):
     """MinMax as NormNet uses it around the RealNVP flow of PathConnectedNet (awesome/transforms/min_max.py:22-61;
     net_factory.py:160-162: MinMax(dim=(0, 2, 3)) fitted on the normalized grid, new range [-1, 1])."""
@@ -349,6 +381,7 @@ def main():
     gen_fit_disc(ref, out)
     gen_minmax(ref, out)
     gen_pixel_losses(ref, out)
+    gen_fcnet(ref, out)
     with open(os.path.join(out, "PROVENANCE.txt"), "w") as f:
         f.write("Generated by tools/gen_golden.py from jp-schneider/awesome @ 2024_08_07 (reference classes imported on CPU),\n")
         f.write(f"torch {torch.__version__}, numpy {np.__version__}.\n")
