@@ -429,3 +429,33 @@ def test_fit_sequence_minibatches(dev):
     got = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     for k in pf:
         np.testing.assert_allclose(got[k].numpy(), pf[k].numpy(), rtol=5e-3, atol=3e-4, err_msg=k)
+
+
+def test_batch_of_images_equals_single_fits(dev):
+    """Independent images in one call: every image's result equals its own single-image fit (separable grid, C = 2) and
+    an (x, y, t) batch with per-image explicit grids works the same way."""
+    from awesome_amd import rnvp as R
+    import awesome_amd as A
+    ispec, rspec, sd = _case(2, 32, 12, 2, seed=51)
+    H, W = 16, 24
+    ip, fp = _split(ispec, rspec, sd, dev)
+    torch.manual_seed(3)
+    un = (torch.rand(3, H * W) > 0.5).float().to(dev)
+    grid = A.Grid.linspace(W, H, dev)
+    kw = dict(lr=2e-3, flow_weight_decay=1e-3, plateau=dict(patience=2, factor=0.5))
+    res = R.pcn_fit(ispec, rspec, ip.repeat(3, 1).contiguous(), fp.repeat(3, 1).contiguous(), grid, un, 8, **kw)
+    for i in range(3):
+        one = R.pcn_fit(ispec, rspec, ip.clone(), fp.clone(), grid, un[i:i + 1].contiguous(), 8, **kw)
+        np.testing.assert_allclose(res.loss_hist[i].cpu().numpy(), one.loss_hist[0].cpu().numpy(), rtol=1e-5)
+        np.testing.assert_allclose(res.flow_params[i].cpu().numpy(), one.flow_params[0].cpu().numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(res.icnn_params[i].cpu().numpy(), one.icnn_params[0].cpu().numpy(), rtol=1e-4, atol=1e-6)
+    # (x, y, t): per-image explicit grids
+    ispec3, rspec3, sd3 = _case(3, 32, 6, 1, seed=52)
+    ip3, fp3 = _split(ispec3, rspec3, sd3, dev)
+    coords = torch.stack([_rows(3, H, W, t)[0].reshape(3, -1) for t in (0.2, 0.9)]).to(dev)
+    un3 = (torch.rand(2, H * W) > 0.5).float().to(dev)
+    both = R.pcn_fit(ispec3, rspec3, ip3.repeat(2, 1).contiguous(), fp3.repeat(2, 1).contiguous(), A.Grid.explicit(coords), un3, 5, **kw)
+    for i in range(2):
+        one = R.pcn_fit(ispec3, rspec3, ip3.clone(), fp3.clone(), A.Grid.explicit(coords[i].contiguous()), un3[i:i + 1].contiguous(), 5, **kw)
+        np.testing.assert_allclose(both.loss_hist[i].cpu().numpy(), one.loss_hist[0].cpu().numpy(), rtol=1e-5)
+        np.testing.assert_allclose(both.flow_params[i].cpu().numpy(), one.flow_params[0].cpu().numpy(), rtol=1e-4, atol=1e-6)
