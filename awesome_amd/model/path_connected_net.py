@@ -351,6 +351,50 @@ class PathConnectedNet(nn.Module):
                          weight_mode=weight_mode, flow_weight_decay=flow_weight_decay,
                          plateau=dict(patience=200, factor=0.5) if plateau is None else (plateau or None))
 
+    def fit_frames(self, grid: "K.Grid", frame_unaries: torch.Tensor, num_epochs: int = 2000, reuse_state: bool = True,
+                   reuse_state_epochs: int = 200, proper_prior_fit_threshold: float = 0.5, proper_prior_fit_retrys: int = 1,
+                   model_factory=None, **fit_kwargs):
+        """_prior_based_pretrain over the frames of ONE sequence with one prior per frame (path_connected_net.py:803-1001): frame
+        0 is fitted from this module's state for `num_epochs` (incl. the pre-fit stages if requested in fit_kwargs); with
+        `reuse_state` every later frame starts from the previous properly fitted frame's parameters and trains
+        `reuse_state_epochs` (:867-870, 899-908); a frame whose fg-IoU against its unaries stays below the threshold is
+        re-fitted from a fresh model for `num_epochs`, up to `proper_prior_fit_retrys` times (:964-985; the fresh model comes
+        from `model_factory`, default: a new real_nvp_path_connected_net with this module's sizes).  frame_unaries [T, N] on the
+        device.  Returns (icnn_params [T, P], flow_params [T, RP], iou [T], retries)."""
+        from .. import icnn as KK
+        T, dev = frame_unaries.shape[0], frame_unaries.device
+        ispec, rspec = self._specs()
+        if model_factory is None:
+            nf = self.flow_net.net.network
+            model_factory = lambda: real_nvp_path_connected_net(  # noqa: E731
+                channels=self.in_channels, hidden_units=rspec.hidden_units, flow_n_flows=rspec.n_flows,
+                flow_output_fn=getattr(nf, "output_fn", None), flow_output_scale=getattr(nf, "output_scale", None),
+                convex_net_hidden_units=ispec.n_hidden, convex_net_hidden_layers=ispec.n_layers).to(dev)
+        prefit = {k: v for k, v in fit_kwargs.items() if k.startswith("prefit_")}
+        plain = {k: v for k, v in fit_kwargs.items() if not k.startswith("prefit_")}
+        out_i, out_f, ious, retries = [], [], [], []
+        prev = None
+        for t in range(T):
+            un = frame_unaries[t:t + 1].contiguous()
+            if reuse_state and prev is not None:
+                res = R.pcn_fit(ispec, rspec, prev[0].clone(), prev[1].clone(), grid, un, reuse_state_epochs,
+                                plateau=dict(patience=200, factor=0.5), **{k: v for k, v in plain.items() if k != "plateau"})
+            else:
+                res = self.fit_images(grid, un, num_epochs=num_epochs, **fit_kwargs)
+            iou = float(KK.miou(torch.sigmoid(res.logits), un)[0])
+            n_retry = 0
+            while iou < proper_prior_fit_threshold and n_retry < proper_prior_fit_retrys:
+                res = model_factory().fit_images(grid, un, num_epochs=num_epochs, **plain, **prefit)
+                iou = float(KK.miou(torch.sigmoid(res.logits), un)[0])
+                n_retry += 1
+            if iou >= proper_prior_fit_threshold:
+                prev = (res.icnn_params, res.flow_params)   # only a proper fit is handed on (:987-994)
+            out_i.append(res.icnn_params[0])
+            out_f.append(res.flow_params[0])
+            ious.append(iou)
+            retries.append(n_retry)
+        return torch.stack(out_i), torch.stack(out_f), torch.tensor(ious), retries
+
     def fit_sequence(self, frame_coords: torch.Tensor, frame_unaries: torch.Tensor, num_epochs: int = 2000, lr: float = 1e-3,
                      flow_weight_decay: float = 1e-5, batch_size: int = 1, dataloader_shuffle: bool = False, loss: str = "se",
                      weight_mode: str = "none", optimizer: str = "adamax", plateau=None, generator=None):

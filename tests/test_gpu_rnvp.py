@@ -459,3 +459,26 @@ def test_batch_of_images_equals_single_fits(dev):
         one = R.pcn_fit(ispec3, rspec3, ip3.clone(), fp3.clone(), A.Grid.explicit(coords[i].contiguous()), un3[i:i + 1].contiguous(), 5, **kw)
         np.testing.assert_allclose(both.loss_hist[i].cpu().numpy(), one.loss_hist[0].cpu().numpy(), rtol=1e-5)
         np.testing.assert_allclose(both.flow_params[i].cpu().numpy(), one.flow_params[0].cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_fit_frames_warm_start(dev):
+    """reuse_state chain of _prior_based_pretrain: frame 1 starts from frame 0's fit and needs only a few epochs."""
+    import awesome_amd as A
+    from awesome_amd.model import real_nvp_path_connected_net
+    torch.manual_seed(0)
+    S = 48
+    yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+
+    def frame(dx):
+        m = (((yy - 16) ** 2 + (xx - 14 - dx) ** 2) < 60) | (((yy - 32) ** 2 + (xx - 32 - dx) ** 2) < 60) | \
+            (((yy - 16).abs() < 3) & (xx >= 14 + dx) & (xx <= 32 + dx)) | (((xx - 32 - dx).abs() < 3) & (yy >= 16) & (yy <= 32))
+        return 1.0 - m.float().reshape(-1)
+
+    un = torch.stack([frame(0), frame(2), frame(4)]).to(dev)
+    grid = A.Grid.linspace(S, S, dev)
+    m = real_nvp_path_connected_net(channels=2, hidden_units=32, flow_n_flows=12, flow_output_fn="tanh").to(dev)
+    ip, fp, iou, retries = m.fit_frames(grid, un, num_epochs=1200, reuse_state_epochs=150, lr=2e-3,
+                                        prefit_flow_net_identity=True, prefit_convex_net=True)
+    assert ip.shape[0] == 3 and fp.shape[0] == 3
+    assert float(iou.min()) > 0.85, iou
+    assert retries == [0, 0, 0]
