@@ -538,9 +538,9 @@ static int launch_step_timed(const KernelEntry* e, const Workspace& w, const Inr
         return launch_step(e, w, true, grid, targets, loss_kind, n_images, nullptr, s);
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return INR_ELAUNCH;
-    hipEventRecord(a, s);
+    (void)hipEventRecord(a, s);
     const int rc = launch_step(e, w, true, grid, targets, loss_kind, n_images, nullptr, s);
-    hipEventRecord(b, s);
+    (void)hipEventRecord(b, s);
     g_timing.ev.push_back(a);
     g_timing.ev.push_back(b);
     return rc;
@@ -679,8 +679,8 @@ int inrfit_step_only(const InrModelDesc* model, const float* params, const InrGr
 }
 
 static void timing_clear() {
-    for (hipEvent_t e : g_timing.ev) hipEventDestroy(e);
-    for (hipEvent_t e : g_timing.evu) hipEventDestroy(e);
+    for (hipEvent_t e : g_timing.ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g_timing.evu) (void)hipEventDestroy(e);
     g_timing.ev.clear();
     g_timing.evu.clear();
 }
@@ -747,9 +747,9 @@ int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const
         if (g_timing.on && (int)g_timing.evu.size() < 2 * g_timing.max_samples) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return INR_ELAUNCH;
-            hipEventRecord(a, s);
+            (void)hipEventRecord(a, s);
             hipLaunchKernelGGL(icnn_update_kernel, ugrid, ublock, 0, s, u);
-            hipEventRecord(b, s);
+            (void)hipEventRecord(b, s);
             g_timing.evu.push_back(a);
             g_timing.evu.push_back(b);
         } else {
