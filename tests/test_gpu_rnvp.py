@@ -482,3 +482,30 @@ def test_fit_frames_warm_start(dev):
     assert ip.shape[0] == 3 and fp.shape[0] == 3
     assert float(iou.min()) > 0.85, iou
     assert retries == [0, 0, 0]
+
+
+@pytest.mark.parametrize("C,H,W", [(2, 1, 5), (3, 3, 1)])
+def test_tiny_grids(dev, C, H, W):
+    """Fewer points than one wave: forward, gradients and a few fit steps still match the oracle."""
+    from awesome_amd import rnvp as R
+    import awesome_amd as A
+    F = 4
+    ispec, rspec, sd = _case(C, 32, F, 1, seed=61 + C)
+    grid_t, rows = _rows(C, H, W, 0.3)
+    un = torch.rand(H * W, 1)
+    masks = O.rnvp_masks(C, F)
+    vmin, vmax = torch.tensor(rspec.vmin), torch.tensor(rspec.vmax)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lo = O.weighted_loss(torch.sigmoid(O.pcn_forward(sdo, rows, masks, vmin, vmax)).reshape(1, 1, -1, 1), un.reshape(1, 1, -1, 1), "se")
+    lo.backward()
+    ip, fp = _split(ispec, rspec, sd, dev)
+    grid = A.Grid.from_image_grid(grid_t.to(dev))
+    loss, gi, gf = R.pcn_loss_grad(ispec, rspec, ip, fp, grid, un.reshape(1, -1).to(dev), loss="se")
+    assert float(loss[0]) == pytest.approx(float(lo.detach()), rel=3e-5)
+    got = _merge(ispec, rspec, gi[0].cpu(), gf[0].cpu())
+    for k in sdo:
+        ref = sdo[k].grad.numpy()
+        np.testing.assert_allclose(got[k].numpy(), ref, rtol=1e-3, atol=3e-5 * float(np.abs(ref).max()) + 1e-7, err_msg=k)
+    pf, losses, _ = O.fit_pcn(sd, rows, un, 4, masks, vmin, vmax, lr=2e-3, flow_weight_decay=1e-3)
+    res = R.pcn_fit(ispec, rspec, ip, fp, grid, un.reshape(1, -1).to(dev), 4, lr=2e-3, flow_weight_decay=1e-3)
+    np.testing.assert_allclose(res.loss_hist[0].cpu().numpy(), np.asarray(losses, np.float32), rtol=5e-4)
