@@ -1169,8 +1169,8 @@ void launch_rnvp_pack(const PcnWs& w, const float* rp, int n_images, hipStream_t
 }
 
 void launch_rnvp_fwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, int n_images, float* out, bool keep, hipStream_t s,
-                     bool unit_linear = false) {
-    launch_rnvp_pack(w, rp, n_images, s, unit_linear);
+                     bool unit_linear = false, bool packed = false) {
+    if (!packed) launch_rnvp_pack(w, rp, n_images, s, unit_linear);   // (in the fit loops the update kernel refreshes the image)
     RnvpFwdArgs a{};
     a.RE = w.RE;
     a.xd = out;
@@ -1363,13 +1363,15 @@ int inrfit_rnvp_fit_identity(const InrRnvpDesc* rnvp, float* flow_params, float*
     ia.N = grid->n_points;
     const dim3 gl(w.blocksL, n_images);
     for (int it = 0; it < steps; ++it) {
-        launch_rnvp_fwd(w, flow_params, grid, n_images, w.xd, true, s, true);
+        launch_rnvp_fwd(w, flow_params, grid, n_images, w.xd, true, s, true, it > 0);
         if (C == 2) hipLaunchKernelGGL(rnvp_identity_loss_kernel<2>, gl, dim3(256), 0, s, ia);
         else hipLaunchKernelGGL(rnvp_identity_loss_kernel<3>, gl, dim3(256), 0, s, ia);
         launch_rnvp_bwd(w, flow_params, grid, n_images, s);
         RnvpUpdArgs u = make_rnvp_upd_args(w, n_images, 0, flow_params, flow_opt_state, nullptr, opt, opt->weight_decay,
                                            step0 + it + 1, nullptr, 0, nullptr);
         u.skip_linear = 1;
+        u.RE = w.RE;
+        u.unit_linear = 1;
         u.lossp = w.lossp;
         u.lossp_blocks = w.blocksL;
         u.loss_scale = 1.f / ((float)C * (float)grid->n_points);
@@ -1439,7 +1441,7 @@ int inrfit_pcn_fit(const InrModelDesc* model, const InrRnvpDesc* rnvp, float* ic
     const dim3 ugrid = upd_grid(e->P, n_images), ublock = upd_block(e->P);
     const long long hdr_stride = 2 * (long long)e->P + INR_OPT_HEADER_FLOATS;
     for (int it = 0; it < steps; ++it) {
-        launch_rnvp_fwd(w, flow_params, grid, n_images, w.xd, true, s);
+        launch_rnvp_fwd(w, flow_params, grid, n_images, w.xd, true, s, false, it > 0);
         if ((rc = launch_step(e, w.icnn, true, &w.dgrid, targets, loss->kind, n_images, nullptr, s, w.dxd))) return rc;
         u.t = step0 + it + 1;
         u.bc1 = 1.0 - pow((double)opt->beta1, (double)u.t);
@@ -1448,8 +1450,10 @@ int inrfit_pcn_fit(const InrModelDesc* model, const InrRnvpDesc* rnvp, float* ic
         hipLaunchKernelGGL(icnn_update_kernel, ugrid, ublock, 0, s, u);
         launch_rnvp_bwd(w, flow_params, grid, n_images, s);
         // the learning rate of THIS step sits in header[t & 1] (the plateau thread wrote the next one into the other slot)
-        launch_rnvp_update(w, n_images, 0, flow_params, flow_opt_state, nullptr, opt, flow_weight_decay, u.t,
-                           icnn_opt_state + 2 * (size_t)e->P, hdr_stride, status, s);
+        RnvpUpdArgs ru = make_rnvp_upd_args(w, n_images, 0, flow_params, flow_opt_state, nullptr, opt, flow_weight_decay, u.t,
+                                            icnn_opt_state + 2 * (size_t)e->P, hdr_stride, status);
+        ru.RE = w.RE;
+        launch_rnvp_update_args(w, n_images, ru, s);
     }
     if (hipGetLastError() != hipSuccess) return INR_ELAUNCH;
     if (final_logits) {

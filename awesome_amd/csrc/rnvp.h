@@ -758,6 +758,8 @@ struct RnvpUpdArgs {
     float loss_scale;
     float* loss_hist;     // [n_images][hist_stride] or null
     int hist_idx, hist_stride;
+    float* RE;            // [n_images][LDSF] packed image to refresh after the step (mode 0), or null
+    int unit_linear;      // header of RE with a = 1, b = 0 (learn_flow_identity)
 };
 
 __device__ __forceinline__ float opt_apply(const RnvpUpdArgs& u, float p, float g, float lr, float wd, float* m_, float* v_) {
@@ -821,7 +823,14 @@ __global__ __launch_bounds__(256) void rnvp_update_kernel(const RnvpUpdArgs u) {
         const float t = block_sum256(part, sm);
         if (tid == 0 && u.loss_hist) u.loss_hist[(size_t)img * u.hist_stride + u.hist_idx] = t * u.loss_scale;
     }
-    if (f == F && u.skip_linear) return;
+    if (f == F && u.skip_linear) {
+        if (u.mode == 0 && u.RE != nullptr) {
+            float* re = u.RE + (size_t)img * m.LDSF;
+            rnvp_header_image<C>(rp, re);
+            if (u.unit_linear && tid < 6) re[tid] = tid < 3 ? (tid < C ? 1.f : 0.f) : 0.f;
+        }
+        return;
+    }
     const int base = f < F ? 2 * C + f * m.pf : 0;
     const int count = f < F ? m.pf : 2 * C;
     for (int i = tid; i < count; i += 256) {
@@ -850,6 +859,17 @@ __global__ __launch_bounds__(256) void rnvp_update_kernel(const RnvpUpdArgs u) {
             go[base + i] = g;
         } else if (!frozen && isfinite(g)) {
             rp[base + i] = opt_apply(u, rp[base + i], g, lr, f < F ? u.wd_flow : 0.f, &om[base + i], &ov[base + i]);
+        }
+    }
+    if (u.mode == 0 && u.RE != nullptr) {
+        // the next forward's packed image, straight from the parameters this block has just written (one launch less per step)
+        __syncthreads();
+        float* re = u.RE + (size_t)img * m.LDSF;
+        if (f < F) {
+            rnvp_flow_image<C>(rp, re + RNVP_HDR + f * m.fl, m, f);
+        } else {
+            rnvp_header_image<C>(rp, re);
+            if (u.unit_linear && tid < 6) re[tid] = tid < 3 ? (tid < C ? 1.f : 0.f) : 0.f;
         }
     }
 }
