@@ -314,25 +314,24 @@ def test_gradient_accuracy_against_float64(amd, layers, C):
     assert max(e_hip) <= 3.0 * max(e_ref) + 1e-6, (max(e_hip), max(e_ref))
 
 
-def test_baseline_config_full_fit_matches_cpu_oracle(amd, golden_dir):
+def test_baseline_config_full_fit_matches_reference(amd, golden_dir):
     """BASELINE configs[1] end to end at full size: 2000 full-batch Adam steps of ConvexNextNet(h=130, L=1) on the 256x256 blob,
-    HIP vs the CPU oracle's fit of the same seeded problem (cached by tests/manual_parity_c2.py: final mask + loss curve).
-    north_star's tolerance: mIoU within +-1e-3."""
+    HIP vs the REAL reference classes' fit of the same seeded problem (tools/gen_golden.py gen_fit_blob256: final mask, loss
+    curve, fg-mIoU).  north_star's tolerance: mIoU within +-1e-3."""
     A = amd
     from awesome_amd.dataset import convex_blob_unaries
     from awesome_amd.model import ConvexNextNet
-    z = np.load(os.path.join(golden_dir, "c2_oracle_fit2000.npz"))
+    z = np.load(os.path.join(golden_dir, "fit_blob256_reference.npz"))
     S, E = 256, 2000
     torch.manual_seed(0)
     m = ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=1)
     un = convex_blob_unaries(S, 0).reshape(1, -1).to("cuda:0")
     res = A.fit(m.spec, m.flat_parameters()[None].to("cuda:0"), A.Grid.linspace(S, S, "cuda:0"), un, E, lr=2e-3)
-    mask_h = (torch.sigmoid(res.logits[0]) > 0.5).float()
-    mask_o = torch.from_numpy(z["mask"]).to("cuda:0")
-    tgt = (un > 0.5).float()
-    iou_h, iou_o = float(A.miou(mask_h[None], tgt)[0]), float(A.miou(mask_o[None], tgt)[0])
-    assert abs(iou_h - iou_o) <= 1e-3, (iou_h, iou_o)
-    assert int((mask_h != mask_o).sum()) <= 0.002 * S * S
+    mask_h = (torch.sigmoid(res.logits[0]) > 0.5)
+    mask_r = torch.from_numpy(z["final_mask"]).to("cuda:0")
+    iou_h = float(A.miou(mask_h[None].float(), (un > 0.5).float())[0])
+    assert abs(iou_h - float(z["final_miou"])) <= 1e-3, (iou_h, float(z["final_miou"]))
+    assert int((mask_h != mask_r).sum()) <= 0.002 * S * S
     h = res.loss_hist[0].cpu().numpy()
     np.testing.assert_allclose(h[:100], z["losses"][:100], rtol=5e-4)          # same trajectory while rounding has not piled up
     assert abs(h[-1] - z["losses"][-1]) <= 0.1 * z["losses"][-1]               # and the same end point

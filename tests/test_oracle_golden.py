@@ -183,3 +183,13 @@ def test_fcnet_no_prior_network(golden_dir, name):
     np.testing.assert_allclose(np.asarray(losses, np.float32), z["adam10.losses"], rtol=1e-5)
     for k in p:
         np.testing.assert_allclose(p[k].detach().numpy(), z["adam10." + k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def test_full_size_fit_oracle_vs_reference(golden_dir):
+    """BASELINE configs[1], 2000 steps at 256x256: the oracle's fit (cached by tests/manual_parity_c2.py, ~2 min of CPU) against
+    the real reference classes' fit of the same seeded problem (tools/gen_golden.py gen_fit_blob256)."""
+    o = np.load(os.path.join(golden_dir, "c2_oracle_fit2000.npz"))
+    r = np.load(os.path.join(golden_dir, "fit_blob256_reference.npz"))
+    np.testing.assert_allclose(o["losses"][:200], r["losses"][:200], rtol=1e-4)
+    assert abs(o["losses"][-1] - r["losses"][-1]) <= 0.02 * r["losses"][-1]
+    assert int((o["mask"].astype(bool) != r["final_mask"].astype(bool)).sum()) <= 30   # of 65 536 pixels

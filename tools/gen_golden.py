@@ -266,6 +266,37 @@ def gen_fit_disc(ref, out):
     print("wrote fit_disc64: loss", losses[0], "->", losses[-1], "miou", rec["final_miou"])
 
 
+def gen_fit_blob256(ref, out):
+    """BASELINE configs[1] end to end with the REAL reference classes: 256x256 convex blob (awesome_amd.dataset.convex_blob_unaries,
+    seed 0 - pure numpy, no reference code), ConvexNextNet(h=130, L=1) seeded like bench.py rank 0, UnariesWeightedLoss(SE('mean')),
+    torch.optim.Adam(lr 2e-3), enforce_convexity, 2000 full-batch steps (~3 min on 8 threads).  Only the final mask, the loss
+    curve and the fg-mIoU are kept (8 KB)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from awesome_amd.dataset.synthetic import convex_blob_unaries   # numpy-only synthetic input (not product compute)
+    T = ref.transformator.Transformator
+    torch.manual_seed(0)
+    model = ref.convex_net.ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=1)
+    grid = T.get_positional_matrices(256, 256)[None]
+    unaries = convex_blob_unaries(256, 0)[None, None]
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    crit = ref.uwl.UnariesWeightedLoss(ref.se.SE("mean"))
+    losses = []
+    for step in range(2000):
+        opt.zero_grad()
+        loss = crit(torch.sigmoid(model(grid)), unaries)
+        loss.backward()
+        opt.step()
+        model.enforce_convexity()
+        losses.append(loss.item())
+    with torch.no_grad():
+        outp = torch.sigmoid(model(grid))
+    miou = ref.miou.MIOU(average="binary", invert=True)
+    rec = {"losses": np.asarray(losses, dtype=np.float32), "final_mask": (outp > 0.5).numpy().reshape(-1),
+           "final_miou": np.float32(miou((outp > 0.5).float(), (unaries > 0.5).float()).item())}
+    np.savez_compressed(os.path.join(out, "fit_blob256_reference.npz"), **rec)
+    print("wrote fit_blob256_reference: loss", losses[0], "->", losses[-1], "miou", rec["final_miou"])
+
+
 def gen_flow(ref, out):
     """a6-a9: WNLinear, NormalBlock, WNScale, NormalizingFlow1D forward/grad (diffeomorphism_net.py)."""
     seed_all(21)
@@ -379,6 +410,7 @@ def main():
     gen_adamax(ref, out)
     gen_flow(ref, out)
     gen_fit_disc(ref, out)
+    gen_fit_blob256(ref, out)
     gen_minmax(ref, out)
     gen_pixel_losses(ref, out)
     gen_fcnet(ref, out)
