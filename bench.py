@@ -190,6 +190,17 @@ def main():
                "us_per_optimizer_step_per_image": round(tdt / E / TB * 1e6, 2), "miou_vs_unaries": round(float(tiou.mean()), 5),
                "note": "one complete E-step fit of the batch; all images step together (BASELINE configs[2] per-GPU share)"}
 
+    # parity of the timed workload with the real reference classes: rank 0's image 0 is exactly the problem of the golden
+    # fixture tests/golden/fit_blob256_reference.npz (tools/gen_golden.py gen_fit_blob256: same seeds, E = 2000, 256x256)
+    reference_parity = {}
+    fx = os.path.join(ROOT, "tests", "golden", "fit_blob256_reference.npz")
+    if rank == 0 and S == 256 and E == 2000 and os.path.exists(fx):
+        import numpy as np
+        z = np.load(fx)
+        mask0 = (prob[0] > 0.5).cpu().numpy().reshape(-1)
+        reference_parity = {"reference_miou": round(float(z["final_miou"]), 5),
+                            "miou_abs_diff_vs_reference": round(abs(float(iou[0]) - float(z["final_miou"])), 6),
+                            "mask_pixels_differing_from_reference": int((mask0 != z["final_mask"].astype(bool)).sum())}
     out = None
     if rank == 0:
         fits = args.steps * B * world
@@ -201,7 +212,7 @@ def main():
             "config": {"workload": f"{B} x {S}x{S} synthetic convex blob per GPU, ConvexNextNet(h=130,L=1), "
                                    f"SE(sigmoid) mean, Adam lr 2e-3, clamp, E={E} full-batch steps (BASELINE configs[1])",
                        "images_per_gpu": B, "grid": f"{S}x{S}", "epochs_per_fit": E, "parallelism": f"dp{world} (independent fits)"},
-            "miou_vs_unaries": round(miou, 5), "nonfinite_fits": status_bad,
+            "miou_vs_unaries": round(miou, 5), "nonfinite_fits": status_bad, **reference_parity,
             "us_per_optimizer_step": round(elapsed / args.steps / E * 1e6, 2),
             "roofline": roofline,
         }
