@@ -155,3 +155,22 @@ def test_hip_cdn_fit_trajectory(dev):
     for k in pf:
         np.testing.assert_allclose(got[k].numpy(), pf[k].numpy(), rtol=5e-3, atol=3e-4, err_msg=k)
     np.testing.assert_allclose(res.logits[0].cpu().numpy(), logits.reshape(-1).numpy(), rtol=5e-3, atol=2e-3)
+
+
+def test_hip_cdn_fit_end_to_end_vs_reference_modules(dev, golden_dir):
+    """300 steps of the fused ICNN(flow(Ax+b)) fit against the fit of the reference's own modules (golden cdn_fit48.npz)."""
+    import awesome_amd as A
+    from awesome_amd import flow as FL
+    z = np.load(os.path.join(golden_dir, "cdn_fit48.npz"))
+    sd0 = O.load_npz_state(z, "sd0.")
+    un = torch.from_numpy(z["unaries"])
+    S = un.shape[-1]
+    ispec, fspec = A.IcnnSpec(130, 2, 2), FL.FlowSpec(130, 6)
+    ip, fp = FL.split_cdn_state_dict(ispec, fspec, sd0, dev)
+    res = FL.cdn_fit(ispec, fspec, ip[None].contiguous(), fp[None].contiguous(), A.Grid.linspace(S, S, dev), un.reshape(1, -1).to(dev),
+                     300, lr=3e-3, loss="bce", weight_decay_on_weight_g=5e-5, plateau=None)
+    h = res.loss_hist[0].cpu().numpy()
+    np.testing.assert_allclose(h[:50], z["losses"][:50], rtol=5e-4)   # (trajectories of this unconverged fit drift apart later)
+    assert abs(h[-1] - float(z["losses"][-1])) <= 0.05 * float(z["losses"][-1])
+    agree = ((res.logits[0].cpu() > 0) == (torch.from_numpy(z["final_logits"]).reshape(-1) > 0)).float().mean()
+    assert float(agree) > 0.95

@@ -43,8 +43,9 @@ def _import_reference():
     import awesome.measures.awesome_loss as al
     import awesome.dataset.transformator as transformator
     import awesome.transforms.min_max as min_max
+    import awesome.util.torch as autil
     return types.SimpleNamespace(convex_net=convex_net, diffeo=diffeo, fc_net=fc_net, resnet_1d=resnet_1d, se=se, uwl=uwl,
-                                 miou=miou, ail=ail, al=al, transformator=transformator, min_max=min_max)
+                                 miou=miou, ail=ail, al=al, autil=autil, transformator=transformator, min_max=min_max)
 
 
 def seed_all(seed: int) -> None:
@@ -297,6 +298,52 @@ def gen_fit_blob256(ref, out):
     print("wrote fit_blob256_reference: loss", losses[0], "->", losses[-1], "miou", rec["final_miou"])
 
 
+def gen_cdn_fit(ref, out):
+    """The path-connected prior end to end with the reference's own modules: ConvexNextNet(130, L=2) behind
+    NormalizingFlow1D(6 couplings, width 130, normal_block) behind nn.Linear(2, 2) - composed exactly as
+    ConvexDiffeomorphismNet.forward does (convex_diffeomorphism_net.py:173-178; the class itself needs `toml` to import) - and
+    trained like its pretrain loop (:405-430): Adam over get_weight_normalized_param_groups(5e-5), lr 3e-3, BCE on the sigmoid,
+    enforce_convexity; 300 steps on a 48x48 two-disc shape."""
+    T = ref.transformator.Transformator
+    seed_all(4)
+    convex_net = ref.convex_net.ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=2)
+    diffeo_net = ref.diffeo.NormalizingFlow1D(num_coupling=6, width=130, in_features=2, backbone="normal_block")
+    linear = torch.nn.Linear(2, 2)
+    linear.weight.data.normal_(0.0, 1 / np.sqrt(2))
+    linear.bias.data.fill_(0)
+    net = torch.nn.ModuleDict(dict(convex_net=convex_net, diffeo_net=diffeo_net, linear=linear))
+    S = 48
+    yy, xx = np.mgrid[0:S, 0:S]
+    mask = (((yy - 16) ** 2 + (xx - 14) ** 2) < 60) | (((yy - 32) ** 2 + (xx - 32) ** 2) < 60) | \
+           ((np.abs(yy - 16) < 3) & (xx >= 14) & (xx <= 32)) | ((np.abs(xx - 32) < 3) & (yy >= 16) & (yy <= 32))
+    unaries = torch.from_numpy(1.0 - mask.astype(np.float32))[None, None]
+    grid = T.get_positional_matrices(S, S)[None]
+    rows = grid.permute(0, 2, 3, 1).reshape(-1, 2)
+
+    def forward():
+        return convex_net(diffeo_net(linear(rows))).reshape(1, S, S, 1).permute(0, 3, 1, 2)
+
+    rec = {"unaries": unaries.numpy()}
+    rec.update(sd_np(net, "sd0."))
+    opt = torch.optim.Adam(ref.autil.get_weight_normalized_param_groups(net, 5e-5, norm_suffix="weight_g"), lr=3e-3)
+    crit = torch.nn.BCELoss()
+    losses = []
+    for step in range(300):
+        opt.zero_grad()
+        loss = crit(torch.sigmoid(forward()), unaries)
+        loss.backward()
+        opt.step()
+        convex_net.enforce_convexity()
+        losses.append(loss.item())
+    with torch.no_grad():
+        logits = forward()
+    rec["losses"] = np.asarray(losses, dtype=np.float32)
+    rec["final_logits"] = logits.numpy().astype(np.float32)
+    rec.update(sd_np(net, "final."))
+    np.savez_compressed(os.path.join(out, "cdn_fit48.npz"), **rec)
+    print("wrote cdn_fit48: loss", losses[0], "->", losses[-1])
+
+
 def gen_flow(ref, out):
     """a6-a9: WNLinear, NormalBlock, WNScale, NormalizingFlow1D forward/grad (diffeomorphism_net.py)."""
     seed_all(21)
@@ -411,6 +458,7 @@ def main():
     gen_flow(ref, out)
     gen_fit_disc(ref, out)
     gen_fit_blob256(ref, out)
+    gen_cdn_fit(ref, out)
     gen_minmax(ref, out)
     gen_pixel_losses(ref, out)
     gen_fcnet(ref, out)
