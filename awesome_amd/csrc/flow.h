@@ -68,7 +68,6 @@ __device__ __forceinline__ void flow_weights_to_lds(const float* __restrict__ sr
     __syncthreads();
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // "relu form" of a coupling net.  leaky_relu(p) = slope p + (1 - slope) relu(p), and the slope part is affine in u:
 //   w2 . leaky_relu(w1 u + b1) + b2  =  (b2 + slope <w2, b1>)  +  slope <w2, w1> u  +  sum_j w2'_j relu(w1_j u + b1_j)

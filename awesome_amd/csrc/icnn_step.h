@@ -25,6 +25,7 @@
 #include "inrfit.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 // LLVM SchedGroupMask bits for __builtin_amdgcn_sched_group_barrier
@@ -196,6 +197,12 @@ __device__ __forceinline__ float sum_over_groups(float v) {  // the 4 lanes shar
 
 #ifndef INR_SCHED_HINTS
 #define INR_SCHED_HINTS 1
+#endif
+#ifndef INR_FWD_SPLIT
+#define INR_FWD_SPLIT 1
+#endif
+#ifndef INR_BWD_SPREAD
+#define INR_BWD_SPREAD 1
 #endif
 #if INR_SCHED_HINTS
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
@@ -415,6 +422,64 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
         float la[HRA];  // leftover units' pre-activation, partial over this lane group's positions
 #pragma unroll
         for (int u = 0; u < HRA; ++u) la[u] = 0.f;
+#if INR_FWD_SPLIT
+        // Operand reads of k-group tk+1 are spread over the products of k-group tk, one ds_read after every third MFMA and
+        // pinned there (OPERAND_FENCE: MFMAs and LDS reads keep their program order, VALU work may still move).  A wave
+        // issues in order and an LDS read holds the issue port for tens of cycles: reads issued back to back let the matrix
+        // pipe run dry (tools/micro/mfma_rate.hip: 40.7 cycles per MFMA with 8 b128 reads in a burst, 33.6 spread out).
+        f32x4 wq[2][TM];    // A operands of the main units: rows 16t + l15, 4 k-steps each
+        f32x4 wlq[2][HRA];  // same columns of the leftover units' rows
+        float winq[2];      // layer-0 A operand of the next z0 tile
+        f32x4 wo[TM];       // w_o of this lane's positions (requested during the last k-group)
+#pragma unroll
+        for (int t = 0; t < TM; ++t) wq[0][t] = *(const f32x4*)(wf + t * 16 * S);
+#pragma unroll
+        for (int u = 0; u < HR; ++u) wlq[0][u] = *(const f32x4*)(Wimg + (HM + u) * S + 4 * g);
+        z0[0] = z0_tile(0);
+        winq[1] = WinE[g * PT + 16 * (TM > 1 ? 1 : 0) + l15];
+#pragma unroll
+        for (int tk = 0; tk < KG; ++tk) {
+            const int cur = tk & 1, nx = cur ^ 1;
+            constexpr int NRD = TM + HR + 1;  // reads per k-group
+            auto next_read = [&](int i) {     // i-th operand read for k-group tk+1 (last k-group: w_o for the output layer)
+                if (tk + 1 < KG) {
+                    if (i < TM) wq[nx][i] = *(const f32x4*)(wf + i * 16 * S + 16 * (tk + 1));
+                    else if (i < TM + HR) wlq[nx][i - TM] = *(const f32x4*)(Wimg + (HM + i - TM) * S + 16 * (tk + 1) + 4 * g);
+                    else if (i == TM + HR && tk + 2 < TM) winq[cur] = WinE[g * PT + 16 * (tk + 2) + l15];
+                } else if (i < TM) {
+                    wo[i] = *(const f32x4*)&woT[16 * i + 4 * g];
+                }
+            };
+            f32x4 zn = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (tk + 1 < TM) zn = MFMA16(winq[nx], xe, (f32x4{0.f, 0.f, 0.f, 0.f}));  // pre-activation of z0[tk+1]
+            constexpr int dummy_ = 0;
+            (void)dummy_;
+            const int nmf = G::nr_in(tk) * TM;                    // products of this k-group
+            const int every = nmf / NRD > 0 ? nmf / NRD : 1;      // one read after every `every`-th product
+#pragma unroll
+            for (int r = 0; r < G::nr_in(tk); ++r) {
+#pragma unroll
+                for (int t = 0; t < TM; ++t) {
+                    acc[t] = MFMA16(wq[cur][t][r], z0[tk][r], (tk == 0 && r == 0) ? (f32x4{0.f, 0.f, 0.f, 0.f}) : acc[t]);
+                    const int q = r * TM + t;
+                    if (q % every == every - 1 && q / every < NRD) next_read(q / every);
+                    OPERAND_FENCE();
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NRD; ++i)
+                if (i >= nmf / every) next_read(i);
+#pragma unroll
+            for (int u = 0; u < HR; ++u)
+#pragma unroll
+                for (int r = 0; r < G::nr_in(tk); ++r) la[u] = fmaf(wlq[cur][u][r], z0[tk][r], la[u]);
+            if (tk + 1 < TM) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z0[tk + 1][r] = fmaxf(zn[r], 0.f);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
         f32x4 wq[2][TM];    // A operands of the main units: rows 16t + l15, 4 k-steps each
         f32x4 wlq[2][HRA];  // same columns of the leftover units' rows
         float winq[2];      // layer-0 A operand of the next z0 tile
@@ -462,6 +527,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+
+#endif
 
         STAMP(2);
         // ---- output layer, sigmoid, data term ------------------------------------------------------------------
@@ -575,8 +642,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 const int tk = ks >> 2, r = ks & 3;
                 if (ks + 1 < KS) {
                     const float* br = b_row(ks + 1);
+#if !INR_BWD_SPREAD
 #pragma unroll
                     for (int t = 0; t < TM; ++t) bq[(ks + 1) & 1][t] = br[16 * t];
+#endif
                     if (DX) bqx[(ks + 1) & 1] = br[16 * TM];
                 }
                 if (r == 0 && (tk + 1) * 4 < KS) {
@@ -585,9 +654,18 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 }
                 OPERAND_FENCE();
                 const float bop = tk < TM ? acc[tk < TM ? tk : 0][r] : (g == 0 ? dzl[r < HRA ? r : 0] : 0.f);
+#if INR_BWD_SPREAD
+#pragma unroll
+                for (int t = 0; t < TM; ++t) {  // D = dZ0 with POINTS on the rows; next k-step's operand reads one per product
+                    dz0[t] = MFMA16(bop, bq[ks & 1][t], ks == 0 ? (f32x4{0.f, 0.f, 0.f, 0.f}) : dz0[t]);
+                    if (ks + 1 < KS) bq[(ks + 1) & 1][t] = b_row(ks + 1)[16 * t];
+                    OPERAND_FENCE();
+                }
+#else
 #pragma unroll
                 for (int t = 0; t < TM; ++t)  // D = dZ0 with POINTS on the rows
                     dz0[t] = MFMA16(bop, bq[ks & 1][t], ks == 0 ? (f32x4{0.f, 0.f, 0.f, 0.f}) : dz0[t]);
+#endif
                 if (DX) dzx = MFMA16(bop, bqx[ks & 1], dzx);
                 MFMA_STEP_FENCE();
                 if (r == 1 && tk + 1 < TM) dz1_tile(tk + 1);  // next tile's dz1 + staging, in the shadow of the MFMAs

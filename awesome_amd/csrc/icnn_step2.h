@@ -9,6 +9,13 @@
 #pragma once
 #include "icnn_step.h"
 
+#ifndef INR2_FWD_SPREAD
+#define INR2_FWD_SPREAD 1
+#endif
+#ifndef INR2_BWD_SPREAD
+#define INR2_BWD_SPREAD 1
+#endif
+
 namespace {
 
 template <int H, int C>
@@ -163,6 +170,31 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
 #pragma unroll
         for (int tk = 0; tk < KG; ++tk) {
             const int cur = tk & 1, nx = cur ^ 1;
+#if INR2_FWD_SPREAD
+            // next k-group's operand reads one after every other product, pinned (see icnn_step.h: reads in a burst stall the issue)
+            auto next_read = [&](int i) {
+                if (tk + 1 < KG) {
+                    if (i < TM) wq[nx][i] = *(const f32x4*)(wf + i * 16 * S + 16 * (tk + 1));
+                    else wlq[nx][i - TM] = *(const f32x4*)(Wl + (HM + i - TM) * S + 16 * (tk + 1) + 4 * g);
+                }
+            };
+            constexpr int NRD = TM + HR;
+            const int nmf = G::nr_in(tk) * TM;
+            const int every = nmf / NRD > 0 ? nmf / NRD : 1;
+#pragma unroll
+            for (int r = 0; r < G::nr_in(tk); ++r) {
+#pragma unroll
+                for (int t = 0; t < TM; ++t) {
+                    acc[t] = MFMA16(wq[cur][t][r], B[tk][r], (tk == 0 && r == 0) ? (f32x4{0.f, 0.f, 0.f, 0.f}) : acc[t]);
+                    const int q = r * TM + t;
+                    if (q % every == every - 1 && q / every < NRD) next_read(q / every);
+                    OPERAND_FENCE();
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NRD; ++i)
+                if (i >= nmf / every) next_read(i);
+#else
             if (tk + 1 < KG) {
 #pragma unroll
                 for (int t = 0; t < TM; ++t) wq[nx][t] = *(const f32x4*)(wf + t * 16 * S + 16 * (tk + 1));
@@ -176,6 +208,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
                     acc[t] = MFMA16(wq[cur][t][r], B[tk][r], (tk == 0 && r == 0) ? (f32x4{0.f, 0.f, 0.f, 0.f}) : acc[t]);
                 MFMA_STEP_FENCE();
             }
+#endif
 #pragma unroll
             for (int u = 0; u < HR; ++u)
 #pragma unroll
@@ -215,8 +248,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
             const int tk = ks >> 2, r = ks & 3;
             if (ks + 1 < KS) {
                 const float* br = b_row(ks + 1);
+#if !INR2_BWD_SPREAD
 #pragma unroll
                 for (int t = 0; t < TM; ++t) bq[(ks + 1) & 1][t] = br[16 * t];
+#endif
                 if (DX) bqx[(ks + 1) & 1] = br[16 * TM];
             }
             if (r == 0 && (tk + 1) * 4 < KS) {
@@ -229,6 +264,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
             for (int t = 0; t < TM; ++t) {
                 const f32x4 c0 = ks == 0 ? (f32x4{0.f, 0.f, 0.f, 0.f}) : out[t];
                 out[t] = SWAP ? MFMA16(bop, bq[ks & 1][t], c0) : MFMA16(bq[ks & 1][t], bop, c0);
+#if INR2_BWD_SPREAD
+                if (ks + 1 < KS) bq[(ks + 1) & 1][t] = b_row(ks + 1)[16 * t];   // next k-step's operands, one read per product
+                OPERAND_FENCE();
+#endif
             }
             if (DX) outx = SWAP ? MFMA16(bop, bqx[ks & 1], outx) : MFMA16(bqx[ks & 1], bop, outx);
             MFMA_STEP_FENCE();

@@ -335,3 +335,25 @@ def test_baseline_config_full_fit_matches_reference(amd, golden_dir):
     h = res.loss_hist[0].cpu().numpy()
     np.testing.assert_allclose(h[:100], z["losses"][:100], rtol=5e-4)          # same trajectory while rounding has not piled up
     assert abs(h[-1] - z["losses"][-1]) <= 0.1 * z["losses"][-1]               # and the same end point
+
+
+def test_full_fit_two_hidden_layers_matches_reference(amd, golden_dir):
+    """The same full-size fit with the two-hidden-layer net every flow prior evaluates (icnn2_step_kernel): 2000 Adam steps of
+    ConvexNextNet(h=130, L=2) on the 256x256 blob vs the reference classes' fit (golden fit_blob256_l2_reference.npz)."""
+    A = amd
+    from awesome_amd.dataset import convex_blob_unaries
+    from awesome_amd.model import ConvexNextNet
+    z = np.load(os.path.join(golden_dir, "fit_blob256_l2_reference.npz"))
+    S, E = 256, 2000
+    torch.manual_seed(0)
+    m = ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=2)
+    un = convex_blob_unaries(S, 0).reshape(1, -1).to("cuda:0")
+    res = A.fit(m.spec, m.flat_parameters()[None].to("cuda:0"), A.Grid.linspace(S, S, "cuda:0"), un, E, lr=2e-3)
+    mask_h = (torch.sigmoid(res.logits[0]) > 0.5)
+    mask_r = torch.from_numpy(z["final_mask"]).to("cuda:0")
+    iou_h = float(A.miou(mask_h[None].float(), (un > 0.5).float())[0])
+    assert abs(iou_h - float(z["final_miou"])) <= 1e-3, (iou_h, float(z["final_miou"]))
+    assert int((mask_h != mask_r).sum()) <= 0.002 * S * S
+    h = res.loss_hist[0].cpu().numpy()
+    np.testing.assert_allclose(h[:100], z["losses"][:100], rtol=5e-4)          # same trajectory while rounding has not piled up
+    assert abs(h[-1] - z["losses"][-1]) <= 0.1 * z["losses"][-1]               # and the same end point

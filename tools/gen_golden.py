@@ -267,16 +267,17 @@ def gen_fit_disc(ref, out):
     print("wrote fit_disc64: loss", losses[0], "->", losses[-1], "miou", rec["final_miou"])
 
 
-def gen_fit_blob256(ref, out):
+def gen_fit_blob256(ref, out, layers=1, name="fit_blob256_reference"):
     """BASELINE configs[1] end to end with the REAL reference classes: 256x256 convex blob (awesome_amd.dataset.convex_blob_unaries,
     seed 0 - pure numpy, no reference code), ConvexNextNet(h=130, L=1) seeded like bench.py rank 0, UnariesWeightedLoss(SE('mean')),
     torch.optim.Adam(lr 2e-3), enforce_convexity, 2000 full-batch steps (~3 min on 8 threads).  Only the final mask, the loss
-    curve and the fg-mIoU are kept (8 KB)."""
+    curve and the fg-mIoU are kept (8 KB).  `layers=2` writes the same fit for the two-hidden-layer net every flow prior uses
+    (fit_blob256_l2_reference.npz, ~5 min)."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from awesome_amd.dataset.synthetic import convex_blob_unaries   # numpy-only synthetic input (not product compute)
     T = ref.transformator.Transformator
     torch.manual_seed(0)
-    model = ref.convex_net.ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=1)
+    model = ref.convex_net.ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=layers)
     grid = T.get_positional_matrices(256, 256)[None]
     unaries = convex_blob_unaries(256, 0)[None, None]
     opt = torch.optim.Adam(model.parameters(), lr=2e-3)
@@ -294,8 +295,8 @@ def gen_fit_blob256(ref, out):
     miou = ref.miou.MIOU(average="binary", invert=True)
     rec = {"losses": np.asarray(losses, dtype=np.float32), "final_mask": (outp > 0.5).numpy().reshape(-1),
            "final_miou": np.float32(miou((outp > 0.5).float(), (unaries > 0.5).float()).item())}
-    np.savez_compressed(os.path.join(out, "fit_blob256_reference.npz"), **rec)
-    print("wrote fit_blob256_reference: loss", losses[0], "->", losses[-1], "miou", rec["final_miou"])
+    np.savez_compressed(os.path.join(out, name + ".npz"), **rec)
+    print("wrote", name, ": loss", losses[0], "->", losses[-1], "miou", rec["final_miou"])
 
 
 def gen_cdn_fit(ref, out):
@@ -445,11 +446,14 @@ def gen_minmax(ref, out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden"))
+    ap.add_argument("--only", default=None, help="run a single generator, e.g. fit_blob256_l2")
     args = ap.parse_args()
     out = os.path.abspath(args.out)
     os.makedirs(out, exist_ok=True)
     torch.set_num_threads(4)
     ref = _import_reference()
+    if args.only == "fit_blob256_l2":
+        return gen_fit_blob256(ref, out, layers=2, name="fit_blob256_l2_reference")
     gen_grid(ref, out)
     gen_miou(ref, out)
     gen_losses(ref, out)
@@ -458,6 +462,7 @@ def main():
     gen_flow(ref, out)
     gen_fit_disc(ref, out)
     gen_fit_blob256(ref, out)
+    gen_fit_blob256(ref, out, layers=2, name="fit_blob256_l2_reference")
     gen_cdn_fit(ref, out)
     gen_minmax(ref, out)
     gen_pixel_losses(ref, out)
@@ -465,7 +470,7 @@ def main():
     with open(os.path.join(out, "PROVENANCE.txt"), "w") as f:
         f.write("Generated by tools/gen_golden.py from jp-schneider/awesome @ 2024_08_07 (reference classes imported on CPU),\n")
         f.write(f"torch {torch.__version__}, numpy {np.__version__}.\n")
-        f.write("All files regenerate bit for bit except the long fp32 trajectories fit_blob256_reference.npz and cdn_fit48.npz:\n"
+        f.write("All files regenerate bit for bit except the long fp32 trajectories fit_blob256*_reference.npz and cdn_fit48.npz:\n"
                 "the reference's multi-threaded CPU fit differs between runs from the 1-ulp level on (two runs of the 2000-step\n"
                 "fit: 1 mask pixel, 1.7e-4 mIoU, 0.7 % of the final loss apart); the committed files are one such run.\n")
 

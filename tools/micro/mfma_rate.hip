@@ -1,0 +1,132 @@
+// Micro-benchmark: issue rate of v_mfma_f32_16x16x4_f32 streams shaped like the step kernel's products (gfx950).
+// hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_rate.hip -o gpurun_out/mfma_rate && gpurun_out/mfma_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <type_traits>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int NACC, int MODE>
+__global__ __launch_bounds__(256) void rate_kernel(float* out, unsigned long long* cyc, int iters) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 32 * 1024; i += 256) lds[i] = 0.001f * (i & 63);
+    __syncthreads();
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 a4[2][8];   // operands, double-buffered: the reads of group it+1 are requested before the products of group it
+#pragma unroll
+    for (int t = 0; t < 8; ++t) a4[0][t] = a4[1][t] = *(const f32x4*)&lds[(lane & 15) * 140 + 4 * (lane >> 4) + 16 * t * 140 % 8192];
+    f32x4 b = f32x4{1.f + lane, 2.f, 3.f, 4.f};
+    unsigned long long t0, t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    auto body = [&](auto par, int it) {
+        constexpr int cur = decltype(par)::value, nx = cur ^ 1;
+        if (MODE == 1 || MODE == 3) {  // 8 x ds_read_b128 per 32 MFMAs, like the forward product
+#pragma unroll
+            for (int t = 0; t < 8; ++t) a4[nx][t] = *(const f32x4*)&lds[((lane & 15) * 140 + 4 * (lane >> 4) + 16 * ((it + t) & 31) + 2240 * t) & 8191];
+        }
+        if (MODE == 2) {  // 32 x ds_read_b32 per 32 MFMAs (column reads), like the backward product
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a4[nx][t][r] = lds[((lane & 15) + 16 * t + (4 * (lane >> 4) + r + 16 * (it & 3)) * 140) & 16383];
+        }
+        if (MODE == 4) {  // the same bytes with 8 x ds_read_b128 (permuted unit order)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 q = *(const f32x4*)&lds[(4 * (lane & 15) + 64 * h + (4 * (lane >> 4) + r + 16 * (it & 3)) * 140) & 16383];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) a4[nx][4 * h + t][r] = q[t];
+                }
+        }
+        if (MODE != 0) __builtin_amdgcn_sched_barrier(0x676);
+        if (MODE == 5 || MODE == 6 || MODE == 7) {   // the same reads, one after every 4th (5: b128) / 2nd (6: b64) / every (7: b32) MFMA, pinned
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    acc[t] = MFMA16(a4[cur][t][r], b[r], acc[t]);
+                    const int q = 8 * r + t;   // 0..31
+                    const float* base = &lds[((lane & 15) * 140 + 4 * (lane >> 4) + 16 * (it & 31)) & 8191];
+                    if (MODE == 5 && (q & 3) == 3) a4[nx][q >> 2] = *(const f32x4*)(base + 2240 * (q >> 2));
+                    if (MODE == 6 && (q & 1) == 1) {
+                        const float2 v = *(const float2*)(base + 2240 * (q >> 2) + 2 * ((q >> 1) & 1));
+                        a4[nx][q >> 2][2 * ((q >> 1) & 1)] = v.x;
+                        a4[nx][q >> 2][2 * ((q >> 1) & 1) + 1] = v.y;
+                    }
+                    if (MODE == 7) a4[nx][q >> 2][q & 3] = base[2240 * (q >> 2) + (q & 3)];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int t = 0; t < NACC; ++t) acc[t] = MFMA16(a4[cur][t & 7][r], b[r], acc[t]);
+            __builtin_amdgcn_sched_barrier(0x7F6);
+        }
+        }
+        if (MODE == 3) {  // VALU consumer of a finished tile, like the relu of the next z0 tile
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b[r] = fmaxf(acc[0][r] * 1e-30f, 1.f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int it = 0; it < iters; it += 2) {
+        body(std::integral_constant<int, 0>{}, it);
+        body(std::integral_constant<int, 1>{}, it + 1);
+    }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s + b[0];
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int NACC, int MODE>
+static void run(const char* name, int blocks, int threads) {
+    float* out;
+    unsigned long long* cyc;
+    hipMalloc(&out, 1024 * 256 * 4);
+    hipMalloc(&cyc, 1024 * 8);
+    const int iters = 2000;
+    hipFuncSetAttribute((const void*)rate_kernel<NACC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    rate_kernel<NACC, MODE><<<blocks, threads, 140 * 1024>>>(out, cyc, 10);
+    hipEventRecord(e0);
+    rate_kernel<NACC, MODE><<<blocks, threads, 140 * 1024>>>(out, cyc, iters);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(blocks);
+    hipMemcpy(h.data(), cyc, blocks * 8, hipMemcpyDeviceToHost);
+    const double n = (double)iters * 4 * NACC;
+    printf("%-44s blocks %4d waves/blk %d: %6.2f memtime-ticks/MFMA, %6.2f ns/MFMA  (%.3f GHz if 32 cyc)\n", name, blocks, threads / 64,
+           h[0] / n, ms * 1e6 / n, 32.0 / (ms * 1e6 / n));
+    hipFree(out); hipFree(cyc);
+}
+
+int main() {
+    for (int blocks : {1, 256}) {
+        run<8, 0>("8 acc, no fillers", blocks, 256);
+        run<18, 0>("18 acc, no fillers", blocks, 256);
+        run<8, 1>("8 acc + 8 ds_read_b128 per 32", blocks, 256);
+        run<8, 2>("8 acc + 32 ds_read_b32 per 32", blocks, 256);
+        run<8, 3>("8 acc + b128 + VALU consumer", blocks, 256);
+        run<8, 4>("8 acc + 8 ds_read_b128 (column data) per 32", blocks, 256);
+        run<8, 5>("8 acc + 8 b128, one per 4 MFMAs", blocks, 256);
+        run<8, 6>("8 acc + 16 b64, one per 2 MFMAs", blocks, 256);
+        run<8, 7>("8 acc + 32 b32, one per MFMA", blocks, 256);
+        run<8, 1>("8 acc + 8 ds_read_b128 burst, 1 wave", blocks, 64);
+        run<8, 5>("8 acc + 8 b128 spread, 1 wave", blocks, 64);
+        run<8, 0>("8 acc, no fillers, 1 wave", blocks, 64);
+    }
+    return 0;
+}
