@@ -75,6 +75,7 @@ EXPORTS = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "inrfit_step_only": (C.c_int, [C.POINTER(InrModelDesc), C.c_void_p, C.POINTER(InrGridDesc), C.c_void_p,
                                    C.POINTER(InrLossDesc), C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_mfma_stream": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]),
     "inrfit_flow_param_count": (C.c_int64, [C.POINTER(InrFlowDesc)]),
     "inrfit_cdn_workspace_bytes": (C.c_int64, [C.POINTER(InrModelDesc), C.POINTER(InrFlowDesc), C.POINTER(InrGridDesc), C.c_int]),
     "inrfit_flow_forward": (C.c_int, [C.POINTER(InrFlowDesc), C.c_void_p, C.POINTER(InrGridDesc), C.c_int, C.c_void_p,

@@ -28,6 +28,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// relu as ONE instruction: v_max_i32 on the bit pattern (negative floats are negative integers; -0.0 and negative NaNs
+// become +0).  fmaxf / fmed3 cost two (hipcc first quiets a possible signalling NaN with v_max x, x), and inline asm is not an
+// option: the hazard recogniser does not insert the MFMA-write -> VALU-read wait states in front of an asm statement.
+__device__ __forceinline__ float relu0(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 // LLVM SchedGroupMask bits for __builtin_amdgcn_sched_group_barrier
 #define SG_VALU 0x2
 #define SG_MFMA 0x8
@@ -198,12 +202,6 @@ __device__ __forceinline__ float sum_over_groups(float v) {  // the 4 lanes shar
 #ifndef INR_SCHED_HINTS
 #define INR_SCHED_HINTS 1
 #endif
-#ifndef INR_FWD_SPLIT
-#define INR_FWD_SPLIT 1
-#endif
-#ifndef INR_BWD_SPREAD
-#define INR_BWD_SPREAD 1
-#endif
 #if INR_SCHED_HINTS
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 #else
@@ -218,9 +216,6 @@ __device__ __forceinline__ float sum_over_groups(float v) {  // the 4 lanes shar
 #define SLAB_ST(ptr, v) __builtin_nontemporal_store((v), (ptr))
 #else
 #define SLAB_ST(ptr, v) (*(ptr) = (v))
-#endif
-#ifndef INR_FWD_FENCE
-#define INR_FWD_FENCE 0
 #endif
 #ifndef INR_MFMA_ORDER
 #define INR_MFMA_ORDER 1
@@ -242,6 +237,7 @@ __device__ __forceinline__ float sum_over_groups(float v) {  // the 4 lanes shar
 #endif
 #if INR_STAMPS
 __device__ unsigned long long g_stamps[16];
+__device__ unsigned long long g_wgtimes[1024][4];   // per workgroup, s_memrealtime (100 MHz): entry, loop start, loop end, stores done
 #define STAMP(k)                                                                                   \
     do {                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                         \
@@ -274,6 +270,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
     float* const stA = smem + G::OFF_STA;
     float* const stB = smem + G::OFF_STB;
 
+#if INR_STAMPS
+    const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -316,7 +315,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
     // per-lane LDS addresses
     const float* const wf = Wimg + l15 * S + 4 * g;  // forward A operand: row 16t + l15, columns 16tk + 4g ..+3
     const float* const wb = Wimg + l15;              // backward A operand: row o, column 16t + l15
-    const bool row_ok = wave * RPW < TM;             // this wave owns row tiles of the dW product
+    const bool row_ok = (4 * RPW == TM) || wave * RPW < TM;             // this wave owns row tiles of the dW product
     const int arow = 16 * wave * RPW + l15;          // first dW row tile of this wave (+ lane column)
 
     // persistent gradient accumulators (TRAIN)
@@ -355,13 +354,28 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
         float x[C];
         float tg;
     };
+    const bool fast_div = N <= (1ll << 24);
+    const float inv_width = a.grid.mode == INR_GRID_SEPARABLE ? 1.f / (float)a.grid.width : 0.f;
     auto load_point = [&](int chunk) -> PointIn {
         PointIn q;
         int pc = chunk * SP + wave * 16 + l15;   // points per image < 2^31 (checked on the host)
         pc = pc < (int)N ? pc : (int)N - 1;
         if (a.grid.mode == INR_GRID_SEPARABLE) {
-            const int row = pc / a.grid.width;
-            const int col = pc - row * a.grid.width;
+            int row, col;
+            if (fast_div) {   // pc < 2^24 is exact in fp32 and the quotient estimate is off by at most one
+                row = (int)((float)pc * inv_width);
+                col = pc - row * a.grid.width;
+                if (col < 0) {
+                    row -= 1;
+                    col += a.grid.width;
+                } else if (col >= a.grid.width) {
+                    row += 1;
+                    col -= a.grid.width;
+                }
+            } else {
+                row = pc / a.grid.width;
+                col = pc - row * a.grid.width;
+            }
             q.x[0] = a.grid.xs[col];
             q.x[1] = a.grid.ys[row];
             if (C > 2) q.x[C - 1] = a.grid.ts ? a.grid.ts[img] : 0.f;
@@ -378,16 +392,13 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
     unsigned long long st_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
     const unsigned long long st_begin = st_prev;
+    const unsigned long long rt_loop = __builtin_amdgcn_s_memrealtime();
 #endif
     for (int chunk = wg; chunk < n_chunks; chunk += a.wgs) {
         STAMP(0);
         const int p = chunk * SP + wave * 16 + l15;
         const bool valid = p < (int)N;
         const PointIn cur = nxt;
-        {   // prefetch the next chunk's inputs: the global-load latency hides under this chunk's MFMAs
-            const int cn = chunk + a.wgs;
-            nxt = load_point(cn < n_chunks ? cn : chunk);
-        }
         float x[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) x[c] = cur.x[c];
@@ -401,7 +412,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
         auto z0_tile = [&](int tk) -> f32x4 {
             f32x4 z = MFMA16(WinE[g * PT + 16 * tk + l15], xe, (f32x4{0.f, 0.f, 0.f, 0.f}));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z[r] = fmaxf(z[r], 0.f);
+            for (int r = 0; r < 4; ++r) z[r] = relu0(z[r]);
             return z;
         };
         {
@@ -422,7 +433,6 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
         float la[HRA];  // leftover units' pre-activation, partial over this lane group's positions
 #pragma unroll
         for (int u = 0; u < HRA; ++u) la[u] = 0.f;
-#if INR_FWD_SPLIT
         // Operand reads of k-group tk+1 are spread over the products of k-group tk, one ds_read after every third MFMA and
         // pinned there (OPERAND_FENCE: MFMAs and LDS reads keep their program order, VALU work may still move).  A wave
         // issues in order and an LDS read holds the issue port for tens of cycles: reads issued back to back let the matrix
@@ -450,10 +460,12 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                     wo[i] = *(const f32x4*)&woT[16 * i + 4 * g];
                 }
             };
+            if (tk == (KG > 2 ? 1 : 0)) {   // next chunk's inputs: address arithmetic in the shadow of these products, latency under the chunk
+                const int cn = chunk + a.wgs;
+                nxt = load_point(cn < n_chunks ? cn : chunk);
+            }
             f32x4 zn = f32x4{0.f, 0.f, 0.f, 0.f};
             if (tk + 1 < TM) zn = MFMA16(winq[nx], xe, (f32x4{0.f, 0.f, 0.f, 0.f}));  // pre-activation of z0[tk+1]
-            constexpr int dummy_ = 0;
-            (void)dummy_;
             const int nmf = G::nr_in(tk) * TM;                    // products of this k-group
             const int every = nmf / NRD > 0 ? nmf / NRD : 1;      // one read after every `every`-th product
 #pragma unroll
@@ -475,69 +487,32 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 for (int r = 0; r < G::nr_in(tk); ++r) la[u] = fmaf(wlq[cur][u][r], z0[tk][r], la[u]);
             if (tk + 1 < TM) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) z0[tk + 1][r] = fmaxf(zn[r], 0.f);
+                for (int r = 0; r < 4; ++r) z0[tk + 1][r] = relu0(zn[r]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-#else
-        f32x4 wq[2][TM];    // A operands of the main units: rows 16t + l15, 4 k-steps each
-        f32x4 wlq[2][HRA];  // same columns of the leftover units' rows
-        float winq[2];      // layer-0 A operand of the next z0 tile
-        f32x4 wo[TM];       // w_o of this lane's positions (requested during the last k-group)
-#pragma unroll
-        for (int t = 0; t < TM; ++t) wq[0][t] = *(const f32x4*)(wf + t * 16 * S);
-#pragma unroll
-        for (int u = 0; u < HR; ++u) wlq[0][u] = *(const f32x4*)(Wimg + (HM + u) * S + 4 * g);
-        z0[0] = z0_tile(0);
-        winq[1] = WinE[g * PT + 16 * (TM > 1 ? 1 : 0) + l15];
-#pragma unroll
-        for (int tk = 0; tk < KG; ++tk) {
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int cur = tk & 1, nx = cur ^ 1;
-            if (tk + 1 < KG) {
-#pragma unroll
-                for (int t = 0; t < TM; ++t) wq[nx][t] = *(const f32x4*)(wf + t * 16 * S + 16 * (tk + 1));
-#pragma unroll
-                for (int u = 0; u < HR; ++u) wlq[nx][u] = *(const f32x4*)(Wimg + (HM + u) * S + 16 * (tk + 1) + 4 * g);
-                if (tk + 2 < TM) winq[cur] = WinE[g * PT + 16 * (tk + 2) + l15];
-            } else {
-#pragma unroll
-                for (int t = 0; t < TM; ++t) wo[t] = *(const f32x4*)&woT[16 * t + 4 * g];
-            }
-#if INR_FWD_FENCE
-            OPERAND_FENCE();
-#endif
-            f32x4 zn = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (tk + 1 < TM) zn = MFMA16(winq[nx], xe, (f32x4{0.f, 0.f, 0.f, 0.f}));  // pre-activation of z0[tk+1]
-#pragma unroll
-            for (int r = 0; r < G::nr_in(tk); ++r) {
-#pragma unroll
-                for (int t = 0; t < TM; ++t)
-                    acc[t] = MFMA16(wq[cur][t][r], z0[tk][r], (tk == 0 && r == 0) ? (f32x4{0.f, 0.f, 0.f, 0.f}) : acc[t]);
-                MFMA_STEP_FENCE();
-            }
-#pragma unroll
-            for (int u = 0; u < HR; ++u)
-#pragma unroll
-                for (int r = 0; r < G::nr_in(tk); ++r) la[u] = fmaf(wlq[cur][u][r], z0[tk][r], la[u]);
-            if (tk + 1 < TM) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) z0[tk + 1][r] = fmaxf(zn[r], 0.f);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-
-#endif
 
         STAMP(2);
+        // relu mask of layer 0 in the transposed layout of the backward product (rows = points): z0^T is the layer-0 product
+        // with swapped operands, TM more MFMAs - issued here, where the matrix pipe would otherwise idle under the VALU work
+        // of the output layer and the data term.
+        f32x4 z0p[TM];
+        if (TRAIN) {
+            float wie[TM];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) wie[t] = WinE[g * PT + 16 * t + l15];
+            OPERAND_FENCE();
+#pragma unroll
+            for (int t = 0; t < TM; ++t) z0p[t] = MFMA16(xe, wie[t], (f32x4{0.f, 0.f, 0.f, 0.f}));
+            MFMA_STEP_FENCE();
+        }
         // ---- output layer, sigmoid, data term ------------------------------------------------------------------
         float ypart = 0.f;
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                acc[t][r] = fmaxf(acc[t][r], 0.f);  // z1
+                acc[t][r] = relu0(acc[t][r]);  // z1
                 ypart = fmaf(wo[t][r], acc[t][r], ypart);
             }
         }
@@ -545,7 +520,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
         float z1l[HRA];
 #pragma unroll
         for (int u = 0; u < HR; ++u) {
-            z1l[u] = fmaxf(sum_over_groups(la[u]), 0.f);
+            z1l[u] = relu0(sum_over_groups(la[u]));
             ypart = fmaf(wol[u], z1l[u], ypart);
         }
         float y = ypart + b_o;
@@ -642,10 +617,6 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 const int tk = ks >> 2, r = ks & 3;
                 if (ks + 1 < KS) {
                     const float* br = b_row(ks + 1);
-#if !INR_BWD_SPREAD
-#pragma unroll
-                    for (int t = 0; t < TM; ++t) bq[(ks + 1) & 1][t] = br[16 * t];
-#endif
                     if (DX) bqx[(ks + 1) & 1] = br[16 * TM];
                 }
                 if (r == 0 && (tk + 1) * 4 < KS) {
@@ -654,18 +625,12 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 }
                 OPERAND_FENCE();
                 const float bop = tk < TM ? acc[tk < TM ? tk : 0][r] : (g == 0 ? dzl[r < HRA ? r : 0] : 0.f);
-#if INR_BWD_SPREAD
 #pragma unroll
                 for (int t = 0; t < TM; ++t) {  // D = dZ0 with POINTS on the rows; next k-step's operand reads one per product
                     dz0[t] = MFMA16(bop, bq[ks & 1][t], ks == 0 ? (f32x4{0.f, 0.f, 0.f, 0.f}) : dz0[t]);
                     if (ks + 1 < KS) bq[(ks + 1) & 1][t] = b_row(ks + 1)[16 * t];
                     OPERAND_FENCE();
                 }
-#else
-#pragma unroll
-                for (int t = 0; t < TM; ++t)  // D = dZ0 with POINTS on the rows
-                    dz0[t] = MFMA16(bop, bq[ks & 1][t], ks == 0 ? (f32x4{0.f, 0.f, 0.f, 0.f}) : dz0[t]);
-#endif
                 if (DX) dzx = MFMA16(bop, bqx[ks & 1], dzx);
                 MFMA_STEP_FENCE();
                 if (r == 1 && tk + 1 < TM) dz1_tile(tk + 1);  // next tile's dz1 + staging, in the shadow of the MFMAs
@@ -684,20 +649,12 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 }
             }
             STAMP(4);
-            // relu mask of layer 0 in the same transposed layout: z0^T comes from the layer-0 product with swapped operands
-            // (TM more MFMAs); then dL0[t] += dZ0[:, tile t]^T . ext columns of this wave's own stage-B rows.
+            // relu mask of layer 0 (z0p, computed before the output layer); then dL0[t] += dZ0[:, tile t]^T . ext columns of
+            // this wave's own stage-B rows.
             {
                 float bfe[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bfe[r] = stB[(wave * 16 + 4 * g + r) * G::SB + HM + l15];
-                float wie[TM];
-#pragma unroll
-                for (int t = 0; t < TM; ++t) wie[t] = WinE[g * PT + 16 * t + l15];
-                OPERAND_FENCE();
-                f32x4 z0p[TM];
-#pragma unroll
-                for (int t = 0; t < TM; ++t) z0p[t] = MFMA16(xe, wie[t], (f32x4{0.f, 0.f, 0.f, 0.f}));
-                MFMA_STEP_FENCE();
 #pragma unroll
                 for (int t = 0; t < TM; ++t)
 #pragma unroll
@@ -779,37 +736,43 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                     for (int b = 0; b < KG; ++b) bf[0][b] = stB[pt * G::SB + 16 * b + l15];
                 }
 #pragma unroll
-                for (int it = 0; it < SP / 4; ++it) {
-                    const int ptc = stage_pt(it);
+            for (int it = 0; it < SP / 4; ++it) {
+                const int cur = it & 1, nx = cur ^ 1;
+                const int ptc = stage_pt(it), ptn = stage_pt(it + 1 < SP / 4 ? it + 1 : it);
+                // next k-step's operands, one ds_read after each of the first RPW + KG products (never two in a row: an LDS read
+                // holds the issue port, a burst lets the matrix pipe run dry)
+                auto next_read = [&](int i) {
                     if (it + 1 < SP / 4) {
-                        const int pt = stage_pt(it + 1);
-#pragma unroll
-                        for (int j = 0; j < RPW; ++j) af[(it + 1) & 1][j] = stA[pt * G::SA + arow + 16 * j];
-#pragma unroll
-                        for (int b = 0; b < KG; ++b) bf[(it + 1) & 1][b] = stB[pt * G::SB + 16 * b + l15];
+                        if (i < RPW) af[nx][i] = stA[ptn * G::SA + arow + 16 * i];
+                        else if (i < RPW + KG) bf[nx][i - RPW] = stB[ptn * G::SB + 16 * (i - RPW) + l15];
                     }
-                    if (HR > 0 && (it & 3) == 0) {  // every wave takes a quarter of the k-steps for the leftover rows
-                        const f32x4 dl = *(const f32x4*)(stA + ptc * G::SA + HM);
+                };
+                if (HR > 0 && (it & 3) == 0) {  // every wave takes a quarter of the k-steps for the leftover rows
+                    const f32x4 dl = *(const f32x4*)(stA + ptc * G::SA + HM);
 #pragma unroll
-                        for (int u = 0; u < HR; ++u)
+                    for (int u = 0; u < HR; ++u)
 #pragma unroll
-                            for (int b = 0; b < KG; ++b) dWl[u][b] = fmaf(dl[u], bf[it & 1][b], dWl[u][b]);
-                    }
-                    if (row_ok) {
-#pragma unroll
-                        for (int j = 0; j < RPW; ++j)
-#pragma unroll
-                            for (int b = 0; b < KG; ++b) dW[j][b] = MFMA16(af[it & 1][j], bf[it & 1][b], dW[j][b]);
-                        MFMA_STEP_FENCE();
-                    }
-#pragma unroll
-                    for (int b = 0; b < KG; ++b) {
-                        SGB(SG_DS_READ, 2);
-                        SGB(SG_VALU, 2);
-                        SGB(SG_MFMA, RPW);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                        for (int b = 0; b < KG; ++b) dWl[u][b] = fmaf(dl[u], bf[cur][b], dWl[u][b]);
                 }
+                if (row_ok) {
+#pragma unroll
+                    for (int j = 0; j < RPW; ++j)
+#pragma unroll
+                        for (int b = 0; b < KG; ++b) {
+                            dW[j][b] = MFMA16(af[cur][j], bf[cur][b], dW[j][b]);
+                            next_read(j * KG + b);
+                            OPERAND_FENCE();
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < RPW + KG; ++i) next_read(i);
+                }
+                if (RPW * KG < RPW + KG) {
+#pragma unroll
+                    for (int i = RPW * KG; i < RPW + KG; ++i) next_read(i);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             }
             STAMP(7);
             __syncthreads();
@@ -819,6 +782,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
 #if INR_STAMPS
     unsigned long long st_loop_end;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_loop_end)::"memory");
+    const unsigned long long rt_loop_end = __builtin_amdgcn_s_memrealtime();
 #endif
 
     if (TRAIN) {
@@ -942,6 +906,16 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
         }
     }
 #if INR_STAMPS
+    if (TRAIN && (tid & 63) == 0 && blockIdx.x < 1024) {
+        __builtin_amdgcn_s_waitcnt(0);   // this wave's slab stores have left
+        const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            g_wgtimes[blockIdx.x][0] = rt_entry;
+            g_wgtimes[blockIdx.x][1] = rt_loop;
+            g_wgtimes[blockIdx.x][2] = rt_loop_end;
+        }
+        atomicMax(&g_wgtimes[blockIdx.x][3], rt_end);
+    }
     if (TRAIN && blockIdx.x == 0 && tid == 0) {
         unsigned long long t_end;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end)::"memory");

@@ -9,12 +9,6 @@
 #pragma once
 #include "icnn_step.h"
 
-#ifndef INR2_FWD_SPREAD
-#define INR2_FWD_SPREAD 1
-#endif
-#ifndef INR2_BWD_SPREAD
-#define INR2_BWD_SPREAD 1
-#endif
 
 namespace {
 
@@ -170,7 +164,6 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
 #pragma unroll
         for (int tk = 0; tk < KG; ++tk) {
             const int cur = tk & 1, nx = cur ^ 1;
-#if INR2_FWD_SPREAD
             // next k-group's operand reads one after every other product, pinned (see icnn_step.h: reads in a burst stall the issue)
             auto next_read = [&](int i) {
                 if (tk + 1 < KG) {
@@ -194,21 +187,6 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
 #pragma unroll
             for (int i = 0; i < NRD; ++i)
                 if (i >= nmf / every) next_read(i);
-#else
-            if (tk + 1 < KG) {
-#pragma unroll
-                for (int t = 0; t < TM; ++t) wq[nx][t] = *(const f32x4*)(wf + t * 16 * S + 16 * (tk + 1));
-#pragma unroll
-                for (int u = 0; u < HR; ++u) wlq[nx][u] = *(const f32x4*)(Wl + (HM + u) * S + 16 * (tk + 1) + 4 * g);
-            }
-#pragma unroll
-            for (int r = 0; r < G::nr_in(tk); ++r) {
-#pragma unroll
-                for (int t = 0; t < TM; ++t)
-                    acc[t] = MFMA16(wq[cur][t][r], B[tk][r], (tk == 0 && r == 0) ? (f32x4{0.f, 0.f, 0.f, 0.f}) : acc[t]);
-                MFMA_STEP_FENCE();
-            }
-#endif
 #pragma unroll
             for (int u = 0; u < HR; ++u)
 #pragma unroll
@@ -248,10 +226,6 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
             const int tk = ks >> 2, r = ks & 3;
             if (ks + 1 < KS) {
                 const float* br = b_row(ks + 1);
-#if !INR2_BWD_SPREAD
-#pragma unroll
-                for (int t = 0; t < TM; ++t) bq[(ks + 1) & 1][t] = br[16 * t];
-#endif
                 if (DX) bqx[(ks + 1) & 1] = br[16 * TM];
             }
             if (r == 0 && (tk + 1) * 4 < KS) {
@@ -264,10 +238,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
             for (int t = 0; t < TM; ++t) {
                 const f32x4 c0 = ks == 0 ? (f32x4{0.f, 0.f, 0.f, 0.f}) : out[t];
                 out[t] = SWAP ? MFMA16(bop, bq[ks & 1][t], c0) : MFMA16(bq[ks & 1][t], bop, c0);
-#if INR2_BWD_SPREAD
                 if (ks + 1 < KS) bq[(ks + 1) & 1][t] = b_row(ks + 1)[16 * t];   // next k-step's operands, one read per product
                 OPERAND_FENCE();
-#endif
             }
             if (DX) outx = SWAP ? MFMA16(bop, bqx[ks & 1], outx) : MFMA16(bqx[ks & 1], bop, outx);
             MFMA_STEP_FENCE();
@@ -400,7 +372,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
 #pragma unroll
             for (int t = 0; t < TM; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) z[t][r] = fmaxf(z[t][r], 0.f);
+                for (int r = 0; r < 4; ++r) z[t][r] = relu0(z[t][r]);
         };
         f32x4 z0last;  // last k-group of z0ext: leftover hidden units (lane group 0) + ext inputs (lane groups 1-2)
         {
@@ -423,12 +395,12 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
 #pragma unroll
             for (int t = 0; t < TM; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) z1[t][r] = fmaxf(acc[t][r], 0.f);
+                for (int r = 0; r < 4; ++r) z1[t][r] = relu0(acc[t][r]);
         }
 #pragma unroll
         for (int u = 0; u < HRA; ++u) z1l[u] = 0.f;
 #pragma unroll
-        for (int u = 0; u < HR; ++u) z1l[u] = fmaxf(sum_over_groups(la[u]), 0.f);
+        for (int u = 0; u < HR; ++u) z1l[u] = relu0(sum_over_groups(la[u]));
         // last k-group of z1ext: lane group 0 = leftover units, lane groups 1-2 = the same ext inputs as in z0ext
 #pragma unroll
         for (int r = 0; r < 4; ++r) z1[TM][r] = g == 0 ? (r < HR ? z1l[r < HRA ? r : 0] : 0.f) : z0last[r];
@@ -446,7 +418,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
         for (int t = 0; t < TM; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                acc2[t][r] = fmaxf(acc2[t][r], 0.f);  // z2
+                acc2[t][r] = relu0(acc2[t][r]);  // z2
                 ypart = fmaf(wo[t][r], acc2[t][r], ypart);
             }
         ypart = sum_over_groups(ypart);
@@ -454,7 +426,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
         for (int u = 0; u < HRA; ++u) z2l[u] = 0.f;
 #pragma unroll
         for (int u = 0; u < HR; ++u) {
-            z2l[u] = fmaxf(sum_over_groups(la[u]), 0.f);
+            z2l[u] = relu0(sum_over_groups(la[u]));
             ypart = fmaf(wol[u], z2l[u], ypart);
         }
         float y = ypart + b_o;

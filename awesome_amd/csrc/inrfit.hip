@@ -464,6 +464,37 @@ Workspace carve(const KernelEntry* e, long long n_points, int n_images, void* ba
 
 }  // namespace
 
+// Measurement only (bench.py): nothing but independent v_mfma_f32_16x16x4_f32 on every SIMD of the chip - what the matrix pipes
+// sustain at the clock the chip holds under that load (tools/micro/mfma_rate.hip is the stand-alone version with LDS variants).
+__global__ __launch_bounds__(256) void mfma_stream_kernel(float* __restrict__ sink, int iters) {
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // operands with the bit activity of real data (the clock the chip holds depends on it): 36 pseudo-random values in (-1, 1)
+    f32x4 av[8], bv;
+    unsigned h = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+    auto rnd = [&]() { h = h * 1664525u + 1013904223u; return (float)(int)(h >> 8) * (1.f / 8388608.f) - 1.f; };
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) av[t][r] = rnd();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = rnd();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] = MFMA16(av[t][r], bv[r], acc[t]);
+            __builtin_amdgcn_sched_barrier(0x7F6);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+    if (s == 12345.678f) sink[blockIdx.x * 256 + threadIdx.x] = s;   // never true: keeps the products alive
+}
+
+
 extern "C" {
 
 int inrfit_query(int* abi_version, int* max_hidden, int* lds_bytes) {
@@ -676,6 +707,13 @@ int inrfit_step_only(const InrModelDesc* model, const float* params, const InrGr
     for (int it = 0; it < iters; ++it)
         if ((rc = launch_step_timed(e, w, grid, targets, loss->kind, n_images, s))) return rc;
     return INR_OK;
+}
+
+int inrfit_mfma_stream(int workgroups, int iters, double* flop, void* scratch, void* stream) {
+    if (workgroups <= 0 || workgroups > 65535 || iters <= 0 || !scratch) return INR_EINVAL;
+    hipLaunchKernelGGL(mfma_stream_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (float*)scratch, iters);
+    if (flop) *flop = 2.0 * 16 * 16 * 4 * 32.0 * iters * 4.0 * workgroups;   // 32 products per iteration and wave, 4 waves
+    return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 
 static void timing_clear() {
@@ -1483,6 +1521,11 @@ int inrfit_pack_masks(const float* values, int n_images, int64_t n_points, float
 #if INR_STAMPS
 int inrfit_debug_stamps(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -4;
+}
+int inrfit_debug_wgtimes(unsigned long long* host_out) {   // [1024][4], then cleared for the next launch
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wgtimes), sizeof(unsigned long long) * 4096) != hipSuccess) return -4;
+    static unsigned long long zeros[4096];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wgtimes), zeros, sizeof(zeros)) == hipSuccess ? 0 : -4;
 }
 #endif
 

@@ -267,6 +267,22 @@ def step_only(spec: IcnnSpec, params: Tensor, grid: Grid, targets: Tensor, iters
     return ws
 
 
+def mfma_stream_tflops(device, workgroups: int = 256, iters: int = 12000) -> float:
+    """Measurement hook: TFLOP/s of a launch that issues nothing but independent fp32 16x16x4 MFMAs on `workgroups` x 4 waves -
+    what the matrix pipes sustain at the clock the chip holds under that load (the practical ceiling under the nominal peak)."""
+    scratch = torch.empty(workgroups * 256, dtype=torch.float32, device=device)
+    flop = C.c_double(0.0)
+    lib = L.load()
+    sp = _stream_ptr(torch.device(device))
+    L.check(lib.inrfit_mfma_stream(workgroups, 2000, C.byref(flop), scratch.data_ptr(), sp), "inrfit_mfma_stream")   # warm (clocks up)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.check(lib.inrfit_mfma_stream(workgroups, int(iters), C.byref(flop), scratch.data_ptr(), sp), "inrfit_mfma_stream")
+    e1.record()
+    torch.cuda.synchronize(device)
+    return flop.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+
 @dataclass
 class FitResult:
     params: Tensor            # [n_images, P] final parameters (same storage as the input)

@@ -160,12 +160,16 @@ def main():
     if B == 1 and S == 256 and os.path.exists(tf):
         with open(tf) as f:
             traffic = json.load(f).get("traffic_bytes_per_launch")
+    # what a launch of nothing but independent fp32 MFMAs on all 1024 SIMDs reaches on THIS box (~2.1 GHz under that load instead
+    # of the 2.4 GHz the nominal peak assumes): the practical ceiling, reported next to `peak`, never instead of it
+    mfma_stream = A.icnn.mfma_stream_tflops(dev)
     roofline = {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": traffic,
                 "kernel": "icnn_step_kernel<130,2,train>", "kernel_us": round(kernel_ms * 1e3, 2),
                 "kernel_samples": seq.samples, "kernel_us_back_to_back": round(kernel_b2b_ms * 1e3, 2),
                 "update_kernel_us": round(update_us, 2), "event_bracket_excess_us": round(excess, 2),
-                "flop_per_launch": flop_per_launch}
+                "flop_per_launch": flop_per_launch, "mfma_only_stream_tflops": round(mfma_stream, 1),
+                "frac_of_mfma_only_stream": round(achieved / mfma_stream, 4)}
 
     # ---- throughput mode (extra, not `value`): configs[2]'s per-GPU share, one complete E-step fit of a batch ---------
     thr = None

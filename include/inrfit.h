@@ -267,6 +267,12 @@ int inrfit_step_only(const InrModelDesc* model, const float* params, const InrGr
                      const InrLossDesc* loss, int n_images, int iters, void* workspace, int64_t workspace_bytes,
                      void* stream);
 
+/* Measurement hook (bench.py): one launch of `workgroups` x 4 waves that issue nothing but independent fp32 16x16x4 MFMAs
+ * (32 * iters per wave); *flop = the products' flops.  Timed by the caller, it gives the matrix-pipe rate the chip sustains at
+ * the clock it holds under full MFMA load - the practical ceiling next to the nominal peak.  `scratch`: any device buffer of
+ * >= workgroups * 1 KiB (never written in practice). */
+int inrfit_mfma_stream(int workgroups, int iters, double* flop, void* scratch, void* stream);
+
 /* Measurement hook (bench.py): between begin and end, inrfit_fit and inrfit_step_only calls of this thread bracket each of
  * their (first max_samples) step-kernel launches - inrfit_fit also its update-kernel launches - with a pair of HIP events on
  * the launch stream; end waits for them and returns the average elapsed time of a bracket in microseconds (0 if none).
