@@ -392,6 +392,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
     unsigned long long st_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
     const unsigned long long st_begin = st_prev;
+    unsigned long long st_f0 = 0, st_fsum = 0;
     const unsigned long long rt_loop = __builtin_amdgcn_s_memrealtime();
 #endif
     for (int chunk = wg; chunk < n_chunks; chunk += a.wgs) {
@@ -460,6 +461,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                     wo[i] = *(const f32x4*)&woT[16 * i + 4 * g];
                 }
             };
+#if INR_STAMPS
+            if (tk == 2) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_f0)::"memory"); __builtin_amdgcn_sched_barrier(0); }
+            if (tk == 7) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); __builtin_amdgcn_sched_barrier(0); st_fsum += t_ - st_f0; }
+#endif
             if (tk == (KG > 2 ? 1 : 0)) {   // next chunk's inputs: address arithmetic in the shadow of these products, latency under the chunk
                 const int cn = chunk + a.wgs;
                 nxt = load_point(cn < n_chunks ? cn : chunk);
@@ -634,19 +639,14 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 if (DX) dzx = MFMA16(bop, bqx[ks & 1], dzx);
                 MFMA_STEP_FENCE();
                 if (r == 1 && tk + 1 < TM) dz1_tile(tk + 1);  // next tile's dz1 + staging, in the shadow of the MFMAs
-                if (r == 3 || ks == KS - 1) {  // leftover hidden inputs: dz0l[u] += W1[:, HM+u] . dz1 over this tile
+                // leftover hidden inputs: dz0l[u] += W1[:, HM+u] . dz1 - this k-step's share (HR FMAs per MFMA block, not 4 HR
+                // in one gap every fourth block)
 #pragma unroll
-                    for (int u = 0; u < HR; ++u) {
-                        if (tk < TM) {
-#pragma unroll
-                            for (int rr = 0; rr < 4; ++rr)
-                                dz0l[u] = fmaf(wcq[tk & 1][u][rr], acc[tk < TM ? tk : 0][rr], dz0l[u]);
-                        } else if (g == 0) {
-#pragma unroll
-                            for (int rr = 0; rr < HR; ++rr) dz0l[u] = fmaf(wcq[tk & 1][u][rr], dzl[rr], dz0l[u]);
-                        }
-                    }
+                for (int u = 0; u < HR; ++u) {
+                    if (tk < TM) dz0l[u] = fmaf(wcq[tk & 1][u][r], acc[tk < TM ? tk : 0][r], dz0l[u]);
+                    else if (g == 0) dz0l[u] = fmaf(wcq[tk & 1][u][r], dzl[r < HRA ? r : 0], dz0l[u]);
                 }
+                MFMA_STEP_FENCE();
             }
             STAMP(4);
             // relu mask of layer 0 (z0p, computed before the output layer); then dL0[t] += dZ0[:, tile t]^T . ext columns of
@@ -736,43 +736,43 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                     for (int b = 0; b < KG; ++b) bf[0][b] = stB[pt * G::SB + 16 * b + l15];
                 }
 #pragma unroll
-            for (int it = 0; it < SP / 4; ++it) {
-                const int cur = it & 1, nx = cur ^ 1;
-                const int ptc = stage_pt(it), ptn = stage_pt(it + 1 < SP / 4 ? it + 1 : it);
-                // next k-step's operands, one ds_read after each of the first RPW + KG products (never two in a row: an LDS read
-                // holds the issue port, a burst lets the matrix pipe run dry)
-                auto next_read = [&](int i) {
-                    if (it + 1 < SP / 4) {
-                        if (i < RPW) af[nx][i] = stA[ptn * G::SA + arow + 16 * i];
-                        else if (i < RPW + KG) bf[nx][i - RPW] = stB[ptn * G::SB + 16 * (i - RPW) + l15];
-                    }
-                };
-                if (HR > 0 && (it & 3) == 0) {  // every wave takes a quarter of the k-steps for the leftover rows
-                    const f32x4 dl = *(const f32x4*)(stA + ptc * G::SA + HM);
-#pragma unroll
-                    for (int u = 0; u < HR; ++u)
-#pragma unroll
-                        for (int b = 0; b < KG; ++b) dWl[u][b] = fmaf(dl[u], bf[cur][b], dWl[u][b]);
-                }
-                if (row_ok) {
-#pragma unroll
-                    for (int j = 0; j < RPW; ++j)
-#pragma unroll
-                        for (int b = 0; b < KG; ++b) {
-                            dW[j][b] = MFMA16(af[cur][j], bf[cur][b], dW[j][b]);
-                            next_read(j * KG + b);
-                            OPERAND_FENCE();
+                for (int it = 0; it < SP / 4; ++it) {
+                    const int cur = it & 1, nx = cur ^ 1;
+                    const int ptc = stage_pt(it), ptn = stage_pt(it + 1 < SP / 4 ? it + 1 : it);
+                    // next k-step's operands, one ds_read after each of the first RPW + KG products (never two in a row: an LDS read
+                    // holds the issue port, a burst lets the matrix pipe run dry)
+                    auto next_read = [&](int i) {
+                        if (it + 1 < SP / 4) {
+                            if (i < RPW) af[nx][i] = stA[ptn * G::SA + arow + 16 * i];
+                            else if (i < RPW + KG) bf[nx][i - RPW] = stB[ptn * G::SB + 16 * (i - RPW) + l15];
                         }
-                } else {
+                    };
+                    if (HR > 0 && (it & 3) == 0) {  // every wave takes a quarter of the k-steps for the leftover rows
+                        const f32x4 dl = *(const f32x4*)(stA + ptc * G::SA + HM);
 #pragma unroll
-                    for (int i = 0; i < RPW + KG; ++i) next_read(i);
-                }
-                if (RPW * KG < RPW + KG) {
+                        for (int u = 0; u < HR; ++u)
 #pragma unroll
-                    for (int i = RPW * KG; i < RPW + KG; ++i) next_read(i);
+                            for (int b = 0; b < KG; ++b) dWl[u][b] = fmaf(dl[u], bf[cur][b], dWl[u][b]);
+                    }
+                    if (row_ok) {
+#pragma unroll
+                        for (int j = 0; j < RPW; ++j)
+#pragma unroll
+                            for (int b = 0; b < KG; ++b) {
+                                dW[j][b] = MFMA16(af[cur][j], bf[cur][b], dW[j][b]);
+                                next_read(j * KG + b);
+                                OPERAND_FENCE();
+                            }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < RPW + KG; ++i) next_read(i);
+                    }
+                    if (RPW * KG < RPW + KG) {
+#pragma unroll
+                        for (int i = RPW * KG; i < RPW + KG; ++i) next_read(i);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            }
             }
             STAMP(7);
             __syncthreads();
@@ -923,6 +923,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
         g_stamps[9] = st_begin;     // (absolute) loop start
         g_stamps[10] = st_loop_end - st_begin;
         g_stamps[11] = t_end - st_loop_end;   // epilogue
+        g_stamps[12] = st_fsum;               // forward k-groups 2..6 (5 x 33 MFMAs per chunk)
     }
 #endif
 }

@@ -243,17 +243,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
             }
             if (DX) outx = SWAP ? MFMA16(bop, bqx[ks & 1], outx) : MFMA16(bqx[ks & 1], bop, outx);
             MFMA_STEP_FENCE();
-            if (r == 3 || ks == KS - 1) {
 #pragma unroll
-                for (int u = 0; u < HR; ++u) {
-                    if (tk < TM) {
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) outl[u] = fmaf(wcq[tk & 1][u][rr], dz[tk < TM ? tk : 0][rr], outl[u]);
-                    } else if (g == 0) {
-#pragma unroll
-                        for (int rr = 0; rr < HR; ++rr) outl[u] = fmaf(wcq[tk & 1][u][rr], dzl[rr], outl[u]);
-                    }
-                }
+            for (int u = 0; u < HR; ++u) {  // leftover hidden inputs, this k-step's share
+                if (tk < TM) outl[u] = fmaf(wcq[tk & 1][u][r], dz[tk < TM ? tk : 0][r], outl[u]);
+                else if (g == 0) outl[u] = fmaf(wcq[tk & 1][u][r], dzl[r < HRA ? r : 0], outl[u]);
             }
         }
     };

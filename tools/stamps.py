@@ -27,6 +27,8 @@ tot = buf[10]
 for k, n in enumerate(names):
     print(f"{n:36s} {buf[k]:9d} cycles  {100.0 * buf[k] / tot:5.1f}%")
 print(f"{'loop total':36s} {tot:9d} cycles ; epilogue after loop {buf[11]} cycles")
+if buf[12]:
+    print(f"forward k-groups 2..6: {buf[12]} cycles = {buf[12] / (4 * 5 * 33):.2f} cycles per MFMA (4 chunks x 5 k-groups x 33)")
 
 # ---- per-workgroup wall clock of ONE launch (s_memrealtime, 100 MHz) against the HIP-event duration of the same launch ----
 import numpy as np
