@@ -16,7 +16,8 @@
 // 16.4 us per chunk against 15.0 us for icnn_step_kernel; front waves alone 12.8 us (592 MFMAs: 38 spilled registers at the
 // 256-register budget and the per-chunk DPP reduction of d w_o cost ~4 k cycles), back waves alone 5.6 us (320 MFMAs; the z0 rebuild
 // of each 16-point group is one serial LDS -> MFMA -> VALU -> LDS chain), together only 2 us less than their sum: the two streams
-// alternate on the matrix pipe instead of one filling the other's gaps, and s_setprio on the front waves changes nothing.  With 4
+// alternate on the matrix pipe instead of one filling the other's gaps; s_setprio on the front waves changes nothing and
+// throttling the back waves with s_sleep (to spread their products over the whole chunk) makes it slower.  With 4
 // chunks per workgroup (one 256x256 image) the extra pipeline stage costs what the overlap gains (76.0 vs 70.5 us per launch).
 // Selected with INRFIT_RW=1 in the environment.
 #pragma once
