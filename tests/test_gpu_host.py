@@ -166,3 +166,47 @@ def test_fcnet_no_prior_network_on_hip(golden_dir, name, width, depth):
     flat = res.params[0].cpu()
     sd_i = A.unpack_params(m.spec, flat)
     assert all(float(sd_i[k].abs().max()) == 0.0 for k in sd_i if k.endswith("skp.weight"))   # never moved
+
+
+def test_mfma_stream_hook():
+    """inrfit_mfma_stream (bench.py's `mfma_only_stream_tflops`): a launch of nothing but fp32 MFMAs must land between a third of
+    and just above the nominal 157.3 TFLOP/s - it is the yardstick next to roofline.peak, so a broken count would mislead."""
+    import awesome_amd as A
+    t = A.icnn.mfma_stream_tflops("cuda:0", workgroups=256, iters=3000)
+    assert 50.0 < t < 165.0, t
+
+
+def test_prior_bank_joint_step_and_prefit(golden_dir):
+    """Joint-training step on a bank-bound prior model (forward/backward on the HIP path, torch optimizer on the views) equals the
+    same step on a stand-alone copy bit for bit, and PriorBank.fit updates the resident rows exactly like awesome_amd.fit."""
+    import copy
+    import awesome_amd as A
+    from awesome_amd.model import ConvexNextNet
+    from awesome_amd.prior_bank import PriorBank
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    factory = lambda: ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=1).to(dev)
+    bank = PriorBank(factory, n_images=4, device=dev)
+    model = factory()
+    x = torch.rand(1, 2, 24, 24, device=dev)
+    target = (torch.rand(1, 1, 24, 24, device=dev) > 0.5).float()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    for key in (3, 1, 3):
+        with bank.manager(model, key):
+            twin = copy.deepcopy(model)                       # same values, own storage
+            topt = torch.optim.Adam(twin.parameters(), lr=1e-2)
+            topt.load_state_dict(copy.deepcopy(opt.state_dict()))
+            for m, o in ((model, opt), (twin, topt)):
+                o.zero_grad()
+                loss = ((torch.sigmoid(m(x)) - target) ** 2).mean()
+                loss.backward()
+                o.step()
+                m.enforce_convexity()
+            assert torch.equal(bank.row(key), twin.flat_parameters())
+    # per-image pre-fit straight on the rows
+    S = 32
+    grid = A.Grid.linspace(S, S, dev)
+    un = torch.stack([(torch.rand(S * S, device=dev) > 0.5).float() for _ in range(2)])
+    expect = A.fit(model.spec, bank.rows([1, 2]).contiguous(), grid, un, 50, lr=2e-3).params
+    bank.fit([1, 2], grid, un, 50, lr=2e-3)
+    assert torch.equal(bank.rows([1, 2]), expect)

@@ -185,3 +185,42 @@ def test_oracle_rnvp_restatement_properties():
     ea, at = torch.exp(sd["flow_net.net.network.flows.1.s"]), sd["flow_net.net.network.flows.1.t"]
     np.testing.assert_allclose(z1[:, 0].numpy(), (z[:, 0] * ea[0, 0] + at[0, 0]).numpy(), rtol=1e-6, atol=1e-6)
     assert float((z1[:, 1] - (z[:, 1] * ea[0, 1] + at[0, 1])).abs().max()) > 1e-3
+
+
+def test_prior_bank_swap_is_an_index():
+    """PriorBank: the PriorManager / PriorCache pair of the joint-training path with all priors in one tensor.
+    Host logic only (CPU tensors): binding re-points the parameters at a row, a step inside the manager is stored without a
+    copy, keys get fresh initialisations lazily, and the export has PriorCache.get_state()'s layout."""
+    from awesome_amd.model import ConvexNextNet
+    from awesome_amd.prior_bank import PriorBank
+    torch.manual_seed(0)
+    factory = lambda: ConvexNextNet(n_hidden=32, in_features=2, n_hidden_layers=1)
+    bank = PriorBank(factory, n_images=3, device="cpu")
+    model = factory()
+    opt = torch.optim.SGD(model.parameters(), lr=0.5)
+    ref_keys = list(model.state_dict().keys())
+    assert 7 not in bank and len(bank) == 3
+    with bank.manager(model, 7):
+        assert 7 in bank
+        before = bank.row(7).clone()
+        for p in model.parameters():
+            assert p.data_ptr() >= bank.params.data_ptr() and p.data_ptr() < bank.params.data_ptr() + bank.params.numel() * 4
+        loss = sum((p ** 2).sum() for p in model.parameters())     # any differentiable function of the parameters
+        opt.zero_grad(); loss.backward(); opt.step()
+    torch.testing.assert_close(bank.row(7), before * (1 - 0.5 * 2))      # p <- p - lr * 2p, written straight into the bank
+    with bank.manager(model, "b"):                                        # another key: a fresh prior, row 7 untouched
+        assert not torch.equal(bank.row("b"), bank.row(7))
+        model.enforce_convexity()
+        assert float(model.state_dict()["skip.0.ln.weight"].min()) >= 0.0
+    torch.testing.assert_close(bank.row(7), before * 0.0)
+    with bank.manager(model, 7):                                          # back to key 7: the model sees the stored step
+        flat = torch.cat([p.detach().reshape(-1) for p in model._ordered_params()])
+        assert torch.equal(flat, bank.row(7))
+    st = bank.get_state(model_args={"n_hidden": 32})
+    assert set(st) == {"model_type", "model_args", "store_device", "cache"} and set(st["cache"]) == {"7", "b"}
+    assert list(st["cache"]["b"].keys()) == ref_keys
+    for k, v in st["cache"]["b"].items():
+        assert v.shape == model.state_dict()[k].shape
+    bank.index_of("c")
+    with pytest.raises(KeyError):
+        bank.index_of("d")
