@@ -146,8 +146,10 @@ class FBMSJointLoss:
         seg, prior = output[:, :c], output[:, c:]
         seg_loss = self.alpha * self.criterion(seg, target)
         pen = self.beta * self.penalty_criterion(prior, seg)
-        if self.clip_penalty and bool(pen > seg_loss):
-            pen = pen * (seg_loss / pen).detach()
+        if self.clip_penalty:
+            # the reference branches on the host (`if penalty > seg_loss`, one device->host sync per step); same values, no sync
+            scale = torch.where(pen > seg_loss, seg_loss / pen, torch.ones_like(pen)).detach()
+            pen = pen * scale
         return seg_loss + pen
 
     def get_name(self) -> str:

@@ -224,3 +224,29 @@ def test_prior_bank_swap_is_an_index():
     bank.index_of("c")
     with pytest.raises(KeyError):
         bank.index_of("d")
+
+
+def test_fbms_joint_loss_clip_without_host_sync():
+    """FBMSJointLoss (awesome/measures/fbms_joint_loss.py:35-59): alpha crit(seg, t) + clipped beta SE(prior, seg).  The clip is
+    a device-side select here (the reference branches on the host); values and gradients must be those of the reference formula
+    in both regimes."""
+    from awesome_amd.measures.losses import FBMSJointLoss, SE
+    torch.manual_seed(1)
+    for beta in (0.05, 50.0):                                   # penalty below / above the segmentation loss
+        out = torch.rand(2, 2, 8, 8, requires_grad=True)
+        tgt = (torch.rand(2, 1, 8, 8) > 0.5).float()
+        crit = FBMSJointLoss(criterion=SE("mean"), penalty_criterion=SE("mean"), alpha=1.0, beta=beta)
+        loss = crit(out, tgt)
+        g, = torch.autograd.grad(loss, out)
+        o2 = out.detach().clone().requires_grad_(True)
+        seg, pri = o2[:, :1], o2[:, 1:]
+        sl = ((tgt - seg) ** 2).mean()
+        pl = beta * ((seg - pri) ** 2).mean()
+        clipped = bool(pl > sl)
+        if clipped:
+            pl = pl * (sl / pl).detach()
+        ref = sl + pl
+        g2, = torch.autograd.grad(ref, o2)
+        assert clipped == (beta > 1.0)
+        torch.testing.assert_close(loss, ref)
+        torch.testing.assert_close(g, g2)
