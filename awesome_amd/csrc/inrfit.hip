@@ -1361,6 +1361,26 @@ int inrfit_rnvp_actnorm_init(const InrRnvpDesc* rnvp, float* flow_params, const 
     a.m = w.rm;
     const size_t lds = (size_t)(RNVP_HDR + w.rm.fl) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
+    const long long N = grid->n_points;
+    if (N >= 16384) {
+        // large grids: 2 F + 1 launches over all points instead of one block per image (13 ms at 128x128x16, F = 18)
+        RnvpInitParArgs pa{};
+        pa.b = a;
+        pa.nb = (int)((N + 1023) / 1024);
+        if (pa.nb > 256) pa.nb = 256;
+        pa.part = (double*)w.dxd;   // [n_images][2][nb][C] doubles: 48 KB at most per image, dxd has C N floats
+        const dim3 g((unsigned)pa.nb, (unsigned)n_images);
+        for (int f = 0; f <= w.rm.F; ++f) {
+            pa.f = f;
+            if (w.rm.C == 2) hipLaunchKernelGGL(rnvp_init_couple_kernel<2>, g, dim3(256), lds, s, pa);
+            else hipLaunchKernelGGL(rnvp_init_couple_kernel<3>, g, dim3(256), lds, s, pa);
+            if (f < w.rm.F) {
+                if (w.rm.C == 2) hipLaunchKernelGGL(rnvp_init_var_kernel<2>, g, dim3(256), 0, s, pa);
+                else hipLaunchKernelGGL(rnvp_init_var_kernel<3>, g, dim3(256), 0, s, pa);
+            }
+        }
+        return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
+    }
     if (w.rm.C == 2) hipLaunchKernelGGL(rnvp_actnorm_init_kernel<2>, dim3(n_images), dim3(1024), lds, s, a);
     else hipLaunchKernelGGL(rnvp_actnorm_init_kernel<3>, dim3(n_images), dim3(1024), lds, s, a);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;

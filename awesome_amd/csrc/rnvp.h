@@ -967,4 +967,129 @@ __global__ __launch_bounds__(1024) void rnvp_actnorm_init_kernel(const RnvpInitA
     }
 }
 
+// ---- the same initialisation spread over the chip (large grids: one block walking 262 144 points 3 x 18 times takes 13 ms) ------
+// Per flow two launches over all points: (A) finish the previous flow - its (s, t) from the statistics every block re-derives from
+// the per-block partial sums, in fixed order - apply them, run this flow's coupling, write per-block sums of the result;
+// (B) per-block sums of squared deviations from the mean.  A last (A) launch with f = F only finishes flow F - 1.
+// part: [n_images][2][nb][C] doubles (sums | squared deviations), one slot per block, no atomics: reproducible.
+struct RnvpInitParArgs {
+    RnvpInitArgs b;
+    double* part;
+    int nb, f;
+};
+
+__device__ __forceinline__ double block_sum_d256(double v, double* sm) {   // 256 threads, fixed order
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((sm[0] + sm[1]) + sm[2]) + sm[3];
+}
+
+template <int C>
+__device__ __forceinline__ void rnvp_init_stats(const RnvpInitParArgs& a, int img, double (&mean)[C], double (&ssq)[C]) {
+    const double* ps = a.part + ((size_t)img * 2 + 0) * a.nb * C;
+    const double* pq = a.part + ((size_t)img * 2 + 1) * a.nb * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        double t = 0.0, q = 0.0;
+        for (int k = 0; k < a.nb; ++k) {
+            t += ps[(size_t)k * C + c];
+            q += pq[(size_t)k * C + c];
+        }
+        mean[c] = t / (double)a.b.N;
+        ssq[c] = q;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void rnvp_init_couple_kernel(const RnvpInitParArgs a) {
+    const int img = blockIdx.y, N = (int)a.b.N, f = a.f;
+    extern __shared__ __attribute__((aligned(16))) float rsm[];   // header + ONE flow
+    __shared__ double smd[4];
+    float* __restrict__ rp = a.b.RP + (size_t)img * a.b.m.RP;
+    float* __restrict__ zb = a.b.z + (size_t)img * C * N;
+    float sc[C], sh[C];   // ActNorm of the previous flow: z <- z * sc + sh
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        sc[c] = 1.f;
+        sh[c] = 0.f;
+    }
+    if (f > 0) {
+        double mean[C], ssq[C];
+        rnvp_init_stats<C>(a, img, mean, ssq);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float mu = (float)mean[c];
+            const float sd = (float)sqrt(ssq[c] / (double)(N > 1 ? N - 1 : 1));
+            const float as = -logf(sd + 1e-6f);
+            sc[c] = expf(as);
+            sh[c] = -mu * expf(as);
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                rp[2 * C + (size_t)(f - 1) * a.b.m.pf + 2 * a.b.m.net + c] = as;
+                rp[2 * C + (size_t)(f - 1) * a.b.m.pf + 2 * a.b.m.net + C + c] = sh[c];
+            }
+        }
+    }
+    if (f >= a.b.m.F) return;   // finishing launch
+    rnvp_params_to_lds<C>(rp, rsm, a.b.m, f, f + 1);
+    const FlowIdx x = flow_idx<C>(a.b.m.masks[f]);
+    double s[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) s[c] = 0.0;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < N; p += a.nb * 256) {
+        float z[1][C];
+        if (f == 0) {
+            float xin[C];
+            load_coords<C>(a.b.grid, img, a.b.N, p, xin);
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                z[0][c] = minmax_fwd(fmaf(rsm[c], xin[c], rsm[3 + c]), a.b.m.vmin[c], a.b.m.vmax[c], a.b.m.nmin, a.b.m.nmax);
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) z[0][c] = fmaf(zb[(size_t)c * N + p], sc[c], sh[c]);
+        }
+        rnvp_flow_forward<C, false, 1>(rsm + RNVP_HDR, a.b.m, x, z);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            zb[(size_t)c * N + p] = z[0][c];
+            s[c] += (double)z[0][c];
+        }
+    }
+    double* ps = a.part + (((size_t)img * 2 + 0) * a.nb + blockIdx.x) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const double t = block_sum_d256(s[c], smd);
+        if (threadIdx.x == 0) ps[c] = t;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void rnvp_init_var_kernel(const RnvpInitParArgs a) {
+    const int img = blockIdx.y, N = (int)a.b.N;
+    __shared__ double smd[4];
+    const float* __restrict__ zb = a.b.z + (size_t)img * C * N;
+    double mean[C], dummy[C];
+    rnvp_init_stats<C>(a, img, mean, dummy);
+    float mu[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) mu[c] = (float)mean[c];   // the statistic is kept in fp32, like the one-block kernel does
+    double q[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) q[c] = 0.0;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < N; p += a.nb * 256) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const double d = (double)zb[(size_t)c * N + p] - (double)mu[c];
+            q[c] += d * d;
+        }
+    }
+    double* pq = a.part + (((size_t)img * 2 + 1) * a.nb + blockIdx.x) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const double t = block_sum_d256(q[c], smd);
+        if (threadIdx.x == 0) pq[c] = t;
+    }
+}
+
 }  // namespace

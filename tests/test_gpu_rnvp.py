@@ -138,12 +138,12 @@ def test_separable_grid_with_time_channel(dev):
         np.testing.assert_allclose(y[i].cpu().numpy(), yo.reshape(-1).numpy(), rtol=1e-4, atol=5e-5)
 
 
-@pytest.mark.parametrize("C,F", [(2, 12), (3, 6)])
-def test_actnorm_data_dependent_init(dev, C, F):
+@pytest.mark.parametrize("C,F,H,W", [(2, 12, 24, 20), (3, 6, 24, 20), (2, 12, 136, 128), (3, 18, 136, 128)])
+def test_actnorm_data_dependent_init(dev, C, F, H, W):
+    """One block per image below 16 384 points, 2 F + 1 launches over all points above (same statistics, other summation order)."""
     from awesome_amd import rnvp as R
     import awesome_amd as A
     ispec, rspec, sd = _case(C, 32, F, 1, seed=5)
-    H, W = 24, 20
     grid_t, rows = _rows(C, H, W)
     masks = O.rnvp_masks(C, F)
     sdo = {k: v.clone() for k, v in sd.items()}
