@@ -3,3 +3,4 @@ from .diffeomorphism_net import ConvexDiffeomorphismNet, NormalBlock, Normalizin
 from .wrapper_module import ForwardModule, WrapperModule  # noqa: F401
 from .path_connected_net import PathConnectedNet, real_nvp_path_connected_net  # noqa: F401
 from .fc_net import FCNet  # noqa: F401
+from .zoo import Zoo  # noqa: F401

@@ -291,9 +291,19 @@ class PathConnectedNet(nn.Module):
             chans.append(grid.ts[0].expand(chans[0].numel()))
         return torch.stack(chans, 0)
 
-    def learn_flow_identity(self, grid: "K.Grid", lr: float = 1e-2, weight_decay: float = 1e-5, max_iter: int = 1000) -> torch.Tensor:
+    def learn_flow_identity(self, grid: "K.Grid", lr: float = 1e-2, weight_decay: float = 1e-5, max_iter: int = 1000,
+                            zoo=None) -> torch.Tensor:
         """path_connected_net.py:155-250 on the HIP path: Adamax on the flow_net alone towards flow_net(x) = x; updates this
-        module's flow parameters in place and returns the loss history."""
+        module's flow parameters in place and returns the loss history.  `zoo` (awesome_amd.model.zoo.Zoo): like the reference
+        (:177-194, :246-248) a stored flow for this architecture, grid and hyper-parameters is loaded instead of fitted."""
+        zoo_config = None
+        if zoo is not None:
+            from .zoo import tensor_hash
+            zoo_config = dict(lr=lr, weight_decay=weight_decay, max_iter=max_iter, criterion="SE(mean)",
+                              x_data=tensor_hash(self._first_image_coords(grid)))
+            loaded, context = zoo.load_model_state("flow_identity", self.flow_net, config=zoo_config)
+            if loaded:
+                return context.get("loss_hist", None)
         self._actnorm_init_if_needed(self._first_image_coords(grid))
         _, rspec, _, flow = self._ordered_params()
         fp = self._flat(flow)
@@ -304,6 +314,8 @@ class PathConnectedNet(nn.Module):
             for k, v in new.items():
                 if not k.startswith("linear."):
                     own[k].copy_(v.to(own[k].device))
+        if zoo is not None:
+            zoo.save_model_state("flow_identity", self.flow_net, config=zoo_config, context=dict(loss_hist=hist[0].cpu()))
         return hist[0]
 
     def learn_convex_net(self, grid: "K.Grid", unaries: torch.Tensor, lr: float = 1e-3, weight_decay: float = 0.0,

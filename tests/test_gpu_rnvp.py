@@ -509,3 +509,28 @@ def test_tiny_grids(dev, C, H, W):
     pf, losses, _ = O.fit_pcn(sd, rows, un, 4, masks, vmin, vmax, lr=2e-3, flow_weight_decay=1e-3)
     res = R.pcn_fit(ispec, rspec, ip, fp, grid, un.reshape(1, -1).to(dev), 4, lr=2e-3, flow_weight_decay=1e-3)
     np.testing.assert_allclose(res.loss_hist[0].cpu().numpy(), np.asarray(losses, np.float32), rtol=5e-4)
+
+
+def test_learn_flow_identity_with_zoo(dev, tmp_path):
+    """learn_flow_identity(zoo=...) (path_connected_net.py:177-194, 246-248): the first model fits and stores, a second, freshly
+    initialised model of the same architecture on the same grid loads that state instead of fitting."""
+    import awesome_amd as A
+    from awesome_amd.model import Zoo, real_nvp_path_connected_net
+    zoo = Zoo(str(tmp_path))
+    grid = A.Grid.linspace(32, 32, dev)
+    torch.manual_seed(11)
+    m1 = real_nvp_path_connected_net(channels=2, flow_n_flows=4, hidden_units=16).to(dev)
+    h1 = m1.learn_flow_identity(grid, lr=1e-2, max_iter=30, zoo=zoo)
+    assert h1.shape[0] == 30 and float(h1[-1]) < float(h1[0])
+    torch.manual_seed(12)
+    m2 = real_nvp_path_connected_net(channels=2, flow_n_flows=4, hidden_units=16).to(dev)
+    before = {k: v.clone() for k, v in m2.flow_net.state_dict().items()}
+    h2 = m2.learn_flow_identity(grid, lr=1e-2, max_iter=30, zoo=zoo)
+    assert torch.equal(h2.cpu(), h1.cpu())
+    changed = 0
+    for k, v in m1.flow_net.state_dict().items():
+        assert torch.equal(m2.flow_net.state_dict()[k].cpu(), v.cpu()), k
+        changed += int(not torch.equal(before[k].cpu(), v.cpu()))
+    assert changed > 0
+    h3 = m2.learn_flow_identity(grid, lr=5e-3, max_iter=30, zoo=zoo)      # other hyper-parameters: a miss, fits again
+    assert not torch.equal(h3.cpu(), h1.cpu())

@@ -250,3 +250,31 @@ def test_fbms_joint_loss_clip_without_host_sync():
         assert clipped == (beta > 1.0)
         torch.testing.assert_close(loss, ref)
         torch.testing.assert_close(g, g2)
+
+
+def test_zoo_cache_round_trip(tmp_path):
+    """awesome_amd.model.Zoo (the role of awesome/model/zoo.py): keyed by name + repr(model) + config, not by the weights; a hit
+    loads the stored state and returns the context; entries survive on disk."""
+    from awesome_amd.model.zoo import Zoo, tensor_hash
+    torch.manual_seed(0)
+    make = lambda: torch.nn.Sequential(torch.nn.Linear(3, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
+    x = torch.rand(7, 3)
+    cfg = dict(lr=1e-2, max_iter=100, x_data=tensor_hash(x), criterion=torch.nn.MSELoss())
+    zoo = Zoo(str(tmp_path))
+    a = make()
+    assert zoo.load_model_state("flow_identity", a, config=cfg) == (False, None)
+    zoo.save_model_state("flow_identity", a, config=cfg, context=dict(loss_hist=torch.arange(3.0)))
+    b = make()                                                   # other weights, same architecture: a hit overrides them
+    assert not torch.equal(b[0].weight, a[0].weight)
+    ok, ctx = Zoo(str(tmp_path)).load_model_state("flow_identity", b, config=cfg)      # a new instance reads the file
+    assert ok and torch.equal(ctx["loss_hist"], torch.arange(3.0))
+    for k, v in a.state_dict().items():
+        assert torch.equal(b.state_dict()[k], v)
+    assert zoo.load_model_state("flow_identity", make(), config=dict(cfg, lr=2e-2))[0] is False        # other hyper-parameters
+    assert zoo.load_model_state("flow_identity", make(), config=dict(cfg, x_data=tensor_hash(x + 1)))[0] is False   # other grid
+    assert zoo.load_model_state("other_name", make(), config=cfg)[0] is False
+    wide = torch.nn.Sequential(torch.nn.Linear(3, 6), torch.nn.Tanh(), torch.nn.Linear(6, 2))
+    assert zoo.load_model_state("flow_identity", wide, config=cfg)[0] is False                        # other architecture
+    mem = Zoo(None)                                                                                   # memory only
+    mem.save_model_state("n", a, config=cfg)
+    assert mem.load_model_state("n", make(), config=cfg)[0] is True
