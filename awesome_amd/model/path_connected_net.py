@@ -342,7 +342,7 @@ class PathConnectedNet(nn.Module):
                    plateau=None, prefit_flow_net_identity: bool = False, prefit_flow_net_identity_lr: float = 1e-2,
                    prefit_flow_net_identity_weight_decay: float = 1e-5, prefit_flow_net_identity_num_epochs: int = 100,
                    prefit_convex_net: bool = False, prefit_convex_net_lr: float = 1e-3, prefit_convex_net_weight_decay: float = 0.0,
-                   prefit_convex_net_num_epochs: int = 200):
+                   prefit_convex_net_num_epochs: int = 200, zoo=None):
         """Fused device-resident form of _prior_based_pretrain (path_connected_net.py:871-962) for a batch of images: the
         optional pre-fit stages (flow towards the identity - it only depends on the grid, so it runs once on this module -
         then the convex net of every image on the deformed grid), then the joint inner loop.  Every image starts from this
@@ -352,7 +352,7 @@ class PathConnectedNet(nn.Module):
         self._actnorm_init_if_needed(self._first_image_coords(grid))
         if prefit_flow_net_identity:
             self.learn_flow_identity(grid, lr=prefit_flow_net_identity_lr, weight_decay=prefit_flow_net_identity_weight_decay,
-                                     max_iter=prefit_flow_net_identity_num_epochs)
+                                     max_iter=prefit_flow_net_identity_num_epochs, zoo=zoo)   # `zoo`: kwargs.get("zoo"), :560
         ispec, rspec, icnn, flow = self._ordered_params()
         ip = self._flat(icnn).repeat(n, 1).contiguous().to(dev)
         fp = self._flat(flow).repeat(n, 1).contiguous().to(dev)

@@ -140,6 +140,9 @@ def main(cfg):
         if hasattr(probe, "flow_net"):
             kw.update(weight_mode=wmode, flow_weight_decay=float(pre.get("flow_weight_decay", 1e-5)), optimizer=opt_type)
             kw.update({k: v for k, v in pre.items() if k.startswith("prefit_")})   # the reference's pre-fit stage kwargs
+            if pre.get("zoo"):   # pretrain_args.zoo: a folder (or "memory"): reuse the flow-identity pre-fit (path_connected_net.py:560)
+                from awesome_amd.model import Zoo
+                kw["zoo"] = Zoo(None if pre["zoo"] == "memory" else str(pre["zoo"]))
         model = probe.to(device)
         res = model.fit_images(grid, unaries, **kw)
         iou = A.miou(torch.sigmoid(res.logits), unaries)
