@@ -8,7 +8,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 template <int NACC, int MODE>
-__global__ __launch_bounds__(256) void rate_kernel(float* out, unsigned long long* cyc, int iters) {
+__global__ __launch_bounds__(512) void rate_kernel(float* out, unsigned long long* cyc, int iters) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < 32 * 1024; i += 256) lds[i] = 0.001f * (i & 63);
@@ -22,6 +22,16 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, unsigned long lon
     f32x4 b = f32x4{1.f + lane, 2.f, 3.f, 4.f};
     unsigned long long t0, t1;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    if (threadIdx.x >= 256) {   // second wave on every SIMD (512-thread launches only): VALU work only, same duration
+        float w[8] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
+        for (int it = 0; it < iters * (MODE == 0 ? 6 : 1); ++it) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) w[k & 7] = fmaf(w[k & 7], 1.0001f, 0.5f);
+        }
+        out[blockIdx.x * 512 + threadIdx.x] = w[0] + w[1] + w[2] + w[3] + w[4] + w[5] + w[6] + w[7];
+        return;
+    }
+    float vf[8] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
     auto body = [&](auto par, int it) {
         constexpr int cur = decltype(par)::value, nx = cur ^ 1;
         if (MODE == 1 || MODE == 3) {  // 8 x ds_read_b128 per 32 MFMAs, like the forward product
@@ -43,6 +53,19 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, unsigned long lon
 #pragma unroll
                     for (int t = 0; t < 4; ++t) a4[nx][4 * h + t][r] = q[t];
                 }
+        }
+        if (MODE >= 10) {   // K = MODE - 10 independent v_fma_f32 behind every MFMA (no LDS): how many VALU fillers fit a gap?
+            constexpr int K = MODE - 10;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    acc[t] = MFMA16(a4[cur][t][r], b[r], acc[t]);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) vf[k] = fmaf(vf[k], 1.0001f, b[(k + r) & 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            return;
         }
         if (MODE != 0) __builtin_amdgcn_sched_barrier(0x676);
         if (MODE == 5 || MODE == 6 || MODE == 7) {   // the same reads, one after every 4th (5: b128) / 2nd (6: b64) / every (7: b32) MFMA, pinned
@@ -84,7 +107,7 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, unsigned long lon
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < NACC; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
-    out[blockIdx.x * 256 + threadIdx.x] = s + b[0];
+    out[blockIdx.x * 256 + threadIdx.x] = s + b[0] + vf[0] + vf[1] + vf[2] + vf[3] + vf[4] + vf[5] + vf[6] + vf[7];
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
@@ -92,7 +115,7 @@ template <int NACC, int MODE>
 static void run(const char* name, int blocks, int threads) {
     float* out;
     unsigned long long* cyc;
-    hipMalloc(&out, 1024 * 256 * 4);
+    hipMalloc(&out, 1024 * 512 * 4);
     hipMalloc(&cyc, 1024 * 8);
     const int iters = 2000;
     hipFuncSetAttribute((const void*)rate_kernel<NACC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
@@ -114,7 +137,7 @@ static void run(const char* name, int blocks, int threads) {
 }
 
 int main() {
-    for (int blocks : {1, 256}) {
+    for (int blocks : {1}) {
         run<8, 0>("8 acc, no fillers", blocks, 256);
         run<18, 0>("18 acc, no fillers", blocks, 256);
         run<8, 1>("8 acc + 8 ds_read_b128 per 32", blocks, 256);
@@ -124,6 +147,12 @@ int main() {
         run<8, 5>("8 acc + 8 b128, one per 4 MFMAs", blocks, 256);
         run<8, 6>("8 acc + 16 b64, one per 2 MFMAs", blocks, 256);
         run<8, 7>("8 acc + 32 b32, one per MFMA", blocks, 256);
+        run<8, 0>("8 acc, no fillers + a VALU-only wave per SIMD", blocks, 512);
+        run<8, 5>("8 acc + 8 b128 spread + a VALU-only wave", blocks, 512);
+        run<8, 12>("8 acc + 2 v_fma per MFMA", blocks, 256);
+        run<8, 14>("8 acc + 4 v_fma per MFMA", blocks, 256);
+        run<8, 16>("8 acc + 6 v_fma per MFMA", blocks, 256);
+        run<8, 18>("8 acc + 8 v_fma per MFMA", blocks, 256);
         run<8, 1>("8 acc + 8 ds_read_b128 burst, 1 wave", blocks, 64);
         run<8, 5>("8 acc + 8 b128 spread, 1 wave", blocks, 64);
         run<8, 0>("8 acc, no fillers, 1 wave", blocks, 64);
