@@ -24,6 +24,22 @@ __global__ __launch_bounds__(512) void rate_kernel(float* out, unsigned long lon
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     if (threadIdx.x >= 256) {   // second wave on every SIMD (512-thread launches only): VALU work only, same duration
         float w[8] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
+        if (MODE == 20) {   // helper role: per group read 8 tiles from LDS, ~64 VALU instructions, write 8 tiles back
+            float* h = lds + 16384 + ((threadIdx.x - 256) * 4) % 8192;
+            for (int it = 0; it < iters; ++it) {
+                f32x4 tl[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) tl[t] = *(const f32x4*)(h + 1024 * (t & 3));
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tl[t][r] = fmaf(fmaxf(tl[t][r], 0.f), 1.0001f, w[r]);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) *(f32x4*)(h + 1024 * (t & 3) + 4096) = tl[t];
+            }
+            out[blockIdx.x * 512 + threadIdx.x] = w[0];
+            return;
+        }
         for (int it = 0; it < iters * (MODE == 0 ? 6 : 1); ++it) {
 #pragma unroll
             for (int k = 0; k < 32; ++k) w[k & 7] = fmaf(w[k & 7], 1.0001f, 0.5f);
@@ -54,7 +70,7 @@ __global__ __launch_bounds__(512) void rate_kernel(float* out, unsigned long lon
                     for (int t = 0; t < 4; ++t) a4[nx][4 * h + t][r] = q[t];
                 }
         }
-        if (MODE >= 10) {   // K = MODE - 10 independent v_fma_f32 behind every MFMA (no LDS): how many VALU fillers fit a gap?
+        if (MODE >= 10 && MODE < 20) {   // K = MODE - 10 independent v_fma_f32 behind every MFMA (no LDS): how many VALU fillers fit a gap?
             constexpr int K = MODE - 10;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -68,7 +84,7 @@ __global__ __launch_bounds__(512) void rate_kernel(float* out, unsigned long lon
             return;
         }
         if (MODE != 0) __builtin_amdgcn_sched_barrier(0x676);
-        if (MODE == 5 || MODE == 6 || MODE == 7) {   // the same reads, one after every 4th (5: b128) / 2nd (6: b64) / every (7: b32) MFMA, pinned
+        if (MODE == 5 || MODE == 6 || MODE == 7 || MODE == 20) {   // the same reads, one after every 4th (5: b128) / 2nd (6: b64) / every (7: b32) MFMA, pinned
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -76,7 +92,8 @@ __global__ __launch_bounds__(512) void rate_kernel(float* out, unsigned long lon
                     acc[t] = MFMA16(a4[cur][t][r], b[r], acc[t]);
                     const int q = 8 * r + t;   // 0..31
                     const float* base = &lds[((lane & 15) * 140 + 4 * (lane >> 4) + 16 * (it & 31)) & 8191];
-                    if (MODE == 5 && (q & 3) == 3) a4[nx][q >> 2] = *(const f32x4*)(base + 2240 * (q >> 2));
+                    if ((MODE == 5 || MODE == 20) && (q & 3) == 3) a4[nx][q >> 2] = *(const f32x4*)(base + 2240 * (q >> 2));
+                    if (MODE == 20 && (q & 3) == 1) *(f32x4*)&lds[(24576 + lane * 4 + 256 * (q >> 2)) & 32767] = acc[(t + 4) & 7];   // hand over a tile whose last product issued 4 MFMAs ago
                     if (MODE == 6 && (q & 1) == 1) {
                         const float2 v = *(const float2*)(base + 2240 * (q >> 2) + 2 * ((q >> 1) & 1));
                         a4[nx][q >> 2][2 * ((q >> 1) & 1)] = v.x;
@@ -149,6 +166,7 @@ int main() {
         run<8, 7>("8 acc + 32 b32, one per MFMA", blocks, 256);
         run<8, 0>("8 acc, no fillers + a VALU-only wave per SIMD", blocks, 512);
         run<8, 5>("8 acc + 8 b128 spread + a VALU-only wave", blocks, 512);
+        run<8, 20>("MFMA wave: spread b128 reads + 8 tile writes; helper wave: 8 reads, 64 VALU, 8 writes", blocks, 512);
         run<8, 12>("8 acc + 2 v_fma per MFMA", blocks, 256);
         run<8, 14>("8 acc + 4 v_fma per MFMA", blocks, 256);
         run<8, 16>("8 acc + 6 v_fma per MFMA", blocks, 256);
