@@ -29,10 +29,20 @@ def build(force: bool = False, verbose: bool = True) -> str:
     """Compile the HIP C-ABI library for gfx950.  Cross-compiles without a GPU."""
     if not force and not needs_build():
         return OUT
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", f"-I{INCLUDE}", SRC, "-o", OUT]
+    # -fno-slp-vectorize: the SLP pass packs the leftover-unit FMAs into v_pk_fma_f32 and pays two v_mov per pack for it;
+    # -amdgpu-mfma-vgpr-form: MFMA results in VGPRs where the allocation allows, instead of AGPRs read back with v_accvgpr_read.
+    # Together 14 % fewer VALU instructions in the step kernels' chunk loop (every one of them costs MFMA issue slots, DESIGN.md 8),
+    # no spills left in the L = 2 kernels: step kernel -1 %.
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form",
+           "-shared", "-fPIC", f"-I{INCLUDE}", SRC, "-o", OUT]
     if verbose:
         print("[awesome_amd.build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    if subprocess.run(cmd).returncode != 0:
+        # the two code-generation switches are tuning only (and -mllvm options are not a stable interface): build without them
+        plain = [c for c in cmd if c not in ("-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form")]
+        if verbose:
+            print("[awesome_amd.build] retrying without the code-generation switches:", " ".join(plain), flush=True)
+        subprocess.run(plain, check=True)
     return OUT
 
 
