@@ -62,6 +62,9 @@ class InrOptDesc(C.Structure):
 EXPORTS = {
     # name: (restype, argtypes)
     "inrfit_query": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "inrfit_build_info": (C.c_char_p, []),
+    "inrfit_slabs_per_image": (C.c_int, [C.c_int64, C.c_int]),
+    "inrfit_debug_set_slab_base": (C.c_int, [C.c_int]),
     "inrfit_supported": (C.c_int, [C.POINTER(InrModelDesc)]),
     "inrfit_param_count": (C.c_int64, [C.POINTER(InrModelDesc)]),
     "inrfit_opt_state_floats": (C.c_int64, [C.POINTER(InrModelDesc)]),
@@ -146,6 +149,29 @@ def load() -> C.CDLL:
         raise InrfitError(f"libinrfit ABI {ver.value} != expected {INRFIT_ABI_VERSION}")
     _lib = lib
     return lib
+
+
+# Debug switch (tests/test_gpu_determinism.py; env INRFIT_POISON=1): every scratch / output buffer the host side allocates
+# uninitialised is pre-filled with NaN, so a kernel that reads a byte it (or an earlier kernel of the same call) has not
+# written shows up as a NaN result instead of as run-to-run noise.
+POISON = os.environ.get("INRFIT_POISON", "0") == "1"
+
+
+def scratch(*shape, dtype, device):
+    """torch.empty for workspaces and kernel outputs (NaN-filled while POISON is set)."""
+    import torch
+    if POISON and dtype.is_floating_point:
+        return torch.full(shape, float("nan"), dtype=dtype, device=device)
+    return torch.empty(*shape, dtype=dtype, device=device)
+
+
+def scratch_like(t):
+    return scratch(*t.shape, dtype=t.dtype, device=t.device)
+
+
+def build_info() -> str:
+    """Compiler and code-generation flags the loaded libinrfit.so was built with (inrfit_build_info)."""
+    return load().inrfit_build_info().decode()
 
 
 def check(rc: int, what: str) -> None:

@@ -74,6 +74,11 @@ __device__ __forceinline__ void flow_weights_to_lds(const float* __restrict__ sr
 // with w2' = (1 - slope) w2.  The update kernel keeps b2' = b2 + slope <w2, b1>, a' = slope <w2, w1> and w2' in the
 // effective weights, so a unit costs fma + max + fma here, and its derivative is a' + sum_j (w1_j w2'_j) step(pre_j).
 // step(p) = (p > 0) is one multiply by 2^126 with the [0, 1] output clamp (exact for every normal p).
+// The library is built with -ffp-contract=off (arithmetic = what the source says, awesome_amd/build.py): the fused multiply-adds of
+// the unit loops are written out.  v_pk_fma_f32.
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+
 __device__ __forceinline__ f32x2 step01(f32x2 pre) {
     f32x2 r;
     const f32x2 big = f32x2{0x1p126f, 0x1p126f};
@@ -95,19 +100,19 @@ __device__ __forceinline__ void nb_pair_forward(const float* e, int W, const flo
     f32x2 acc[FLOW_PPL], d[FLOW_PPL];
 #pragma unroll
     for (int q = 0; q < FLOW_PPL; ++q) {
-        acc[q] = f32x2{tail[2], tail[3]} * f32x2{u[q], u[q]} + f32x2{tail[0], tail[1]};
+        acc[q] = pk_fma(f32x2{tail[2], tail[3]}, splat2(u[q]), f32x2{tail[0], tail[1]});
         d[q] = f32x2{tail[2], tail[3]};
     }
     auto unit = [&](const f32x4& lo, const f32x4& hi) {   // lo = (w1s, w1t, b1s, b1t), hi = (w2's, w2't, w1s w2's, w1t w2't)
 #pragma unroll
         for (int q = 0; q < FLOW_PPL; ++q) {
-            const f32x2 pre = f32x2{lo[0], lo[1]} * f32x2{u[q], u[q]} + f32x2{lo[2], lo[3]};
+            const f32x2 pre = pk_fma(f32x2{lo[0], lo[1]}, splat2(u[q]), f32x2{lo[2], lo[3]});
             if (DU) {
                 const f32x2 sp = step01(pre);
-                acc[q] += f32x2{hi[0], hi[1]} * (pre * sp);
-                d[q] += f32x2{hi[2], hi[3]} * sp;
+                acc[q] = pk_fma(f32x2{hi[0], hi[1]}, pre * sp, acc[q]);
+                d[q] = pk_fma(f32x2{hi[2], hi[3]}, sp, d[q]);
             } else {
-                acc[q] += f32x2{hi[0], hi[1]} * f32x2{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f)};
+                acc[q] = pk_fma(f32x2{hi[0], hi[1]}, f32x2{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f)}, acc[q]);
             }
         }
     };
@@ -364,9 +369,9 @@ __global__ __launch_bounds__(256) void flow_bwd_units_kernel(const FlowUnitsArgs
             const f32x2 gu2 = f32x2{bc(guc, k), bc(guc, k + 1)};
 #pragma unroll
             for (int r = 0; r < UPL; ++r) {
-                const f32x2 st = step01(f32x2{w1[r], w1[r]} * u2 + f32x2{b1[r], b1[r]});
-                A0[r] += gq2 * st;
-                A1[r] += gu2 * st;
+                const f32x2 st = step01(pk_fma(splat2(w1[r]), u2, splat2(b1[r])));
+                A0[r] = pk_fma(gq2, st, A0[r]);
+                A1[r] = pk_fma(gu2, st, A1[r]);
             }
         }
     }

@@ -77,6 +77,7 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
     const int tx = threadIdx.x, grp = threadIdx.y;
     const int ppb = 4 * blockDim.x;
     __shared__ float red[UPD_GROUPS][UPD_MAX_PARAMS];
+    __shared__ float redl[UPD_GROUPS];     // this step's loss partials (every block sums them: see `frozen` below)
     const int jl = grp * blockDim.x + tx;  // the first ppb threads finish one parameter each
     const int j = blockIdx.x * ppb + jl;
     // The kernel is one dependent chain (slabs -> LDS -> optimizer -> stores) and at one image it is latency, not bandwidth,
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
     float p_old = 0.f, m_old = 0.f, v_old = 0.f, lr_now = 0.f;
     bool bad_before = false;
     if (u.mode == 0 && jl < ppb && j <= u.P) {
-        bad_before = u.status != nullptr && u.status[img] != INR_STATUS_OK;
+        bad_before = hdr[6 + (u.t & 1)] != 0.f;   // written by the PREVIOUS step's launch (double buffer like the lr: no race)
         lr_now = hdr[u.t & 1];
         if (j < u.P) {
             p_old = u.params[(size_t)img * u.P + j];
@@ -110,6 +111,20 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
             for (; w < u.wgs; w += UPD_GROUPS) part += *(const f32x4*)(sl + (size_t)w * u.PS);
         }
         *(f32x4*)&red[grp][4 * tx] = part;
+        if (u.mode == 0 && tx == 0) {   // the loss column (slab entry P), summed in the same order as any parameter column
+            const float* __restrict__ sl = u.slabs + (size_t)img * u.wgs * u.PS + u.P;
+            float lp = 0.f;
+            int w = grp;
+            for (; w + 15 * UPD_GROUPS < u.wgs; w += 16 * UPD_GROUPS) {
+                float q[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) q[k] = sl[(size_t)(w + k * UPD_GROUPS) * u.PS];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lp += q[k];
+            }
+            for (; w < u.wgs; w += UPD_GROUPS) lp += sl[(size_t)w * u.PS];
+            redl[grp] = lp;
+        }
     }
     __syncthreads();
     if (jl >= ppb || j > u.P) return;
@@ -122,12 +137,21 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
         else u.loss_out[img] = gsum;
         return;
     }
+    // A non-finite loss freezes the image: no parameter, optimizer state or schedule changes at this step or any later one of
+    // this call (the reference raises ValueError("Loss is nan or inf!") before the backward pass, path_connected_net.py:232,374;
+    // torch_agent.py:484-487).  Every block derives the decision from the slabs of THIS launch, so which parameters are updated
+    // does not depend on block timing.
+    float loss_now = 0.f;
+#pragma unroll
+    for (int k = 0; k < UPD_GROUPS; ++k) loss_now += redl[k];
+    const bool frozen = bad_before || !isfinite(loss_now);
     if (j == u.P) {
         // loss bookkeeping + ReduceLROnPlateau (torch semantics, mode 'min', relative threshold)
         const float loss = gsum;
         if (u.loss_hist) u.loss_hist[(size_t)img * u.hist_stride + u.hist_idx] = loss;
         float lr = lr_now;
-        if (!isfinite(loss)) {
+        hdr[6 + ((u.t + 1) & 1)] = frozen ? 1.f : 0.f;
+        if (frozen) {
             if (u.status) u.status[img] = INR_STATUS_NONFINITE;
         } else if (u.opt.plateau) {
             float best = hdr[3];
@@ -151,7 +175,7 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
         hdr[5] = loss;
         return;
     }
-    if (bad_before || !isfinite(gsum)) return;
+    if (frozen || !isfinite(gsum)) return;
     if (u.opt.freeze_skips) {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -276,6 +300,7 @@ __global__ __launch_bounds__(256) void opt_init_kernel(float* opt_state, int P, 
         }
         hdr[2] = lr;
         hdr[(step0 + 1) & 1] = lr;
+        hdr[6] = hdr[7] = 0.f;   // "frozen by a non-finite loss" double buffer: a property of one call, like `status`
     }
 }
 
@@ -416,20 +441,17 @@ const KernelEntry* find_entry(const InrModelDesc* m) {
     return nullptr;
 }
 
-int cu_count() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return cus;
-}
+// Workgroups (= gradient slabs) per launch.  The chunk -> workgroup map fixes the order in which the points' gradient
+// contributions are added up, so it must not depend on the box: this is the MI355X's CU count as a CONSTANT, not a device query
+// (a partition with fewer CUs runs the same 256 workgroups in several rounds and gets the same bits).  It does depend on how
+// many images share a launch (256 / n_images workgroups each): image k of a batch and the same image alone agree to rounding,
+// not bit for bit (tests/test_gpu_determinism.py bounds it).
+constexpr int INR_SLAB_BASE = 256;
+int g_slab_base_override = 0;   // inrfit_debug_set_slab_base (tests / measurement only)
 
 int wgs_per_image(long long n_points, int n_images) {
     const long long n_chunks = (n_points + SP - 1) / SP;
-    long long w = cu_count() / (n_images > 0 ? n_images : 1);
+    long long w = (g_slab_base_override > 0 ? g_slab_base_override : INR_SLAB_BASE) / (n_images > 0 ? n_images : 1);
     if (w < 1) w = 1;
     if (w > n_chunks) w = n_chunks;
     return (int)w;
@@ -525,6 +547,24 @@ int inrfit_query(int* abi_version, int* max_hidden, int* lds_bytes) {
     if (max_hidden) *max_hidden = 130;
     if (lds_bytes) *lds_bytes = Cfg<130, 2>::LDS_BYTES;
     return INR_OK;
+}
+
+#ifndef INRFIT_BUILD_FLAGS
+#define INRFIT_BUILD_FLAGS "unknown (not built by awesome_amd/build.py)"
+#endif
+const char* inrfit_build_info(void) {
+    return "libinrfit abi " "1" "; gfx950; slab_base 256; " __VERSION__ "; flags: " INRFIT_BUILD_FLAGS;
+}
+
+int inrfit_debug_set_slab_base(int slab_base) {
+    if (slab_base < 0 || slab_base > 4096) return INR_EINVAL;
+    g_slab_base_override = slab_base;
+    return INR_OK;
+}
+
+int inrfit_slabs_per_image(int64_t n_points, int n_images) {
+    if (n_points <= 0 || n_images <= 0) return INR_EINVAL;
+    return wgs_per_image(n_points, n_images);
 }
 
 int inrfit_supported(const InrModelDesc* model) { return find_entry(model) ? 1 : 0; }

@@ -172,7 +172,7 @@ __device__ __forceinline__ void rnvp_nets(const float* rec, int HID, const float
         for (int q = 0; q < Q; ++q) {
             f32x2 pre = f32x2{v[2 * NIN], v[2 * NIN + 1]};
 #pragma unroll
-            for (int mm = 0; mm < NIN; ++mm) pre += f32x2{v[2 * mm], v[2 * mm + 1]} * f32x2{zin[q][mm], zin[q][mm]};
+            for (int mm = 0; mm < NIN; ++mm) pre = pk_fma(f32x2{v[2 * mm], v[2 * mm + 1]}, splat2(zin[q][mm]), pre);
             if (DU) {
                 const f32x2 st = step01(pre);
                 const f32x2 h = pre * st;
@@ -182,14 +182,14 @@ __device__ __forceinline__ void rnvp_nets(const float* rec, int HID, const float
 #pragma unroll
                 for (int k = 0; k < NOUT; ++k) {
                     const f32x2 w2 = f32x2{v[2 * (NIN + 1 + k)], v[2 * (NIN + 1 + k) + 1]};
-                    o[q][k] += w2 * h;
+                    o[q][k] = pk_fma(w2, h, o[q][k]);
 #pragma unroll
-                    for (int mm = 0; mm < NIN; ++mm) J[q][k][mm] += w2 * t[mm];
+                    for (int mm = 0; mm < NIN; ++mm) J[q][k][mm] = pk_fma(w2, t[mm], J[q][k][mm]);
                 }
             } else {
                 const f32x2 h = f32x2{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f)};
 #pragma unroll
-                for (int k = 0; k < NOUT; ++k) o[q][k] += f32x2{v[2 * (NIN + 1 + k)], v[2 * (NIN + 1 + k) + 1]} * h;
+                for (int k = 0; k < NOUT; ++k) o[q][k] = pk_fma(f32x2{v[2 * (NIN + 1 + k)], v[2 * (NIN + 1 + k) + 1]}, h, o[q][k]);
             }
         }
     }
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void rnvp_bwd_points_kernel(const RnvpBwdArgs 
                         }
 #pragma unroll
                     for (int mm = 0; mm < C - 1; ++mm)
-                        if (mm < x.nin) gin[mm] += dos[k] * J[q][k][mm][0] + dot[k] * J[q][k][mm][1];
+                        if (mm < x.nin) gin[mm] = fmaf(dos[k], J[q][k][mm][0], fmaf(dot[k], J[q][k][mm][1], gin[mm]));
                 }
             }
 #pragma unroll
@@ -616,13 +616,13 @@ __device__ __forceinline__ void rnvp_units_body(const RnvpUnitsArgs& a, const Fl
                 for (int q = 0; q < PPL; ++q) {
                     f32x2 pre = f32x2{v[2 * NIN], v[2 * NIN + 1]};
 #pragma unroll
-                    for (int mm = 0; mm < NIN; ++mm) pre += f32x2{v[2 * mm], v[2 * mm + 1]} * f32x2{zin[q][mm], zin[q][mm]};
+                    for (int mm = 0; mm < NIN; ++mm) pre = pk_fma(f32x2{v[2 * mm], v[2 * mm + 1]}, splat2(zin[q][mm]), pre);
                     const f32x2 st = step01(pre);
 #pragma unroll
                     for (int k = 0; k < NOUT; ++k) {
-                        S0[u][k] += dd[q][k] * st;
+                        S0[u][k] = pk_fma(dd[q][k], st, S0[u][k]);
 #pragma unroll
-                        for (int mm = 0; mm < NIN; ++mm) S1[u][k][mm] += dz[q][k][mm] * st;
+                        for (int mm = 0; mm < NIN; ++mm) S1[u][k][mm] = pk_fma(dz[q][k][mm], st, S1[u][k][mm]);
                     }
                 }
             }

@@ -73,6 +73,53 @@ def disc_unaries(h: int, w: int, cy: float, cx: float, r: float) -> torch.Tensor
     return torch.from_numpy(1.0 - disc.astype(np.float32))
 
 
+from .prior_dataset import PriorDataset, prior  # noqa: E402
+
+
+class SyntheticPriorDataset(PriorDataset):
+    """The synthetic inputs in the item format of the reference's prior datasets (AwesomeDataset.__getitem__,
+    awesome/dataset/awesome_dataset.py:291-294, wrapped by `@prior()`):
+
+        ((index, prior_state), ((image, features, xy_clean), target))
+
+    `image` (1, S, S) holds segmentation LOGITS whose sigmoid, inverted, is the unaries of the synthetic item (so
+    WrapperModule(ForwardModule(), prior, use_segmentation_output_inversion=...) reproduces them like a trained backbone would);
+    `features` is an empty placeholder, `xy_clean` the (2, S, S) linspace grid of Transformator.get_positional_matrices, `target`
+    (1, S, S) the clean mask in the unaries' convention (object = 0, background = 1: what the inverted segmentation output is
+    trained against).  `kind`: 'blob' | 'noisy_blob' | 'disc' (see SyntheticUnariesDataset)."""
+
+    returns_index = False
+    training_batch_size = 1
+
+    def __init__(self, n_images: int = 1, size: int = 256, kind: str = "blob", seed0: int = 0, prior_model_type=None,
+                 prior_model_args=None, **kwargs):
+        super().__init__(prior_model_type=prior_model_type, prior_model_args=prior_model_args)
+        self._inner = SyntheticUnariesDataset(n_images=n_images, size=size, kind=kind, seed0=seed0)
+        self.size = int(size)
+        xs = torch.linspace(0, 1, self.size)
+        self._xy = torch.stack([xs[None, :].expand(self.size, self.size), xs[:, None].expand(self.size, self.size)], 0).contiguous()
+
+    def __len__(self) -> int:
+        return len(self._inner)
+
+    def unaries(self, i: int) -> torch.Tensor:
+        return self._inner.unaries(i)
+
+    def ground_truth(self, i: int) -> torch.Tensor:
+        return self._inner.ground_truth(i)
+
+    def ground_truth_batch(self, indices) -> torch.Tensor:
+        return self._inner.ground_truth_batch(indices)
+
+    @prior()
+    def __getitem__(self, i: int):
+        un = self._inner.unaries(int(i)).clamp(1e-6, 1 - 1e-6)
+        fg_prob = 1.0 - un                                   # probability of "object" = what sigmoid(seg logits) is
+        image = torch.log(fg_prob / (1.0 - fg_prob))[None]   # logits; sigmoid(image) = fg_prob
+        target = (self._inner.ground_truth(int(i)) > 0.5).float()[None]
+        return (image, torch.zeros(1, 1, 1), self._xy), target
+
+
 class SyntheticUnariesDataset:
     """Minimal stand-in for the reference's prior datasets on the hot path: item i is `(grid_desc, unaries_i)` where
     unaries follow the reference convention (fg = 0).  `kind`: 'disc' (C1), 'blob' (C2/C3, seed = index + seed0) or

@@ -18,6 +18,16 @@ from . import icnn as K
 from .measures import criterion_to_desc
 
 
+class NonFiniteLossError(ValueError):
+    """A fit hit a NaN/Inf loss.  The reference raises ValueError("Loss is nan or inf!") out of the per-image loop
+    (awesome/model/path_connected_net.py:232,374); `.images` lists the positions in the batch, `.report` is the FitReport with
+    the other images' results (the bad images keep the parameters they had before the bad step)."""
+
+    def __init__(self, images, report):
+        super().__init__(f"Loss is nan or inf! (images {list(images)} of the batch)")
+        self.images, self.report = list(images), report
+
+
 @dataclass
 class FitReport:
     params: torch.Tensor              # [n_images, P] fitted flat parameters (device)
@@ -33,7 +43,7 @@ class BatchedPriorFitter:
     def __init__(self, model_factory: Callable[[], torch.nn.Module], num_epochs: int = 2000, lr: float = 1e-3,
                  optimizer: str = "adamax", weight_decay: float = 0.0, criterion=None, plateau: Optional[dict] = None,
                  proper_prior_fit_threshold: float = 0.5, proper_prior_fit_retrys: int = 1, reuse_state: bool = False,
-                 reuse_state_epochs: int = 200, betas=(0.9, 0.999), eps: float = 1e-8):
+                 reuse_state_epochs: int = 200, betas=(0.9, 0.999), eps: float = 1e-8, on_nonfinite: str = "raise"):
         """Defaults follow _prior_based_pretrain's kwargs (path_connected_net.py:756-790): Adamax lr 1e-3,
         ReduceLROnPlateau(patience=200, factor=0.5), UnariesWeightedLoss(SE('mean')), threshold 0.5, 1 retry."""
         self.model_factory = model_factory
@@ -42,6 +52,9 @@ class BatchedPriorFitter:
         self.threshold, self.retrys = proper_prior_fit_threshold, proper_prior_fit_retrys
         self.reuse_state, self.reuse_state_epochs = reuse_state, reuse_state_epochs
         self.betas, self.eps = betas, eps
+        if on_nonfinite not in ("raise", "report"):
+            raise ValueError("on_nonfinite must be 'raise' (the reference's behaviour) or 'report' (status only)")
+        self.on_nonfinite = on_nonfinite
         if criterion is None:
             self.loss_kind, self.weight_mode, self.ratio = "se", "none", 1.0
         else:
@@ -93,7 +106,11 @@ class BatchedPriorFitter:
                 for i in failed:
                     retries[i] += 1
             todo, ep = (failed if attempt < self.retrys else []), self.num_epochs
-        return FitReport(params, iou, final_loss, retries, skipped, status, logits)
+        report = FitReport(params, iou, final_loss, retries, skipped, status, logits)
+        bad = torch.nonzero(status != 0).reshape(-1).cpu().tolist()
+        if bad and self.on_nonfinite == "raise":
+            raise NonFiniteLossError(bad, report)
+        return report
 
     # -- sequences with warm start: frames in order inside a sequence, sequences batched ----------------------------
     def fit_sequences(self, grid: K.Grid, unaries: torch.Tensor, seq_ids: Sequence[int]) -> FitReport:

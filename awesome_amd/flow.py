@@ -97,14 +97,14 @@ def _ws(ispec: Optional[K.IcnnSpec], fspec: FlowSpec, grid: K.Grid, n_images: in
     nbytes = L.load().inrfit_cdn_workspace_bytes(C.byref(md) if md is not None else None, C.byref(fd), C.byref(gd), n_images)
     if nbytes < 0:
         L.check(int(nbytes), "inrfit_cdn_workspace_bytes")
-    return torch.empty(int(nbytes) // 4 + 1, dtype=torch.float32, device=grid.device)
+    return L.scratch(int(nbytes) // 4 + 1, dtype=torch.float32, device=grid.device)
 
 
 def flow_forward(fspec: FlowSpec, flow_params: Tensor, grid: K.Grid) -> Tensor:
     """flow_params [n_images, FP] -> deformed coordinates [n_images, 2, N]."""
     fp = K._check_dev(flow_params, "flow_params")
     n = fp.shape[0]
-    out = torch.empty(n, 2, grid.n_points, dtype=torch.float32, device=fp.device)
+    out = L.scratch(n, 2, grid.n_points, dtype=torch.float32, device=fp.device)
     ws = _ws(None, fspec, grid, n)
     fd, gd = fspec.desc(), grid.desc()
     rc = L.load().inrfit_flow_forward(C.byref(fd), fp.data_ptr(), C.byref(gd), n, out.data_ptr(), ws.data_ptr(), ws.numel() * 4,
@@ -116,7 +116,7 @@ def flow_forward(fspec: FlowSpec, flow_params: Tensor, grid: K.Grid) -> Tensor:
 def cdn_forward(ispec: K.IcnnSpec, fspec: FlowSpec, icnn_params: Tensor, flow_params: Tensor, grid: K.Grid) -> Tensor:
     ip, fp = K._check_dev(icnn_params, "icnn_params"), K._check_dev(flow_params, "flow_params")
     n = ip.shape[0]
-    logits = torch.empty(n, grid.n_points, dtype=torch.float32, device=ip.device)
+    logits = L.scratch(n, grid.n_points, dtype=torch.float32, device=ip.device)
     ws = _ws(ispec, fspec, grid, n)
     md, fd, gd = ispec.desc(), fspec.desc(), grid.desc()
     rc = L.load().inrfit_cdn_forward(C.byref(md), C.byref(fd), ip.data_ptr(), fp.data_ptr(), C.byref(gd), n, logits.data_ptr(),
@@ -130,8 +130,8 @@ def cdn_loss_grad(ispec: K.IcnnSpec, fspec: FlowSpec, icnn_params: Tensor, flow_
     ip, fp = K._check_dev(icnn_params, "icnn_params"), K._check_dev(flow_params, "flow_params")
     n = ip.shape[0]
     targets = K._check_dev(targets, "targets").reshape(n, -1)
-    lo = torch.empty(n, dtype=torch.float32, device=ip.device)
-    gi, gf = torch.empty_like(ip), torch.empty_like(fp)
+    lo = L.scratch(n, dtype=torch.float32, device=ip.device)
+    gi, gf = L.scratch_like(ip), L.scratch_like(fp)
     ws = _ws(ispec, fspec, grid, n)
     md, fd, gd, ld = ispec.desc(), fspec.desc(), grid.desc(), K._loss_desc(loss, weight_mode, ratio, 0.0, 0.0)
     rc = L.load().inrfit_cdn_loss_grad(C.byref(md), C.byref(fd), ip.data_ptr(), fp.data_ptr(), C.byref(gd), targets.data_ptr(),
@@ -165,8 +165,8 @@ def cdn_fit(ispec: K.IcnnSpec, fspec: FlowSpec, icnn_params: Tensor, flow_params
         icnn_opt_state = K.new_opt_state(ispec, n, dev)
     if flow_opt_state is None:
         flow_opt_state = torch.zeros(n, 2 * fspec.n_params, dtype=torch.float32, device=dev)
-    hist = torch.empty(n, max(steps, 1), dtype=torch.float32, device=dev) if record_loss else None
-    logits = torch.empty(n, grid.n_points, dtype=torch.float32, device=dev) if want_logits else None
+    hist = L.scratch(n, max(steps, 1), dtype=torch.float32, device=dev) if record_loss else None
+    logits = L.scratch(n, grid.n_points, dtype=torch.float32, device=dev) if want_logits else None
     status = torch.zeros(n, dtype=torch.int32, device=dev)
     pl = plateau or {}
     od = L.InrOptDesc(L.INR_OPT_ADAM, float(lr), float(betas[0]), float(betas[1]), float(eps), 0.0, 1, int(plateau is not None),

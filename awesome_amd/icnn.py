@@ -181,7 +181,7 @@ def _workspace(spec: IcnnSpec, grid: Grid, n_images: int) -> Tensor:
     nbytes = L.load().inrfit_workspace_bytes(C.byref(md), C.byref(gd), n_images)
     if nbytes < 0:
         L.check(int(nbytes), "inrfit_workspace_bytes")
-    return torch.empty(int(nbytes) // 4 + 1, dtype=torch.float32, device=grid.device)
+    return L.scratch(int(nbytes) // 4 + 1, dtype=torch.float32, device=grid.device)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -195,7 +195,7 @@ def forward(spec: IcnnSpec, params: Tensor, grid: Grid) -> Tensor:
         params = params[None]
     n_images = params.shape[0]
     assert params.shape[1] == spec.n_params, (params.shape, spec.n_params)
-    logits = torch.empty(n_images, grid.n_points, dtype=torch.float32, device=params.device)
+    logits = L.scratch(n_images, grid.n_points, dtype=torch.float32, device=params.device)
     md, gd = spec.desc(), grid.desc()
     ws = _workspace(spec, grid, n_images)
     rc = L.load().inrfit_forward(C.byref(md), params.data_ptr(), C.byref(gd), n_images, logits.data_ptr(), ws.data_ptr(),
@@ -220,8 +220,8 @@ def loss_grad(spec: IcnnSpec, params: Tensor, grid: Grid, targets: Tensor, loss:
     targets = targets.reshape(n_images, -1)
     assert targets.shape[1] == grid.n_points
     ws = _workspace(spec, grid, n_images)
-    loss_out = torch.empty(n_images, dtype=torch.float32, device=params.device)
-    grads = torch.empty_like(params)
+    loss_out = L.scratch(n_images, dtype=torch.float32, device=params.device)
+    grads = L.scratch_like(params)
     md, gd, ld = spec.desc(), grid.desc(), _loss_desc(loss, weight_mode, ratio, c_fg, c_bg)
     rc = L.load().inrfit_loss_grad(C.byref(md), params.data_ptr(), C.byref(gd), targets.data_ptr(), C.byref(ld), n_images,
                                    loss_out.data_ptr(), grads.data_ptr(), ws.data_ptr(), ws.numel() * 4,
@@ -242,8 +242,8 @@ def backward(spec: IcnnSpec, params: Tensor, grid: Grid, dlogits: Tensor, want_d
     dlogits = dlogits.reshape(n_images, -1)
     assert dlogits.shape[1] == grid.n_points
     ws = _workspace(spec, grid, n_images)
-    grads = torch.empty_like(params)
-    dco = torch.empty(n_images, spec.in_features, grid.n_points, dtype=torch.float32, device=params.device) if want_dcoords else None
+    grads = L.scratch_like(params)
+    dco = L.scratch(n_images, spec.in_features, grid.n_points, dtype=torch.float32, device=params.device) if want_dcoords else None
     md, gd = spec.desc(), grid.desc()
     rc = L.load().inrfit_backward(C.byref(md), params.data_ptr(), C.byref(gd), dlogits.data_ptr(), n_images,
                                   grads.data_ptr(), dco.data_ptr() if dco is not None else None, ws.data_ptr(),
@@ -270,7 +270,7 @@ def step_only(spec: IcnnSpec, params: Tensor, grid: Grid, targets: Tensor, iters
 def mfma_stream_tflops(device, workgroups: int = 256, iters: int = 12000) -> float:
     """Measurement hook: TFLOP/s of a launch that issues nothing but independent fp32 16x16x4 MFMAs on `workgroups` x 4 waves -
     what the matrix pipes sustain at the clock the chip holds under that load (the practical ceiling under the nominal peak)."""
-    scratch = torch.empty(workgroups * 256, dtype=torch.float32, device=device)
+    scratch = L.scratch(workgroups * 256, dtype=torch.float32, device=device)
     flop = C.c_double(0.0)
     lib = L.load()
     sp = _stream_ptr(torch.device(device))
@@ -314,8 +314,8 @@ def fit(spec: IcnnSpec, params: Tensor, grid: Grid, targets: Tensor, steps: int,
     if opt_state is None:
         opt_state = new_opt_state(spec, n_images, dev)
     ws = _workspace(spec, grid, n_images)
-    hist = torch.empty(n_images, max(steps, 1), dtype=torch.float32, device=dev) if record_loss else None
-    logits = torch.empty(n_images, grid.n_points, dtype=torch.float32, device=dev) if want_logits else None
+    hist = L.scratch(n_images, max(steps, 1), dtype=torch.float32, device=dev) if record_loss else None
+    logits = L.scratch(n_images, grid.n_points, dtype=torch.float32, device=dev) if want_logits else None
     status = torch.zeros(n_images, dtype=torch.int32, device=dev)
     pl = plateau or {}
     od = L.InrOptDesc(L.OPT_KINDS[optimizer], float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
@@ -339,7 +339,7 @@ def miou(out: Tensor, tgt: Tensor, thr_out: float = 0.5, thr_tgt: float = 0.5, i
     n_images = out.shape[0] if out.dim() > 1 else 1
     out = out.reshape(n_images, -1)
     tgt = tgt.reshape(n_images, -1)
-    res = torch.empty(n_images, dtype=torch.float32, device=out.device)
+    res = L.scratch(n_images, dtype=torch.float32, device=out.device)
     rc = L.load().inrfit_miou(out.data_ptr(), tgt.data_ptr(), n_images, out.shape[1], float(thr_out), float(thr_tgt),
                               int(bool(invert)), res.data_ptr(), _stream_ptr(out.device))
     L.check(rc, "inrfit_miou")

@@ -138,7 +138,7 @@ def _ws(ispec: Optional[K.IcnnSpec], rspec: RnvpSpec, grid: K.Grid, n_images: in
     nbytes = L.load().inrfit_pcn_workspace_bytes(C.byref(md) if md is not None else None, C.byref(rd), C.byref(gd), n_images)
     if nbytes < 0:
         L.check(int(nbytes), "inrfit_pcn_workspace_bytes")
-    return torch.empty(int(nbytes) // 4 + 1, dtype=torch.float32, device=grid.device)
+    return L.scratch(int(nbytes) // 4 + 1, dtype=torch.float32, device=grid.device)
 
 
 def actnorm_init(rspec: RnvpSpec, flow_params: Tensor, grid: K.Grid) -> Tensor:
@@ -157,7 +157,7 @@ def rnvp_forward(rspec: RnvpSpec, flow_params: Tensor, grid: K.Grid) -> Tensor:
     """flow_params [n_images, RP] -> deformed coordinates [n_images, C, N]."""
     fp = K._check_dev(flow_params, "flow_params")
     n = fp.shape[0]
-    out = torch.empty(n, rspec.channels, grid.n_points, dtype=torch.float32, device=fp.device)
+    out = L.scratch(n, rspec.channels, grid.n_points, dtype=torch.float32, device=fp.device)
     ws = _ws(None, rspec, grid, n)
     rd, gd = rspec.desc(), grid.desc()
     rc = L.load().inrfit_rnvp_forward(C.byref(rd), fp.data_ptr(), C.byref(gd), n, out.data_ptr(), ws.data_ptr(), ws.numel() * 4,
@@ -173,7 +173,7 @@ def rnvp_inverse(rspec: RnvpSpec, flow_params: Tensor, coords: Tensor) -> Tensor
     n = fp.shape[0]
     stride = 0 if coords.dim() == 2 else coords.shape[1] * coords.shape[2]
     N = coords.shape[-1]
-    out = torch.empty(n, rspec.channels, N, dtype=torch.float32, device=fp.device)
+    out = L.scratch(n, rspec.channels, N, dtype=torch.float32, device=fp.device)
     ws = _ws(None, rspec, K.Grid.explicit(coords), n)
     rd = rspec.desc()
     rc = L.load().inrfit_rnvp_inverse(C.byref(rd), fp.data_ptr(), coords.data_ptr(), stride, N, n, out.data_ptr(), ws.data_ptr(),
@@ -191,7 +191,7 @@ def fit_identity(rspec: RnvpSpec, flow_params: Tensor, grid: K.Grid, steps: int 
     n, dev = fp.shape[0], fp.device
     if flow_opt_state is None:
         flow_opt_state = torch.zeros(n, 2 * rspec.n_params, dtype=torch.float32, device=dev)
-    hist = torch.empty(n, max(steps, 1), dtype=torch.float32, device=dev)
+    hist = L.scratch(n, max(steps, 1), dtype=torch.float32, device=dev)
     od = L.InrOptDesc(L.OPT_KINDS[optimizer], float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), 0, 0,
                       0, 0.0, 0.0, 0.0, 0.0)
     ws = _ws(None, rspec, grid, n)
@@ -206,7 +206,7 @@ def fit_identity(rspec: RnvpSpec, flow_params: Tensor, grid: K.Grid, steps: int 
 def pcn_forward(ispec: K.IcnnSpec, rspec: RnvpSpec, icnn_params: Tensor, flow_params: Tensor, grid: K.Grid) -> Tensor:
     ip, fp = K._check_dev(icnn_params, "icnn_params"), K._check_dev(flow_params, "flow_params")
     n = ip.shape[0]
-    logits = torch.empty(n, grid.n_points, dtype=torch.float32, device=ip.device)
+    logits = L.scratch(n, grid.n_points, dtype=torch.float32, device=ip.device)
     ws = _ws(ispec, rspec, grid, n)
     md, rd, gd = ispec.desc(), rspec.desc(), grid.desc()
     rc = L.load().inrfit_pcn_forward(C.byref(md), C.byref(rd), ip.data_ptr(), fp.data_ptr(), C.byref(gd), n, logits.data_ptr(),
@@ -220,8 +220,8 @@ def pcn_loss_grad(ispec: K.IcnnSpec, rspec: RnvpSpec, icnn_params: Tensor, flow_
     ip, fp = K._check_dev(icnn_params, "icnn_params"), K._check_dev(flow_params, "flow_params")
     n = ip.shape[0]
     targets = K._check_dev(targets, "targets").reshape(n, -1)
-    lo = torch.empty(n, dtype=torch.float32, device=ip.device)
-    gi, gf = torch.empty_like(ip), torch.empty_like(fp)
+    lo = L.scratch(n, dtype=torch.float32, device=ip.device)
+    gi, gf = L.scratch_like(ip), L.scratch_like(fp)
     ws = _ws(ispec, rspec, grid, n)
     md, rd, gd, ld = ispec.desc(), rspec.desc(), grid.desc(), K._loss_desc(loss, weight_mode, ratio, 0.0, 0.0)
     rc = L.load().inrfit_pcn_loss_grad(C.byref(md), C.byref(rd), ip.data_ptr(), fp.data_ptr(), C.byref(gd), targets.data_ptr(),
@@ -256,8 +256,8 @@ def pcn_fit(ispec: K.IcnnSpec, rspec: RnvpSpec, icnn_params: Tensor, flow_params
         icnn_opt_state = K.new_opt_state(ispec, n, dev)
     if flow_opt_state is None:
         flow_opt_state = torch.zeros(n, 2 * rspec.n_params, dtype=torch.float32, device=dev)
-    hist = torch.empty(n, max(steps, 1), dtype=torch.float32, device=dev) if record_loss else None
-    logits = torch.empty(n, grid.n_points, dtype=torch.float32, device=dev) if want_logits else None
+    hist = L.scratch(n, max(steps, 1), dtype=torch.float32, device=dev) if record_loss else None
+    logits = L.scratch(n, grid.n_points, dtype=torch.float32, device=dev) if want_logits else None
     status = torch.zeros(n, dtype=torch.int32, device=dev)
     pl = plateau or {}
     od = L.InrOptDesc(L.OPT_KINDS[optimizer], float(lr), float(betas[0]), float(betas[1]), float(eps), 0.0, 1,

@@ -1,0 +1,1 @@
+from .prior_cache import PriorCache  # noqa: F401

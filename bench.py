@@ -8,7 +8,10 @@ One "step" = one complete cold fit of the workload on every GPU:
 Workload per GPU: BASELINE configs[1] - a single image (`--images-per-gpu 1`, the default).  Every rank fits its own
 images (no data-path collective; "weak" scaling), RCCL is used for the barrier / max-time reduction only.
 
-    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched through torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
+N > 1: one process per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment: how the driver starts it) this
+process is one rank; started plainly with --gpus N > 1 it launches `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+as a child BEFORE touching the GPU, relays rank 0's JSON line and exits with the child's code.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (icnn_step_kernel): algorithmic FLOPs per launch
 (105,312 flop/point/step x 65,536 points x images) / its average launch duration measured live with events on the launch
@@ -47,8 +50,31 @@ def parse_args():
     return ap.parse_args()
 
 
+def launch_ranks(args):
+    """`--gpus N` (N > 1) without a torch.distributed environment: start the N ranks as a child process group.  This parent never
+    imports torch or touches the GPU (a process that has initialised the GPU must not exec or fork workers), it only relays the
+    child's output and exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout.splitlines():
+        if line.startswith("{"):
+            print(line, flush=True)
+        elif line.strip():
+            print(line, file=sys.stderr, flush=True)
+    return proc.returncode
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -56,30 +82,103 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # BENCH_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices and the
     # collectives run on CPU tensors); the real multi-GPU run uses "nccl" (= RCCL over xGMI on ROCm), one rank per GPU.
+    # BENCH_REHEARSAL=1 (needs BENCH_BACKEND=gloo; tests/test_parallel_gloo.py): no GPU at all - the fit is replaced by a labelled
+    # stand-in so that the launcher, the rendezvous and every collective of this file run on a CPU-only box.  Its line says
+    # "rehearsal": true and carries no value: it is a plumbing check, never a measurement.
     backend = os.environ.get("BENCH_BACKEND", "nccl")
+    rehearsal = os.environ.get("BENCH_REHEARSAL", "0") == "1"
+    if rehearsal and backend != "gloo":
+        raise SystemExit("[bench] BENCH_REHEARSAL=1 needs BENCH_BACKEND=gloo")
+    if args.gpus != world:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}: start it as "
+                         f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...` "
+                         f"(or plainly, `python bench.py --gpus {args.gpus}`, which does that itself)")
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (the product has no CPU path)")
-    if backend != "nccl":
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    cdev = dev if backend == "nccl" else torch.device("cpu")   # where the (tiny) collective payloads live
+    if rehearsal:
+        dev = cdev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (the product has no CPU path)")
+        if backend != "nccl":
+            local_rank = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        cdev = dev if backend == "nccl" else torch.device("cpu")   # where the (tiny) collective payloads live
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
+    def barrier():
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+
+    def max_over_ranks(x: float) -> float:
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(n: int) -> int:
+        if world == 1:
+            return n
+        t = torch.tensor([n], dtype=torch.int64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t.item())
+
+    def gather_cat(v):
+        """the only data collective: a few bytes of per-image metrics"""
+        if world == 1:
+            return v
+        vc = v.to(cdev)
+        parts = [torch.zeros_like(vc) for _ in range(world)]
+        dist.all_gather(parts, vc)
+        return torch.cat(parts)
+
+    S, E, B = args.size, args.epochs, args.images_per_gpu
+    N = S * S
+    # image i of rank r is blob seed r*B + i; initial weights: the reference's seeded default init
+    seeds = [rank * B + i for i in range(B)]
+
+    if rehearsal:
+        import types
+
+        def one_fit():
+            time.sleep(0.01)
+            return types.SimpleNamespace(status=torch.zeros(B, dtype=torch.int32), iou=torch.tensor([float(sd) for sd in seeds]))
+
+        for _ in range(args.warmup):
+            one_fit()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = one_fit()
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        iou_all = gather_cat(res.iou)
+        bad = sum_over_ranks(int((res.status != 0).sum()))
+        if rank == 0:
+            print(json.dumps({"metric": "REHEARSAL of the rank launcher and collectives (no fit ran)", "value": None, "unit": "fits/s",
+                              "rehearsal": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(elapsed / args.steps * 1e3, 3), "gathered_image_seeds": iou_all.tolist(),
+                              "nonfinite_fits": bad, "backend": backend}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     import awesome_amd as A
     from awesome_amd.dataset import convex_blob_unaries
     from awesome_amd.model import ConvexNextNet
 
-    S, E, B = args.size, args.epochs, args.images_per_gpu
-    N = S * S
     spec = A.IcnnSpec(130, 2, 1)
-    # image i of rank r is blob seed r*B + i; initial weights: the reference's seeded default init
-    seeds = [rank * B + i for i in range(B)]
     unaries = torch.stack([convex_blob_unaries(S, s).reshape(-1) for s in seeds]).to(dev)
     init = []
     for s in seeds:
@@ -93,12 +192,6 @@ def main():
         return A.fit(spec, params, grid, unaries, E, lr=2e-3, loss="se", optimizer="adam", clamp=True, record_loss=False,
                      want_logits=True)
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
     res = None
     for _ in range(args.warmup):
         res = one_fit()
@@ -107,23 +200,13 @@ def main():
     for _ in range(args.steps):
         res = one_fit()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
 
     # quality of the last fit: fg-mIoU of the thresholded prior vs the unaries (the reference's IoU gate metric)
     prob = torch.sigmoid(res.logits)
     iou = A.miou((prob > 0.5).float(), (unaries > 0.5).float(), invert=True)
-    status_bad = int((res.status != 0).sum().item())
-    if world > 1:
-        iou_c = iou.to(cdev)
-        gathered = [torch.zeros_like(iou_c) for _ in range(world)]
-        dist.all_gather(gathered, iou_c)   # the only data collective: a few bytes of metrics
-        iou_all = torch.cat(gathered)
-    else:
-        iou_all = iou
+    status_bad = sum_over_ranks(int((res.status != 0).sum().item()))
+    iou_all = gather_cat(iou)
     miou = float(iou_all.mean().item())
 
     # ---- roofline of the dominant kernel: average launch duration by HIP events on the launch stream ------------------------
@@ -184,13 +267,11 @@ def main():
         tres = A.fit(spec, tinit.clone(), grid, tun, E, lr=2e-3, loss="se", optimizer="adam", clamp=True, record_loss=False,
                      want_logits=True)
         barrier()
-        tdt = time.perf_counter() - t1
-        if world > 1:
-            tt = torch.tensor([tdt], dtype=torch.float64, device=cdev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            tdt = float(tt.item())
+        tdt = max_over_ranks(time.perf_counter() - t1)
         tiou = A.miou((torch.sigmoid(tres.logits) > 0.5).float(), (tun > 0.5).float(), invert=True)
         thr = {"images_per_gpu": TB, "fits_per_s": round(TB * world / tdt, 4), "seconds": round(tdt, 3),
+               "roofline_frac_wall_clock": round(STEP_FLOP_PER_POINT * N * TB * E / tdt / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
+               "nonfinite_fits": int((tres.status != 0).sum().item()), "min_iou_vs_unaries": round(float(tiou.min()), 5),
                "us_per_optimizer_step_per_image": round(tdt / E / TB * 1e6, 2), "miou_vs_unaries": round(float(tiou.mean()), 5),
                "note": "one complete E-step fit of the batch; all images step together (BASELINE configs[2] per-GPU share)"}
 
@@ -205,6 +286,16 @@ def main():
         reference_parity = {"reference_miou": round(float(z["final_miou"]), 5),
                             "miou_abs_diff_vs_reference": round(abs(float(iou[0]) - float(z["final_miou"])), 6),
                             "mask_pixels_differing_from_reference": int((mask0 != z["final_mask"].astype(bool)).sum())}
+    # What the result depends on besides the inputs (the driver's fit differed from every builder-side one): the
+    # build (compiler, code-generation flags; -ffp-contract=off pins the arithmetic to the source) and the number of gradient
+    # slabs per image (a constant of the library, not the box's CU count).  `fit_checksum`: first 64 bits of the SHA-256 of rank
+    # 0's final parameters of the LAST timed fit - every fit of a run, and every run of one build, prints the same value.
+    import hashlib
+    lib = A._lib.load()
+    determinism = {"fit_checksum": hashlib.sha256(res.params.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16],
+                   "slabs_per_image": int(lib.inrfit_slabs_per_image(N, B)),
+                   "cu_count": int(torch.cuda.get_device_properties(dev).multi_processor_count),
+                   "build": A._lib.build_info()}
     out = None
     if rank == 0:
         fits = args.steps * B * world
@@ -216,7 +307,7 @@ def main():
             "config": {"workload": f"{B} x {S}x{S} synthetic convex blob per GPU, ConvexNextNet(h=130,L=1), "
                                    f"SE(sigmoid) mean, Adam lr 2e-3, clamp, E={E} full-batch steps (BASELINE configs[1])",
                        "images_per_gpu": B, "grid": f"{S}x{S}", "epochs_per_fit": E, "parallelism": f"dp{world} (independent fits)"},
-            "miou_vs_unaries": round(miou, 5), "nonfinite_fits": status_bad, **reference_parity,
+            "miou_vs_unaries": round(miou, 5), "nonfinite_fits": status_bad, **reference_parity, **determinism,
             "us_per_optimizer_step": round(elapsed / args.steps / E * 1e6, 2),
             "roofline": roofline,
         }

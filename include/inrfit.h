@@ -106,13 +106,25 @@ typedef struct InrOptDesc {
 /* Per-image optimizer state, `opt_state` = n_images * inrfit_opt_state_floats(model) floats:
  *   exp_avg [P] | exp_avg_sq or exp_inf [P] | header [INR_OPT_HEADER_FLOATS]
  * header: [0],[1] lr of odd/even steps (double buffer, internal), [2] current lr, [3] plateau best,
- *         [4] plateau num_bad (as float), [5] last loss, [6],[7] reserved.
+ *         [4] plateau num_bad (as float), [5] last loss, [6],[7] "frozen by a non-finite loss" flag of odd/even steps
+ *         (double buffer, internal; cleared at the start of every fit call, like `status`).
  * Zero-initialise for a cold fit (step0 == 0 takes lr from InrOptDesc and resets the plateau state;
  * step0 > 0 continues from header[2..4]). */
 #define INR_OPT_HEADER_FLOATS 8
 
 /* Capabilities. max_hidden: largest n_hidden any built kernel supports; lds_bytes: LDS used by the h=130 kernel. */
 int inrfit_query(int* abi_version, int* max_hidden, int* lds_bytes);
+/* Static, host string: ABI version, target, the slab base and the compiler + code-generation flags this binary was built
+ * with (awesome_amd/build.py passes them in).  The fit is a chaotic iteration: two builds whose VALU arithmetic rounds
+ * differently (e.g. another fused-multiply-add contraction) end a 2000-step fit a few mask pixels apart, so bench.py prints
+ * this string next to the parameter checksum.  The library is built with -ffp-contract=off: every fma is an explicit fmaf. */
+const char* inrfit_build_info(void);
+/* Gradient slabs (= workgroups) one image gets in a launch of n_images images over n_points points: min(256 / n_images, chunks),
+ * at least 1.  A constant of the library (NOT the device's CU count), because it fixes the summation order of the gradients. */
+int inrfit_slabs_per_image(int64_t n_points, int n_images);
+/* Test / measurement hook: replace the 256 above (0 = default).  Process-global; not for production use - it changes the
+ * rounding of every gradient sum and therefore the trajectory of a fit (tests/test_gpu_determinism.py bounds by how much). */
+int inrfit_debug_set_slab_base(int slab_base);
 /* 1 if (h, C, L) has a compiled kernel, else 0. */
 int inrfit_supported(const InrModelDesc* model);
 int64_t inrfit_param_count(const InrModelDesc* model);

@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Golden vectors for the BOUNDARY classes of the hot path, generated from the REAL reference classes (CPU, build container
+only; VERDICT r01 item 3, SURVEY.md §8c fixtures 3, 4, 8):
+
+    ConvexDiffeomorphismNet (class forward / gradients / translate)   awesome/model/convex_diffeomorphism_net.py:41-188
+    FBMSJointLoss (both clip branches)                                 awesome/measures/fbms_joint_loss.py:35-59
+    WrapperModule.forward / split_model_output                         awesome/model/wrapper_module.py:157-319
+    PriorCache.get_state() / PriorManager swap                         awesome/util/prior_cache.py:10-90, dataset/prior_dataset.py:70-110
+
+These modules import, directly or through awesome/serialization, three third-party packages that are not installed here
+(`toml`, `jsonpickle`, `simple_parsing`).  None of them takes part in the arithmetic being recorded: `toml` reads the package
+name out of pyproject.toml, `jsonpickle` is a serialisation rule for unknown objects, `simple_parsing` extracts attribute
+docstrings for argparse help texts.  They are replaced IN THIS PROCESS by the inert module objects below (SURVEY.md §8c's
+recipe); every number written to the fixtures comes out of the reference's own code.  PROVENANCE.txt lists these fixtures
+separately.  Nothing in the product imports this file; the reference never travels.
+
+Usage:  python tools/gen_golden_boundary.py [--out tests/golden]
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gen_golden import REF, seed_all, sd_np, grads_np, blob_unaries  # noqa: E402
+
+
+def _install_inert_modules():
+    toml = types.ModuleType("toml")
+    toml.load = lambda *a, **k: {"tool": {"poetry": {"name": "awesome", "version": "0.0.0"}}}
+    sys.modules["toml"] = toml
+    jp = types.ModuleType("jsonpickle")
+    jp.encode = lambda obj, *a, **k: json.dumps(str(obj))
+    jp.decode = lambda s, *a, **k: s
+    sys.modules["jsonpickle"] = jp
+    sp = types.ModuleType("simple_parsing")
+    spd = types.ModuleType("simple_parsing.docstring")
+    spd.get_attribute_docstring = lambda *a, **k: types.SimpleNamespace(docstring_below="", comment_above="", comment_inline="")
+    sp.docstring = spd
+    sys.modules["simple_parsing"] = sp
+    sys.modules["simple_parsing.docstring"] = spd
+
+
+def _import_reference():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference checkout not present; fixtures can only be generated in the build container")
+    _install_inert_modules()
+    sys.path.insert(0, REF)
+    for sub in ("model", "dataset"):  # skip the eager package __init__ files (they pull cv2 / torchvision)
+        pkg = types.ModuleType(f"awesome.{sub}")
+        pkg.__path__ = [os.path.join(REF, "awesome", sub)]
+        sys.modules[f"awesome.{sub}"] = pkg
+    import awesome.model.convex_net as convex_net
+    import awesome.model.convex_diffeomorphism_net as cdn
+    import awesome.model.wrapper_module as wrapper_module
+    import awesome.model.forward_module as forward_module
+    import awesome.measures.fbms_joint_loss as fbms
+    import awesome.measures.se as se
+    import awesome.measures.unaries_weighted_loss as uwl
+    import awesome.util.prior_cache as prior_cache
+    import awesome.dataset.prior_dataset as prior_dataset
+    return types.SimpleNamespace(convex_net=convex_net, cdn=cdn, wrapper_module=wrapper_module, forward_module=forward_module,
+                                 fbms=fbms, se=se, uwl=uwl, prior_cache=prior_cache, prior_dataset=prior_dataset)
+
+
+def linspace_grid(h, w):
+    xs, ys = torch.linspace(0, 1, w), torch.linspace(0, 1, h)
+    return torch.stack([xs[None, :].expand(h, w), ys[:, None].expand(h, w)], 0)[None].contiguous()   # (1, 2, H, W)
+
+
+def gen_cdn_class(ref, out):
+    """The class itself (fixture 3): forward on a (1,2,H,W) grid, BCE(sigmoid) loss gradients w.r.t. every parameter, and
+    translate / translate_only_point (the centre-of-mass warm start, :43-128)."""
+    for tag, kw, hw in (("l2_w130_k6", dict(n_hidden=130, n_hidden_layers=2, nf_layers=6, nf_hidden=130), (24, 20)),
+                        ("l1_w24_k4", dict(n_hidden=64, n_hidden_layers=1, nf_layers=4, nf_hidden=24), (16, 16))):
+        seed_all(21)
+        m = ref.cdn.ConvexDiffeomorphismNet(**kw)
+        grid = linspace_grid(*hw)
+        un = torch.from_numpy(blob_unaries(hw[0], hw[1], 3))[None, None]
+        logits = m(grid)
+        loss = torch.nn.BCELoss()(torch.sigmoid(logits), un)
+        loss.backward()
+        rec = dict(grid=grid.numpy(), unaries=un.numpy(), logits=logits.detach().numpy(), loss=np.float32(loss.item()),
+                   deformation=m.get_deformation(grid).detach().numpy(), kwargs=json.dumps(kw))
+        rec.update(sd_np(m))
+        rec.update(grads_np(m))
+        # the centre-of-mass warm start between frames (:337-348): translate_only_point(prev_com (x, y), com (x, y), grid)
+        src = torch.tensor([7, 9], dtype=torch.long)     # pixel (x, y) of the previous frame's centre of mass
+        dst = torch.tensor([10, 6], dtype=torch.long)    # ... of the current frame
+        m.zero_grad()
+        with torch.no_grad():
+            before = m(grid).numpy()
+        m.translate_only_point(src, dst, grid=grid.squeeze())
+        with torch.no_grad():
+            after = m(grid).numpy()
+        rec.update(tr_src=src.numpy(), tr_dst=dst.numpy(), tr_logits_before=before, tr_logits_after=after)
+        rec.update(sd_np(m, "sd_tr."))
+        np.savez_compressed(os.path.join(out, f"cdn_class_{tag}.npz"), **rec)
+        print("cdn_class", tag, float(loss))
+
+
+def gen_fbms_joint_loss(ref, out):
+    """FBMSJointLoss (fixture 4): output (B, 2, H, W) = [seg, prior]; both clip branches, loss value and gradient w.r.t. the
+    output."""
+    rec = {}
+    rng = np.random.RandomState(5)
+    for case, (beta, scale) in enumerate(((0.5, 1.0), (50.0, 1.0), (2.0, 0.2))):
+        out_t = torch.from_numpy(rng.uniform(0.02, 0.98, (2, 2, 12, 10)).astype(np.float32)).requires_grad_(True)
+        tgt = torch.from_numpy((rng.uniform(size=(2, 1, 12, 10)) > 0.5).astype(np.float32))
+        if scale != 1.0:   # make prior ~ seg so that the penalty is tiny
+            with torch.no_grad():
+                out_t[:, 1] = out_t[:, 0] + (out_t[:, 1] - out_t[:, 0]) * scale
+        crit = ref.fbms.FBMSJointLoss(criterion=torch.nn.BCELoss(), alpha=1.0, beta=beta)
+        loss = crit(out_t, tgt)
+        loss.backward()
+        rec[f"c{case}.output"] = out_t.detach().numpy()
+        rec[f"c{case}.target"] = tgt.numpy()
+        rec[f"c{case}.beta"] = np.float32(beta)
+        rec[f"c{case}.loss"] = np.float32(loss.item())
+        rec[f"c{case}.grad"] = out_t.grad.numpy().copy()
+        print("fbms case", case, float(loss))
+    import inspect
+    rec["signature"] = str(inspect.signature(ref.fbms.FBMSJointLoss.__init__))
+    np.savez_compressed(os.path.join(out, "fbms_joint_loss.npz"), **rec)
+
+
+def gen_wrapper(ref, out):
+    """WrapperModule(ForwardModule, ConvexNextNet) forward (fixture 4b): image mode, param_clean_grid; with and without the
+    segmentation inversion; evaluate_prior off (what the pretrain loop reads the unaries from)."""
+    seed_all(31)
+    prior = ref.convex_net.ConvexNextNet(n_hidden=32, in_features=2, n_hidden_layers=1)
+    seg = ref.forward_module.ForwardModule()
+    H, W = 10, 12
+    grid = linspace_grid(H, W)[0]
+    rng = np.random.RandomState(7)
+    img = torch.from_numpy(rng.normal(size=(2, 1, H, W)).astype(np.float32))     # "image" = the logits the ForwardModule hands on
+    feat = torch.zeros(2, 1, H, W)
+    xy = grid[None].repeat(2, 1, 1, 1)
+    rec = dict(img=img.numpy(), xy=xy.numpy())
+    rec.update(sd_np(prior, "prior."))
+    for inv in (False, True):
+        wm = ref.wrapper_module.WrapperModule(segmentation_module=seg, prior_module=prior, prior_arg_mode="param_clean_grid",
+                                              input_mode="image", use_segmentation_sigmoid=True, use_prior_sigmoid=True,
+                                              use_segmentation_output_inversion=inv)
+        with torch.no_grad():
+            o = wm(img, feat, xy)
+            rec[f"out_inv{int(inv)}"] = o.numpy()
+            wm.evaluate_prior = False
+            rec[f"seg_only_inv{int(inv)}"] = wm(img, feat, xy).numpy()
+            wm.evaluate_prior = True
+            parts = wm.split_model_output(o)
+            rec[f"split0_seg_inv{int(inv)}"] = parts[0][0].numpy()
+            rec[f"split0_prior_inv{int(inv)}"] = parts[0][1].numpy()
+            pa, pk = wm.get_prior_args(img[0], feat[0], xy[0])
+            rec[f"prior_arg_inv{int(inv)}"] = pa[0].numpy()
+    np.savez_compressed(os.path.join(out, "wrapper_module.npz"), **rec)
+    print("wrapper", rec["out_inv0"].shape)
+
+
+def gen_prior_cache(ref, out):
+    """PriorCache.get_state() (fixture 8): the layout a fitted cache has on disk - key names, dtypes, the JSON of model_args -
+    and the PriorManager swap (enter loads the state of a key, exit stores the model's state back)."""
+    PriorCache, PriorManager = ref.prior_cache.PriorCache, ref.prior_dataset.PriorManager
+    model_args = dict(n_hidden=16, in_features=2, n_hidden_layers=1)
+    seed_all(41)
+    cache = PriorCache(ref.convex_net.ConvexNextNet, model_args)
+    model = ref.convex_net.ConvexNextNet(**model_args)
+    s3 = cache[3]            # generated on first access
+    s7 = cache[7]
+    with PriorManager(model, prior_state=(3, s3), prior_cache=cache):
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.25)
+    state = cache.get_state()
+    rec = {"model_type": state["model_type"], "model_args": state["model_args"], "store_device": state["store_device"],
+           "cache_keys": json.dumps(sorted(state["cache"].keys())),
+           "state_keys": json.dumps(list(state["cache"]["3"].keys()))}
+    for k, sd in state["cache"].items():
+        for n, v in sd.items():
+            rec[f"cache.{k}.{n}"] = v.numpy()
+    for n, v in s7.items():
+        rec[f"generated7.{n}"] = v.numpy()
+    # round trip: set_state on a fresh cache gives the same entries
+    c2 = PriorCache(None, None)
+    c2.set_state(state)
+    assert sorted(c2.get_state()["cache"].keys()) == sorted(state["cache"].keys())
+    np.savez_compressed(os.path.join(out, "prior_cache_state.npz"), **rec)
+    print("prior_cache", rec["model_type"], rec["model_args"], rec["cache_keys"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    torch.set_num_threads(4)
+    ref = _import_reference()
+    gen_fbms_joint_loss(ref, args.out)
+    gen_wrapper(ref, args.out)
+    gen_prior_cache(ref, args.out)
+    gen_cdn_class(ref, args.out)
+
+
+if __name__ == "__main__":
+    main()
