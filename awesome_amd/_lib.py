@@ -15,7 +15,8 @@ INR_LOSS_SE, INR_LOSS_BCE = 0, 1
 INR_WEIGHT_NONE, INR_WEIGHT_EQUAL, INR_WEIGHT_RATIO, INR_WEIGHT_SSSDMS, INR_WEIGHT_EXPLICIT = 0, 1, 2, 3, 4
 INR_OPT_ADAM, INR_OPT_ADAMAX = 0, 1
 INR_OPT_HEADER_FLOATS = 8
-INRFIT_ABI_VERSION = 1
+INRFIT_ABI_VERSION = 2
+INR_FLOW_NORMAL_BLOCK, INR_FLOW_SIMPLE = 0, 1
 
 INR_LOSS_EXTERNAL = 2
 LOSS_KINDS = {"se": INR_LOSS_SE, "bce": INR_LOSS_BCE, "external": INR_LOSS_EXTERNAL}
@@ -35,7 +36,7 @@ class InrGridDesc(C.Structure):
 
 
 class InrFlowDesc(C.Structure):
-    _fields_ = [("width", C.c_int32), ("num_coupling", C.c_int32)]
+    _fields_ = [("width", C.c_int32), ("num_coupling", C.c_int32), ("backbone", C.c_int32)]
 
 
 INR_RNVP_MAX_FLOWS = 32
@@ -83,6 +84,8 @@ EXPORTS = {
     "inrfit_cdn_workspace_bytes": (C.c_int64, [C.POINTER(InrModelDesc), C.POINTER(InrFlowDesc), C.POINTER(InrGridDesc), C.c_int]),
     "inrfit_flow_forward": (C.c_int, [C.POINTER(InrFlowDesc), C.c_void_p, C.POINTER(InrGridDesc), C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_flow_backward": (C.c_int, [C.POINTER(InrFlowDesc), C.c_void_p, C.POINTER(InrGridDesc), C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_int64, C.c_void_p]),
     "inrfit_cdn_forward": (C.c_int, [C.POINTER(InrModelDesc), C.POINTER(InrFlowDesc), C.c_void_p, C.c_void_p,
                                      C.POINTER(InrGridDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "inrfit_cdn_loss_grad": (C.c_int, [C.POINTER(InrModelDesc), C.POINTER(InrFlowDesc), C.c_void_p, C.c_void_p,

@@ -21,7 +21,7 @@
 
 namespace {
 
-constexpr float LEAKY_SLOPE = 0.01f;  // F.leaky_relu default
+constexpr float LEAKY_SLOPE = 0.01f;  // F.leaky_relu default (NormalBlock); SimpleBackbone uses relu = slope 0 (FlowMap::slope)
 
 struct FlowMap {   // layouts derived from (W, K)
     int W, K;
@@ -31,12 +31,14 @@ struct FlowMap {   // layouts derived from (W, K)
                       // (w1s, w1t, b1s, b1t, w2's, w2't, w1s*w2's, w1t*w2't) per unit, then (b2's, b2't, a's, a't):
                       // the s and t nets share their input, so they are evaluated as one packed pair
     int e_nb, e_scale, FE;
+    float slope;      // negative slope of the hidden activation: 0.01 (NormalBlock, diffeomorphism_net.py:169-192) or 0 (SimpleBackbone, :83-104)
 };
 
-__host__ __device__ inline FlowMap make_flow_map(int W, int K) {
+__host__ __device__ inline FlowMap make_flow_map(int W, int K, float slope = LEAKY_SLOPE) {
     FlowMap m;
     m.W = W;
     m.K = K;
+    m.slope = slope;
     m.nb_stride = 3 * W + 3;
     m.p_nb = 6;
     m.p_scale = m.p_nb + 2 * K * m.nb_stride;
@@ -377,13 +379,13 @@ __global__ __launch_bounds__(256) void flow_bwd_units_kernel(const FlowUnitsArgs
     }
     const float G0 = sum_over_groups(sum_over_points(g0)), G1 = sum_over_groups(sum_over_points(g1));   // in every lane
     __shared__ float red[4][UPL][3][64];
-    constexpr float SL = LEAKY_SLOPE / (1.f - LEAKY_SLOPE);
+    const float SL = a.m.slope / (1.f - a.m.slope);
 #pragma unroll
     for (int r = 0; r < UPL; ++r) {
         const float a0 = fmaf(SL, G0, A0[r][0] + A0[r][1]), a1 = fmaf(SL, G1, A1[r][0] + A1[r][1]);   // / (1 - slope)
         red[wave][r][0][lane] = w2p[r] * a1;                                      // dw1
         red[wave][r][1][lane] = w2p[r] * a0;                                      // db1
-        red[wave][r][2][lane] = (1.f - LEAKY_SLOPE) * fmaf(w1[r], a1, b1[r] * a0);   // dw2
+        red[wave][r][2][lane] = (1.f - a.m.slope) * fmaf(w1[r], a1, b1[r] * a0);   // dw2
     }
     __syncthreads();
     for (int t = threadIdx.x; t < UPL * 192; t += 256) {
@@ -516,15 +518,15 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
         const float w1e = v1 * (g1 / n1), w2e = v2 * (g2 / n2);   // 0 for the threads past W
         const float sa = block_sum256(w2e * w1e, sm), sb = block_sum256(w2e * b1, sm);
         if (on) {
-            const float w2p = (1.f - LEAKY_SLOPE) * w2e;
+            const float w2p = (1.f - m.slope) * w2e;
             fe[eb + 8 * tid] = w1e;
             fe[eb + 8 * tid + 2] = b1;
             fe[eb + 8 * tid + 4] = w2p;
             fe[eb + 8 * tid + 6] = w1e * w2p;
         }
         if (tid == 0) {
-            fe[eb + 8 * W] = fmaf(LEAKY_SLOPE, sb, b2);
-            fe[eb + 8 * W + 2] = LEAKY_SLOPE * sa;
+            fe[eb + 8 * W] = fmaf(m.slope, sb, b2);
+            fe[eb + 8 * W + 2] = m.slope * sa;
         }
         return;
     }

@@ -553,7 +553,7 @@ int inrfit_query(int* abi_version, int* max_hidden, int* lds_bytes) {
 #define INRFIT_BUILD_FLAGS "unknown (not built by awesome_amd/build.py)"
 #endif
 const char* inrfit_build_info(void) {
-    return "libinrfit abi " "1" "; gfx950; slab_base 256; " __VERSION__ "; flags: " INRFIT_BUILD_FLAGS;
+    return "libinrfit abi " "2" "; gfx950; slab_base 256; " __VERSION__ "; flags: " INRFIT_BUILD_FLAGS;
 }
 
 int inrfit_debug_set_slab_base(int slab_base) {
@@ -879,14 +879,14 @@ struct CdnWs {
 long long align256(long long b) { return (b + 255) / 256 * 256; }
 
 bool flow_ok(const InrFlowDesc* f) {
-    return f && f->width >= 1 && f->width <= 256 &&
+    return f && f->width >= 1 && f->width <= 256 && (f->backbone == INR_FLOW_NORMAL_BLOCK || f->backbone == INR_FLOW_SIMPLE) &&
            (f->num_coupling == 2 || f->num_coupling == 4 || f->num_coupling == 6 || f->num_coupling == 8);
 }
 
 CdnWs carve_cdn(const KernelEntry* e, const InrFlowDesc* f, const InrGridDesc* grid, int n_images, void* base) {
     CdnWs w;
     const long long N = grid->n_points;
-    w.fm = make_flow_map(f->width, f->num_coupling);
+    w.fm = make_flow_map(f->width, f->num_coupling, f->backbone == INR_FLOW_SIMPLE ? 0.f : LEAKY_SLOPE);
     w.blocks1 = (int)((N + 256 * FLOW_PPL - 1) / (256 * FLOW_PPL));
     w.Wp = (f->width + 63) / 64 * 64;
     w.chunks = 64;   // x 2K nets x 4 waves: enough waves for 1024 SIMDs at one image
@@ -1038,6 +1038,22 @@ int inrfit_flow_forward(const InrFlowDesc* flow, const float* flow_params, const
     hipStream_t s = (hipStream_t)stream;
     launch_flow_update(w, flow, n_images, 2, (float*)flow_params, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0, s);
     launch_flow_fwd(w, grid, n_images, out_coords, s);
+    return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
+}
+
+int inrfit_flow_backward(const InrFlowDesc* flow, const float* flow_params, const InrGridDesc* grid, const float* dout_coords,
+                         int n_images, float* flow_grads, void* workspace, int64_t workspace_bytes, void* stream) {
+    const KernelEntry* e;
+    CdnWs w;
+    if (!flow_params || !dout_coords || !flow_grads) return INR_EINVAL;
+    int rc = check_cdn(nullptr, flow, grid, n_images, workspace, workspace_bytes, false, &e, &w);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    launch_flow_update(w, flow, n_images, 2, (float*)flow_params, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0, s);
+    if (hipMemcpyAsync(w.dxd, dout_coords, sizeof(float) * 2 * (size_t)grid->n_points * n_images, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return INR_ELAUNCH;
+    launch_flow_bwd(w, flow, grid, n_images, s);   // recomputes the forward from the grid, walks the couplings backwards
+    launch_flow_update(w, flow, n_images, 1, (float*)flow_params, nullptr, flow_grads, nullptr, 0.f, 0, nullptr, 0, s);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 

@@ -63,6 +63,10 @@ class PriorManager:
         if isinstance(prior_cache, PriorDataset):
             prior_cache = prior_cache.__prior_cache__
         self.prior_cache = prior_cache if isinstance(prior_cache, PriorCache) else None
+        if store_device is None and self.prior_cache is not None:
+            # as in the reference (:84-85): a manager built without store_device clears the cache's one, so what the swap stores
+            # stays on the model's device from then on (get_state() then says store_device 'None'; set_state maps it to cpu)
+            self.prior_cache.store_device = store_device
         if model_device is None:
             model_device = next(model.parameters()).device
         self.model_device, self.training = model_device, training

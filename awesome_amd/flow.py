@@ -23,9 +23,10 @@ Tensor = torch.Tensor
 class FlowSpec:
     width: int = 130
     num_coupling: int = 6
+    backbone: str = "normal_block"   # 'normal_block' (= 'residual_block') | 'default' (SimpleBackbone), diffeomorphism_net.py:252-268
 
     def desc(self) -> L.InrFlowDesc:
-        return L.InrFlowDesc(self.width, self.num_coupling)
+        return L.InrFlowDesc(self.width, self.num_coupling, L.INR_FLOW_SIMPLE if self.backbone == "default" else L.INR_FLOW_NORMAL_BLOCK)
 
     @property
     def n_params(self) -> int:
@@ -34,12 +35,13 @@ class FlowSpec:
     def keys_shapes(self, prefix: str = "diffeo_net.", linear_prefix: str = "linear.") -> List[Tuple[str, Tuple[int, ...]]]:
         """state_dict keys of ConvexDiffeomorphismNet's flow part in flat-vector order."""
         W, out = self.width, [(linear_prefix + "weight", (2, 2)), (linear_prefix + "bias", (2,))]
+        l1, l2 = ("linear1", "linear2") if self.backbone == "default" else ("in_linear", "out_linear")
         for i in range(self.num_coupling):
             for net in ("s", "t"):
                 b = f"{prefix}{net}.{i}."
-                out += [(b + "in_linear.linear.weight_v", (W, 1)), (b + "in_linear.linear.weight_g", ()),
-                        (b + "in_linear.linear.bias", (W,)), (b + "out_linear.linear.weight_v", (1, W)),
-                        (b + "out_linear.linear.weight_g", ()), (b + "out_linear.linear.bias", (1,))]
+                out += [(b + l1 + ".linear.weight_v", (W, 1)), (b + l1 + ".linear.weight_g", ()),
+                        (b + l1 + ".linear.bias", (W,)), (b + l2 + ".linear.weight_v", (1, W)),
+                        (b + l2 + ".linear.weight_g", ()), (b + l2 + ".linear.bias", (1,))]
         for i in range(self.num_coupling):
             b = f"{prefix}scale.{i}."
             out += [(b + "weight", (1,)), (b + "scale.bias", (1,)), (b + "scale.weight_g", (1, 1)), (b + "scale.weight_v", (1, 1))]
@@ -111,6 +113,21 @@ def flow_forward(fspec: FlowSpec, flow_params: Tensor, grid: K.Grid) -> Tensor:
                                       K._stream_ptr(fp.device))
     L.check(rc, "inrfit_flow_forward")
     return out
+
+
+def flow_backward(fspec: FlowSpec, flow_params: Tensor, grid: K.Grid, dout_coords: Tensor) -> Tensor:
+    """Vector-Jacobian product of flow_forward: dout_coords [n_images, 2, N] -> gradients [n_images, FP] (forward recomputed)."""
+    fp = K._check_dev(flow_params, "flow_params")
+    d = K._check_dev(dout_coords, "dout_coords")
+    n = fp.shape[0]
+    assert d.shape == (n, 2, grid.n_points), (d.shape, n, grid.n_points)
+    grads = L.scratch_like(fp)
+    ws = _ws(None, fspec, grid, n)
+    fd, gd = fspec.desc(), grid.desc()
+    rc = L.load().inrfit_flow_backward(C.byref(fd), fp.data_ptr(), C.byref(gd), d.data_ptr(), n, grads.data_ptr(), ws.data_ptr(),
+                                       ws.numel() * 4, K._stream_ptr(fp.device))
+    L.check(rc, "inrfit_flow_backward")
+    return grads
 
 
 def cdn_forward(ispec: K.IcnnSpec, fspec: FlowSpec, icnn_params: Tensor, flow_params: Tensor, grid: K.Grid) -> Tensor:

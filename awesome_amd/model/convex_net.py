@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from .. import icnn as K
+from .pretrainable_module import PriorFitMixin
 
 
 class _IcnnFunction(torch.autograd.Function):
@@ -71,8 +72,34 @@ class _Block(nn.Module):
             self.ln.weight.clamp_(min=0.0)
 
 
-class _IcnnModule(nn.Module):
+class _IcnnModule(nn.Module, PriorFitMixin):
+    """Common part of the ICNN drop-ins.  `pretrain(...)` (PriorFitMixin) is an extension: the reference's ConvexNet /
+    ConvexNextNet are not PretrainableModules (their configs train through TorchAgent._perform_step); here the same
+    `_prior_based_pretrain` loop semantics (path_connected_net.py:730-1007: Adamax lr 1e-3, UnariesWeightedLoss(SE),
+    ReduceLROnPlateau(200, 0.5), IoU gate + retry, reuse_state) run on `inrfit_fit`, so one entry point serves every prior."""
     spec: K.IcnnSpec
+
+    # -- PriorFitMixin engine -----------------------------------------------------------------------------------------------
+    def _pretrain_defaults(self):
+        return dict(num_epochs=2000, lr=1e-3, optimizer="adamax", weight_decay=0.0, reuse_state=True, reuse_state_epochs=200,
+                    proper_prior_fit_threshold=0.5, proper_prior_fit_retrys=1)
+
+    def _engine_pack(self, sd):
+        return K.pack_state_dict(self.spec, sd)
+
+    def _engine_unpack(self, flat):
+        return K.unpack_params(self.spec, flat, convexnet_keys=hasattr(self, "W0y"))
+
+    def _engine_fit(self, grid, unaries, flat, epochs, cold, opts, states=None):
+        from ..measures import criterion_to_desc
+        crit = opts.get("criterion")
+        kind, wmode, ratio = criterion_to_desc(crit) if crit is not None else ("se", "none", 1.0)
+        res = K.fit(self.spec, flat, grid, unaries, epochs, lr=float(opts.get("lr", 1e-3)), loss=kind, weight_mode=wmode, ratio=ratio,
+                    optimizer=opts.get("optimizer", "adamax"), weight_decay=float(opts.get("weight_decay", 0.0)),
+                    plateau=dict(patience=200, factor=0.5) if opts.get("use_plateau", True) else None, record_loss=False,
+                    want_logits=True,
+                    **dict(getattr(self, "fit_options", None) or dict(clamp=True)))
+        return res.params, res.logits, res.status
 
     def _ordered_params(self) -> List[torch.Tensor]:
         sd = dict(self.named_parameters())

@@ -7,8 +7,11 @@ creation order of the leaves (seeded construction = reference init).
 
 `ConvexDiffeomorphismNet.forward` and its autograd backward run entirely on the HIP path (flow kernels + ICNN kernels,
 `inrfit_cdn_forward` / `inrfit_cdn_loss_grad` with an external dL/dlogits); `fit_images` is the fused device-resident
-form of `ConvexDiffeomorphismNet.pretrain`'s inner loop (`inrfit_cdn_fit`).  The stand-alone flow modules
-(`NormalizingFlow1D`, `NormalBlock`, ...) are torch-op modules (they are the containers of the parameters)."""
+form of `ConvexDiffeomorphismNet.pretrain`'s inner loop (`inrfit_cdn_fit`).  `NormalizingFlow1D.forward` (with autograd)
+and `ConvexDiffeomorphismNet.get_deformation` run on `inrfit_flow_forward` / `inrfit_flow_backward`.  The leaf modules
+(`WNLinear`, `NormalBlock`, `SimpleBackbone`, `WNScale`) are the containers of the parameters; called on their own they are
+plain torch expressions of their one-line definitions (no kernel exists for a single 1 -> W -> 1 net: the unit of work on
+the device is the whole flow)."""
 from __future__ import annotations
 
 import math
@@ -22,6 +25,7 @@ import torch.nn.functional as F
 from .. import flow as FL
 from .. import icnn as K
 from .convex_net import ConvexNextNet, _kaiming_uniform_reset
+from .pretrainable_module import PriorFitMixin, center_of_mass
 
 
 class _CdnFunction(torch.autograd.Function):
@@ -48,6 +52,30 @@ class _CdnFunction(torch.autograd.Function):
             outs.append(g[off:off + n].reshape(shp))
             off += n
         return (None, None, None, None, *outs)
+
+
+class _FlowFunction(torch.autograd.Function):
+    """deformed coords (2, N) = flow(A x + b) on the HIP path; backward = inrfit_flow_backward (parameter gradients only - the
+    grid is an input, never a learned quantity)."""
+
+    @staticmethod
+    def forward(ctx, coords: torch.Tensor, fspec, *params: torch.Tensor):
+        fp = torch.cat([p.reshape(-1) for p in params]).to(torch.float32)[None].contiguous()
+        grid = K.Grid.explicit(coords)
+        ctx.fspec, ctx.grid, ctx.shapes = fspec, grid, [p.shape for p in params]
+        ctx.save_for_backward(fp)
+        return FL.flow_forward(fspec, fp, grid)[0]
+
+    @staticmethod
+    def backward(ctx, dout: torch.Tensor):
+        (fp,) = ctx.saved_tensors
+        g = FL.flow_backward(ctx.fspec, fp, ctx.grid, dout.contiguous()[None])[0]
+        outs, off = [], 0
+        for shp in ctx.shapes:
+            n = math.prod(shp) if len(shp) else 1
+            outs.append(g[off:off + n].reshape(shp))
+            off += n
+        return (None, None, *outs)
 
 
 class WNLinear(nn.Module):
@@ -97,6 +125,22 @@ class NormalBlock(nn.Module):
         return torch.tanh(self.out_linear(F.leaky_relu(self.in_linear(x))))
 
 
+class SimpleBackbone(nn.Module):
+    """tanh(WN2(relu(WN1 x)))  (diffeomorphism_net.py:83-104) - NormalizingFlow1D's 'default' backbone."""
+
+    def __init__(self, in_channels: int = 2, network_width: int = 10, **kwargs):
+        super().__init__()
+        self.linear1 = WNLinear(in_channels, network_width)
+        self.linear2 = WNLinear(network_width, in_channels)
+
+    def reset_parameters(self) -> None:
+        _apply_uniform(self.linear1, "relu")
+        _apply_uniform(self.linear2, "tanh")
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.tanh(self.linear2(F.relu(self.linear1(x))))
+
+
 class WNScale(nn.Module):
     """Learnable scalar through a weight-normed 1x1 linear (diffeomorphism_net.py:208-232)."""
 
@@ -120,17 +164,25 @@ class WNScale(nn.Module):
 
 
 class NormalizingFlow1D(nn.Module):
-    """Alternating affine couplings on the two coordinates (diffeomorphism_net.py:235-302), `normal_block` backbone."""
+    """Alternating affine couplings on the two coordinates (diffeomorphism_net.py:235-302).  Backbones as in the reference:
+    'default' = SimpleBackbone (relu; what a bare ConvexDiffeomorphismNet() builds), 'normal_block' / 'residual_block' =
+    NormalBlock (leaky_relu; every reference config).  'resnet' (SimpleResnet, no config uses it) has no fused form."""
 
     def __init__(self, num_coupling: int = 4, width: int = 130, num_blocks: int = 1, in_features: int = 2,
-                 backbone: str = "normal_block", **kwargs):
+                 backbone: str = "default", **kwargs):
         super().__init__()
         if num_coupling % in_features != 0:
             raise ValueError(f"Number of coupling layers should be divisible by in_features ({in_features})")
-        if backbone not in ("normal_block", "residual_block"):
-            raise ValueError("only the normal_block backbone (all path-connectedness configs) is implemented")
+        if backbone == "resnet":
+            raise NotImplementedError("the 'resnet' backbone (SimpleResnet) is not on the HIP path; no reference config uses it")
+        if backbone not in ("default", "normal_block", "residual_block"):
+            raise ValueError(f"Unknown backbone: {backbone}")
         self.num_coupling, self.in_features = num_coupling, in_features
-        mk = lambda: NormalBlock(in_channels=1, mid_channels=width, out_channels=1)  # noqa: E731
+        self.backbone = "default" if backbone == "default" else "normal_block"
+        if backbone == "default":
+            mk = lambda: SimpleBackbone(in_channels=1, network_width=width)  # noqa: E731
+        else:
+            mk = lambda: NormalBlock(in_channels=1, mid_channels=width, out_channels=1)  # noqa: E731
         self.s = nn.ModuleList([mk() for _ in range(num_coupling)])
         self.t = nn.ModuleList([mk() for _ in range(num_coupling)])
         self.scale = nn.ModuleList([WNScale(dim=1) for _ in range(num_coupling)])
@@ -142,18 +194,110 @@ class NormalizingFlow1D(nn.Module):
             sc.reset_parameters()
         return True
 
+    def _spec(self) -> "FL.FlowSpec":
+        first = self.s[0].linear1 if self.backbone == "default" else self.s[0].in_linear
+        return FL.FlowSpec(first.linear.weight_v.shape[0], self.num_coupling, self.backbone)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x1, x2 = x[:, :1], x[:, 1:]
-        for i in range(self.num_coupling):
-            if i % 2 == 0:
-                x2 = torch.exp(self.scale[i]() * self.s[i](x1)) * x2 + self.t[i](x1)
-            else:
-                x1 = torch.exp(self.scale[i]() * self.s[i](x2)) * x1 + self.t[i](x2)
-        return torch.cat([x1, x2], 1)
+        """(N, 2) -> (N, 2) on the HIP flow kernels (forward and autograd backward); the kernels' leading 2x2 linear is the
+        identity here."""
+        if not x.is_cuda:
+            raise RuntimeError("awesome_amd modules run on the MI355X only (no CPU fallback); move module and input to cuda")
+        if self.in_features != 2 or x.dim() != 2 or x.shape[1] != 2:
+            raise ValueError("the coupling flow maps (N, 2) rows (2-D only, like the reference, diffeomorphism_net.py:288)")
+        fspec = self._spec()
+        sd = dict(self.named_parameters())
+        own = [sd[k] for k, _ in fspec.keys_shapes(prefix="") if not k.startswith("linear.")]
+        eye = torch.eye(2, device=x.device, dtype=torch.float32)
+        out = _FlowFunction.apply(x.t().contiguous(), fspec, eye, torch.zeros(2, device=x.device), *own)
+        return out.t()
 
 
-class ConvexDiffeomorphismNet(nn.Module):
-    """ICNN(flow(Ax + b))  (convex_diffeomorphism_net.py:130-188)."""
+def translate_linear(weight: torch.Tensor, bias: torch.Tensor, from_points: torch.Tensor, to_points: torch.Tensor):
+    """ConvexDiffeomorphismNet.translate (convex_diffeomorphism_net.py:79-128): new (weight, bias) of the input linear layer such
+    that `to_points` are mapped where `from_points` were - least squares on the augmented points, same operations."""
+    if from_points.shape != to_points.shape:
+        raise ValueError("From and to points must have the same shape.")
+    if from_points.shape[0] < weight.shape[0]:
+        raise ValueError("Not enough points to sample from. Need at least {} points, got {}.".format(weight.shape[0], from_points.shape[0]))
+    to_points = to_points.to(dtype=weight.dtype, device=weight.device)
+    from_points = from_points.to(dtype=weight.dtype, device=weight.device)
+    from_transf = F.linear(from_points, weight, bias)
+    X = torch.cat((to_points, torch.ones((to_points.shape[0], 1), device=to_points.device, dtype=to_points.dtype)), dim=1)
+    theta = torch.linalg.inv(X.T @ X) @ (X.T @ from_transf)
+    return theta[:-1, :].T.contiguous(), theta[-1, :].contiguous()
+
+
+def translate_only_point_args(from_point: torch.Tensor, to_point: torch.Tensor, grid: torch.Tensor, in_features: int = 2):
+    """translate_only_point (:43-77): the pixel (x, y) `from_point` / `to_point` plus two helper points 3 pixels along each axis,
+    looked up in the (C, H, W) coordinate grid -> (from_points, to_points) [C + 1, C]."""
+    res_from = torch.zeros((in_features + 1, in_features), device=from_point.device, dtype=from_point.dtype)
+    res_to = torch.zeros((in_features + 1, in_features), device=to_point.device, dtype=to_point.dtype)
+    res_from[0, :], res_to[0, :] = from_point, to_point
+    for i in range(in_features):
+        v = torch.zeros(in_features, device=from_point.device, dtype=from_point.dtype)
+        v[i] += 3
+        res_from[i + 1, :] = res_from[0, :] + v
+        res_to[i + 1, :] = res_to[0, :] + v
+    grid = grid.squeeze()
+    pick = lambda pts: grid[..., pts[:, 1].to(dtype=torch.long), pts[:, 0].to(dtype=torch.long)].T  # noqa: E731
+    return pick(res_from), pick(res_to)
+
+
+class ConvexDiffeomorphismNet(nn.Module, PriorFitMixin):
+    """ICNN(flow(Ax + b))  (convex_diffeomorphism_net.py:130-188).  `pretrain` / `pretrain_load_state`: PriorFitMixin (the
+    reference's :190-490 on `inrfit_cdn_fit`, incl. the centre-of-mass translate of the warm start, :337-348)."""
+
+    # -- the reference's translate helpers (:43-128) -----------------------------------------------------------------------------
+    def translate(self, from_points: torch.Tensor, to_points: torch.Tensor) -> None:
+        w, b = translate_linear(self.linear.weight.data, self.linear.bias.data, from_points, to_points)
+        self.linear.weight.data, self.linear.bias.data = w, b
+
+    def translate_only_point(self, from_point: torch.Tensor, to_point: torch.Tensor, grid: torch.Tensor) -> None:
+        self.translate(*translate_only_point_args(from_point, to_point, grid, self.in_features))
+
+    # -- PriorFitMixin engine ------------------------------------------------------------------------------------------------
+    def _pretrain_defaults(self):
+        return dict(num_epochs=2000, lr=0.003, reuse_state=True, reuse_state_epochs=200, proper_prior_fit_threshold=0.5,
+                    proper_prior_fit_retrys=1, weight_decay_on_weight_g=5e-5, weight_decay_on_convex_weight=False)
+
+    def _engine_pack(self, sd):
+        ispec, fspec = self._specs()
+        i, f = FL.split_cdn_state_dict(ispec, fspec, sd)
+        return torch.cat([i.cpu(), f.cpu()])
+
+    def _engine_unpack(self, flat):
+        ispec, fspec = self._specs()
+        return FL.merge_cdn_state_dict(ispec, fspec, flat[:ispec.n_params], flat[ispec.n_params:])
+
+    def _engine_fit(self, grid, unaries, flat, epochs, cold, opts, states=None):
+        from ..measures import criterion_to_desc
+        if opts.get("weight_decay_on_convex_weight", False):
+            raise NotImplementedError("weight_decay_on_convex_weight=True (no reference config sets it) has no fused form")
+        ispec, fspec = self._specs()
+        P = ispec.n_params
+        crit = opts.get("criterion")
+        kind, wmode, ratio = criterion_to_desc(crit) if crit is not None else ("bce", "none", 1.0)   # UnariesWeightedLoss(BCELoss, 'none')
+        res = FL.cdn_fit(ispec, fspec, flat[:, :P].contiguous(), flat[:, P:].contiguous(), grid, unaries, epochs,
+                         lr=float(opts.get("lr", 0.003)), loss=kind, weight_mode=wmode, ratio=ratio,
+                         weight_decay_on_weight_g=float(opts.get("weight_decay_on_weight_g", 5e-5)),
+                         plateau=dict(patience=200, factor=0.5) if opts.get("use_plateau", True) else None, record_loss=False,
+                    want_logits=True)
+        return torch.cat([res.icnn_params, res.flow_params], 1), res.logits, res.status
+
+    def _engine_warm_start(self, flat, ctx, image, opts):
+        """:337-348: shift the previous frame's prior to this frame's centre of mass before the short refit."""
+        com = center_of_mass(image.unaries)
+        if ctx is not None:
+            P = self._specs()[0].n_params
+            w, b = flat[P:P + 4].reshape(2, 2).clone(), flat[P + 4:P + 6].clone()
+            pts = translate_only_point_args(ctx.flip(dims=(-1,)), com.flip(dims=(-1,)), image.grid.squeeze(), self.in_features)
+            w, b = translate_linear(w, b, *pts)
+            flat[P:P + 4], flat[P + 4:P + 6] = w.reshape(-1), b
+        return flat, com
+
+    def _engine_chain_context(self, ctx, image):
+        return center_of_mass(image.unaries) if ctx is None else ctx
 
     def __init__(self, n_hidden: int = 130, n_hidden_layers: int = 1, nf_layers: int = 4, nf_hidden: int = 70,
                  in_features: int = 2, diffeo_args: Optional[Dict[str, Any]] = None, **kwargs):
@@ -179,16 +323,21 @@ class ConvexDiffeomorphismNet(nn.Module):
         return True
 
     def get_deformation(self, x: torch.Tensor) -> torch.Tensor:
-        """(B,C,H,W) or (N,C) -> deformed coordinates in the same layout."""
+        """(B,C,H,W) or (N,C) -> deformed coordinates flow(Ax + b) in the same layout (convex_diffeomorphism_net.py:179-184), on
+        `inrfit_flow_forward`; no autograd (it is an inspection output)."""
+        if not x.is_cuda:
+            raise RuntimeError("awesome_amd modules run on the MI355X only (no CPU fallback); move module and input to cuda")
+        _, fspec, _, flow = self._ordered_params()
+        fp = torch.cat([p.detach().reshape(-1) for p in flow]).to(torch.float32)[None].contiguous()
         if x.dim() == 4:
             b, c, h, w = x.shape
-            rows = x.permute(0, 2, 3, 1).reshape(-1, c)
-            return self.diffeo_net(self.linear(rows)).reshape(b, h, w, c).permute(0, 3, 1, 2)
-        return self.diffeo_net(self.linear(x))
+            outs = [FL.flow_forward(fspec, fp, K.Grid.explicit(x[i].reshape(c, h * w)))[0].reshape(c, h, w) for i in range(b)]
+            return torch.stack(outs, 0)
+        return FL.flow_forward(fspec, fp, K.Grid.explicit(x.t().contiguous()))[0].t()
 
     def _specs(self):
         nf = self.diffeo_net
-        return self.convex_net.spec, FL.FlowSpec(nf.s[0].in_linear.linear.weight_v.shape[0], nf.num_coupling)
+        return self.convex_net.spec, self.diffeo_net._spec()
 
     def _ordered_params(self):
         ispec, fspec = self._specs()

@@ -15,6 +15,7 @@ backward, get_deformation, the ActNorm data-dependent init and the fused fit - r
 from __future__ import annotations
 
 import math
+import copy
 from typing import Any, Dict, Optional, Tuple
 
 import torch
@@ -23,6 +24,7 @@ import torch.nn as nn
 from .. import icnn as K
 from .. import rnvp as R
 from .convex_net import ConvexNextNet
+from .pretrainable_module import PriorFitMixin
 
 
 def _hip_only(name: str):
@@ -169,8 +171,86 @@ class _PcnFunction(torch.autograd.Function):
         return (None, None, None, None, *outs)
 
 
-class PathConnectedNet(nn.Module):
-    """convex_net(flow_net(linear(x)))  (path_connected_net.py:53-85)."""
+class PathConnectedNet(nn.Module, PriorFitMixin):
+    """convex_net(flow_net(linear(x)))  (path_connected_net.py:53-85).  `pretrain` / `pretrain_load_state`: PriorFitMixin
+    (the reference's :472-509, 730-1019 on `inrfit_pcn_fit`)."""
+
+    # -- PriorFitMixin engine (per-image fits of _prior_based_pretrain, :871-962) ---------------------------------------------
+    def _pretrain_defaults(self):
+        return dict(num_epochs=2000, lr=1e-3, flow_weight_decay=1e-5, optimizer="adamax", reuse_state=True, reuse_state_epochs=200,
+                    prefit_flow_net_identity=False, prefit_flow_net_identity_lr=1e-2, prefit_flow_net_identity_weight_decay=1e-5,
+                    prefit_flow_net_identity_num_epochs=100, prefit_convex_net=False, prefit_convex_net_lr=1e-3,
+                    prefit_convex_net_weight_decay=0.0, prefit_convex_net_num_epochs=200, proper_prior_fit_threshold=0.5,
+                    proper_prior_fit_retrys=1, zoo=None)
+
+    def _engine_pack(self, sd):
+        ispec, rspec = self._specs()
+        icnn = K.pack_state_dict(ispec, {k[len("convex_net."):]: v for k, v in sd.items() if k.startswith("convex_net.")})
+        return torch.cat([icnn.cpu(), R.pack_rnvp_state_dict(rspec, sd).cpu()])
+
+    def _engine_unpack(self, flat):
+        ispec, rspec = self._specs()
+        P = ispec.n_params
+        out = {"convex_net." + k: v for k, v in K.unpack_params(ispec, flat[:P]).items()}
+        out.update(R.unpack_rnvp_params(rspec, flat[P:]))
+        return out
+
+    def _engine_after_fit(self, sd):
+        for k in sd:
+            if k.endswith("data_dep_init_done"):
+                sd[k] = torch.ones_like(sd[k])      # ActNorm's data-dependent init has happened on this image
+
+    def _engine_fit(self, grid, unaries, flat, epochs, cold, opts, states=None):
+        from ..measures import criterion_to_desc
+        ispec, rspec = self._specs()
+        P = ispec.n_params
+        ip, fp = flat[:, :P].contiguous(), flat[:, P:].contiguous()
+        n = ip.shape[0]
+        # ActNorm initialises itself on the first batch it sees (nf.flows.ActNorm): per image, unless its state says it has
+        need = list(range(n))
+        if states is not None:
+            need = [j for j in range(n) if not all(float(v) > 0 for k, v in states[j].items() if k.endswith("data_dep_init_done"))]
+        if need:
+            sub = fp[need].contiguous()
+            g = grid if grid.coords is None or grid.coords.dim() == 2 else K.Grid.explicit(grid.coords[need].contiguous())
+            R.actnorm_init(rspec, sub, g)
+            fp[need] = sub
+        if cold and opts.get("prefit_flow_net_identity", False):
+            zoo = opts.get("zoo")
+            kw = dict(lr=float(opts.get("prefit_flow_net_identity_lr", 1e-2)),
+                      weight_decay=float(opts.get("prefit_flow_net_identity_weight_decay", 1e-5)))
+            steps = int(opts.get("prefit_flow_net_identity_num_epochs", 100))
+            if zoo is None:
+                R.fit_identity(rspec, fp, grid, steps=steps, **kw)
+            else:
+                # the reference stores the first identity fit of an (architecture, grid, hyper-parameter) combination in the zoo and
+                # LOADS it for every later image (:177-194, 246-248): all images then share that flow
+                keep = copy.deepcopy(self.state_dict())
+                self.load_flat(ip[0], fp[0])
+                for m in self.flow_net.net.network.flows:
+                    if hasattr(m, "data_dep_init_done"):
+                        m.data_dep_init_done.fill_(1.0)
+                g0 = grid if grid.coords is None or grid.coords.dim() == 2 else K.Grid.explicit(grid.coords[0].contiguous())
+                self.learn_flow_identity(g0, max_iter=steps, zoo=zoo, **kw)
+                _, _, _, flow = self._ordered_params()
+                shared = self._flat(flow).to(fp.device)[0]
+                lin = 2 * rspec.channels
+                fp[:, lin:] = shared[lin:]
+                self.load_state_dict(keep)
+        if cold and opts.get("prefit_convex_net", False):
+            xd = R.rnvp_forward(rspec, fp, grid)
+            K.fit(ispec, ip, K.Grid.explicit(xd), unaries, int(opts.get("prefit_convex_net_num_epochs", 200)),
+                  lr=float(opts.get("prefit_convex_net_lr", 1e-3)), loss="se", optimizer="adam",
+                  weight_decay=float(opts.get("prefit_convex_net_weight_decay", 0.0)), plateau=None, record_loss=False,
+                  want_logits=False)
+        crit = opts.get("criterion")
+        kind, wmode, ratio = criterion_to_desc(crit) if crit is not None else ("se", "none", 1.0)
+        res = R.pcn_fit(ispec, rspec, ip, fp, grid, unaries, epochs, lr=float(opts.get("lr", 1e-3)),
+                        optimizer=opts.get("optimizer", "adamax"), loss=kind, weight_mode=wmode, ratio=ratio,
+                        flow_weight_decay=float(opts.get("flow_weight_decay", 1e-5)),
+                        plateau=dict(patience=200, factor=0.5) if opts.get("use_plateau", True) else None,
+                        record_loss=False, want_logits=True)
+        return torch.cat([res.icnn_params, res.flow_params], 1), res.logits, res.status
 
     def __init__(self, convex_net: ConvexNextNet, flow_net: NormNet, in_channels: int = 2, **kwargs):
         super().__init__()
@@ -383,7 +463,7 @@ class PathConnectedNet(nn.Module):
                 flow_output_fn=getattr(nf, "output_fn", None), flow_output_scale=getattr(nf, "output_scale", None),
                 convex_net_hidden_units=ispec.n_hidden, convex_net_hidden_layers=ispec.n_layers).to(dev)
         prefit = {k: v for k, v in fit_kwargs.items() if k.startswith("prefit_")}
-        plain = {k: v for k, v in fit_kwargs.items() if not k.startswith("prefit_")}
+        plain = {k: v for k, v in fit_kwargs.items() if not k.startswith("prefit_") and k != "zoo"}   # pcn_fit's own kwargs only
         out_i, out_f, ious, retries = [], [], [], []
         prev = None
         for t in range(T):
@@ -396,7 +476,7 @@ class PathConnectedNet(nn.Module):
             iou = float(KK.miou(torch.sigmoid(res.logits), un)[0])
             n_retry = 0
             while iou < proper_prior_fit_threshold and n_retry < proper_prior_fit_retrys:
-                res = model_factory().fit_images(grid, un, num_epochs=num_epochs, **plain, **prefit)
+                res = model_factory().fit_images(grid, un, num_epochs=num_epochs, **plain, **prefit, zoo=fit_kwargs.get("zoo"))
                 iou = float(KK.miou(torch.sigmoid(res.logits), un)[0])
                 n_retry += 1
             if iou >= proper_prior_fit_threshold:

@@ -12,6 +12,8 @@ from typing import Any, Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
+from .pretrainable_module import PretrainableModule
+
 
 class ForwardModule(nn.Module):
     """awesome/model/forward_module.py: forwards its input (used when the unaries are given directly)."""
@@ -23,7 +25,7 @@ class ForwardModule(nn.Module):
         return fwd_input if fwd_input.dim() >= 4 else fwd_input[None]
 
 
-class WrapperModule(nn.Module):
+class WrapperModule(nn.Module, PretrainableModule):
     def __init__(self, segmentation_module: nn.Module = None, prior_module: Optional[nn.Module] = None, mode: str = "single",
                  prior_arg_mode: str = "param_clean_grid", input_mode: str = "image", use_segmentation_sigmoid: bool = True,
                  use_segmentation_output_inversion: bool = False, use_prior_sigmoid: bool = True, **kwargs):
@@ -93,3 +95,24 @@ class WrapperModule(nn.Module):
     def enforce_convexity(self) -> None:
         if self.prior_module is not None:
             self.prior_module.enforce_convexity()
+
+    # -- per-image prior state: PriorMode.PARTIAL of AbstractCombinedSegmentationModule (:108-146): the prior module's state ----
+    def extract_prior(self):
+        from ..util.prior_cache import PriorCache
+        return None if self.prior_module is None else PriorCache.extract_prior(self.prior_module)
+
+    def apply_prior(self, prior) -> None:
+        from ..util.prior_cache import PriorCache
+        if self.prior_module is not None:
+            PriorCache.apply_prior(self.prior_module, prior)
+
+    # -- the pretrain entry point TorchAgent._pretrain calls (wrapper_module.py:325-340) -----------------------------------------
+    def pretrain(self, *args, **kwargs) -> Any:
+        if not isinstance(self.prior_module, PretrainableModule):
+            raise ValueError("Prior module must be a PretrainableModule")
+        return self.prior_module.pretrain(*args, wrapper_module=self, **kwargs)
+
+    def pretrain_load_state(self, *args, **kwargs) -> None:
+        if not isinstance(self.prior_module, PretrainableModule):
+            raise ValueError("Prior module must be a PretrainableModule")
+        self.prior_module.pretrain_load_state(*args, wrapper_module=self, **kwargs)

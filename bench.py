@@ -347,7 +347,8 @@ def path_variants(dev, S, steps=300):
     m2 = ConvexNextNet(n_hidden=130, n_hidden_layers=2, in_features=2)
     p2 = m2.flat_parameters()[None].to(dev)
     out[f"ConvexNextNet_L2_{S}x{S}"] = timed(lambda n: A.fit(m2.spec, p2.clone(), grid, un, n, lr=2e-3, record_loss=False, want_logits=False))
-    cdn = ConvexDiffeomorphismNet(n_hidden=130, n_hidden_layers=2, nf_layers=6, nf_hidden=130).to(dev)
+    cdn = ConvexDiffeomorphismNet(n_hidden=130, n_hidden_layers=2, nf_layers=6, nf_hidden=130,
+                                  diffeo_args=dict(backbone="normal_block")).to(dev)   # the reference configs' form
     out[f"ConvexDiffeomorphismNet_K6_w130_L2_{S}x{S}"] = timed(lambda n: cdn.fit_images(grid, un, num_epochs=n))
     pc2 = real_nvp_path_connected_net(channels=2, hidden_units=32, flow_n_flows=12, flow_output_fn="tanh").to(dev)
     out[f"PathConnectedNet_RealNVP_C2_F12_L2_{S}x{S}"] = timed(lambda n: pc2.fit_images(grid, un, num_epochs=n))

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define INRFIT_ABI_VERSION 1
+#define INRFIT_ABI_VERSION 2
 
 enum {
     INR_OK = 0,
@@ -184,9 +184,14 @@ int inrfit_pack_masks(const float* values, int n_images, int64_t n_points, float
  *     for i in 0..K-1, for net in (s, t):  in_linear weight_v [W] | weight_g | bias [W] | out_linear weight_v [W] | weight_g | bias
  *     for i in 0..K-1 (WNScale):  weight | scale.bias | scale.weight_g | scale.weight_v
  *   FP = 6 + 2K(3W + 3) + 4K.   flow_opt_state = n_images * 2 * FP floats (exp_avg | exp_avg_sq), zero for a cold fit. */
+enum { INR_FLOW_NORMAL_BLOCK = 0, /* NormalBlock: tanh(WN2 leaky_relu(WN1 u)), keys in_linear / out_linear (diffeomorphism_net.py:169-192;
+                                     backbone 'normal_block' / 'residual_block' - every reference config) */
+       INR_FLOW_SIMPLE = 1        /* SimpleBackbone: tanh(WN2 relu(WN1 u)), keys linear1 / linear2 (:83-104; NormalizingFlow1D's
+                                     'default' backbone, i.e. what ConvexDiffeomorphismNet() builds without diffeo_args) */ };
 typedef struct InrFlowDesc {
     int32_t width;        /* W <= 256 */
     int32_t num_coupling; /* K in {2, 4, 6, 8} */
+    int32_t backbone;     /* INR_FLOW_NORMAL_BLOCK | INR_FLOW_SIMPLE: same flat parameter layout, the hidden activation differs */
 } InrFlowDesc;
 
 int64_t inrfit_flow_param_count(const InrFlowDesc* flow);
@@ -194,6 +199,11 @@ int64_t inrfit_cdn_workspace_bytes(const InrModelDesc* model, const InrFlowDesc*
 /* out_coords[n_images][2][n_points] = flow(A x + b): ConvexDiffeomorphismNet.get_deformation (:179-184). */
 int inrfit_flow_forward(const InrFlowDesc* flow, const float* flow_params, const InrGridDesc* grid, int n_images,
                         float* out_coords, void* workspace, int64_t workspace_bytes, void* stream);
+/* flow_grads[n_images][FP] = sum_p dout_coords[image][c][p] * d out_coords / d flow_params: the vector-Jacobian product of
+ * inrfit_flow_forward (autograd's backward through NormalizingFlow1D.forward o Linear, diffeomorphism_net.py:286-300; the forward
+ * is recomputed from the grid, nothing is saved).  dout_coords [n_images][2][n_points]. */
+int inrfit_flow_backward(const InrFlowDesc* flow, const float* flow_params, const InrGridDesc* grid, const float* dout_coords,
+                         int n_images, float* flow_grads, void* workspace, int64_t workspace_bytes, void* stream);
 /* logits[n_images][n_points] = ICNN(flow(A x + b)): ConvexDiffeomorphismNet.forward (:173-178). */
 int inrfit_cdn_forward(const InrModelDesc* model, const InrFlowDesc* flow, const float* icnn_params, const float* flow_params,
                        const InrGridDesc* grid, int n_images, float* logits, void* workspace, int64_t workspace_bytes,

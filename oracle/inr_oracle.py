@@ -163,6 +163,30 @@ def awesome_image_loss(output: Tensor, target: Tensor, alpha=1.0, beta=100.0, ga
     return loss
 
 
+def fbms_joint_loss(output: Tensor, target: Tensor, alpha: float = 1.0, beta: float = 1.0, clip_penalty: bool = True,
+                    kind: str = "bce", mode: str = "sssdms", ratio: float = 1.0) -> Tensor:
+    """FBMSJointLoss.__call__ (awesome/measures/fbms_joint_loss.py:35-59): output (B, 2, H, W) = [seg, prior];
+    alpha * crit(seg, target) + beta * SE_mean(prior, seg), the penalty rescaled (detached factor) to the segmentation loss
+    when it exceeds it.  Pinned by tests/golden/fbms_joint_loss.npz (both branches)."""
+    c = output.shape[1] // 2
+    seg, prior = output[:, :c], output[:, c:]
+    seg_loss = alpha * weighted_loss(seg, target, kind=kind, mode=mode, ratio=ratio)
+    pen = beta * torch.mean((seg - prior) ** 2)
+    if clip_penalty and bool(pen > seg_loss):     # the reference branches on the host exactly like this
+        pen = pen * (seg_loss / pen).detach()
+    return seg_loss + pen
+
+
+def wrapper_forward(seg_logits: Tensor, prior_logits: Tensor, invert_seg: bool = False) -> Tensor:
+    """WrapperModule.forward in image mode (awesome/model/wrapper_module.py:157-260): per batch element
+    cat([sigmoid(seg) or 1 - sigmoid(seg), sigmoid(prior)], channel).  seg_logits, prior_logits: (B, 1, H, W).
+    Pinned by tests/golden/wrapper_module.npz."""
+    seg = torch.sigmoid(seg_logits)
+    if invert_seg:
+        seg = 1 - seg
+    return torch.cat([seg, torch.sigmoid(prior_logits)], dim=1)
+
+
 # --------------------------------------------------------------------------------------
 # a17  metric
 # --------------------------------------------------------------------------------------
@@ -322,7 +346,11 @@ def wn_linear(sd: Dict[str, Tensor], prefix: str, x: Tensor) -> Tensor:
 
 
 def normal_block(sd: Dict[str, Tensor], prefix: str, x: Tensor) -> Tensor:
-    """NormalBlock.forward (awesome/model/diffeomorphism_net.py:169-192): tanh(WN2(leaky_relu(WN1 x)))."""
+    """The s / t net of a coupling, by the keys the state_dict holds:
+    NormalBlock.forward (awesome/model/diffeomorphism_net.py:169-192): tanh(WN2(leaky_relu(WN1 x))), keys in_linear / out_linear;
+    SimpleBackbone.forward (:83-104, NormalizingFlow1D's 'default' backbone): tanh(WN2(relu(WN1 x))), keys linear1 / linear2."""
+    if prefix + "linear1.linear.weight_v" in sd:
+        return torch.tanh(wn_linear(sd, prefix + "linear2.", F.relu(wn_linear(sd, prefix + "linear1.", x))))
     h = F.leaky_relu(wn_linear(sd, prefix + "in_linear.", x))
     return torch.tanh(wn_linear(sd, prefix + "out_linear.", h))
 
@@ -335,7 +363,7 @@ def wn_scale(sd: Dict[str, Tensor], prefix: str) -> Tensor:
 
 
 def flow1d_forward(sd: Dict[str, Tensor], x: Tensor, num_coupling: int, prefix: str = "") -> Tensor:
-    """NormalizingFlow1D.forward with normal_block backbones (diffeomorphism_net.py:286-300)."""
+    """NormalizingFlow1D.forward (diffeomorphism_net.py:286-300), NormalBlock or SimpleBackbone nets."""
     x1, x2 = x[:, :1], x[:, 1:]
     for i in range(num_coupling):
         if i % 2 == 0:

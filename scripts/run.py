@@ -72,6 +72,8 @@ def get_config():
     ap.add_argument("--device", type=str, default=None)
     ap.add_argument("--output-folder", type=str, default=None)
     ap.add_argument("--name-experiment", type=str, default=None)
+    ap.add_argument("--dataset-args", type=str, default=None, help="JSON dict merged into the config's dataset_args")
+    ap.add_argument("--prior-model-args", type=str, default=None, help="JSON dict merged into the config's prior_model_args")
     args = ap.parse_args()
     with open(args.config_path) as f:
         cfg = yaml.safe_load(f)
@@ -80,14 +82,31 @@ def get_config():
         v = getattr(args, k)
         if v is not None:
             cfg[k] = v
+    for k in ("dataset_args", "prior_model_args"):
+        v = getattr(args, k)
+        if v is not None:
+            cfg[k] = dict(cfg.get(k) or {}, **json.loads(v))
     return cfg
+
+
+def _fusable(criterion):
+    """The pretrain loops take SE / BCELoss / UnariesWeightedLoss of those as their `criterion` kwarg (fused in the kernels);
+    composite training losses (FBMSJointLoss, AwesomeImageLoss) belong to the joint step, not to the per-image fit."""
+    from awesome_amd.measures import criterion_to_desc
+    try:
+        criterion_to_desc(criterion)
+        return True
+    except TypeError:
+        return False
 
 
 def main(cfg):
     import torch
     import awesome_amd as A
-    from awesome_amd.fitter import BatchedPriorFitter
     from awesome_amd import parallel
+    from awesome_amd.agent import PretrainAgent
+    from awesome_amd.dataset import SyntheticPriorDataset
+    from awesome_amd.model import ForwardModule, WrapperModule
 
     rank, world, local = parallel.init()
     device = torch.device(cfg.get("device", "cuda"))
@@ -101,98 +120,153 @@ def main(cfg):
 
     model_type = dynamic_import(cfg.get("prior_model_type", "awesome_amd.model.ConvexNextNet"))
     model_args = dict(cfg.get("prior_model_args") or {})
-    dataset = dynamic_import(cfg.get("dataset_type", "awesome_amd.dataset.SyntheticUnariesDataset"))(**(cfg.get("dataset_args") or {}))
+    dataset_type = dynamic_import(cfg.get("dataset_type", "awesome_amd.dataset.SyntheticUnariesDataset"))
+    dataset_args = dict(cfg.get("dataset_args") or {})
     pre = dict((cfg.get("agent_args") or {}).get("pretrain_args") or {})
     num_epochs = int(cfg.get("num_epochs", pre.get("num_epochs", 2000)))
     criterion = build_criterion(cfg.get("loss_type"), cfg.get("loss_args"))
     opt_type = cfg.get("optimizer_type", "torch.optim.Adamax").rsplit(".", 1)[-1].lower()
     opt_args = dict(cfg.get("optimizer_args") or {})
-    mine = list(parallel.shard_range(len(dataset), rank, world))
-    size = dataset.size
-    unaries = dataset.batch(mine).to(device)
-    probe = model_type(**model_args)
-    flow_prior = hasattr(probe, "fit_images")   # ConvexDiffeomorphismNet / PathConnectedNet: ICNN behind a learned deformation
-    if hasattr(dataset, "coords"):              # (x, y, t) sequence: one network over all frames
-        grid = A.Grid.explicit(dataset.coords().to(device))
-    else:
-        grid = A.Grid.linspace(size, size, device)
-    lr = float(opt_args.get("lr", pre.get("lr", 1e-3)))
-    thr, retrys = float(pre.get("proper_prior_fit_threshold", 0.5)), int(pre.get("proper_prior_fit_retrys", 1))
+    out_dir = os.path.join(cfg.get("output_folder", "runs"), cfg.get("name_experiment", "inr_fit"))
+    if rank == 0:
+        os.makedirs(out_dir, exist_ok=True)
+    parallel.barrier()
+
+    if hasattr(dataset_type, "coords"):
+        return _run_sequence(cfg, A, parallel, rank, world, device, model_type, model_args, dataset_type(**dataset_args), pre,
+                             num_epochs, criterion, opt_type, opt_args, out_dir)
+
+    # ---- per-image priors through the reference's interface: dataset with a PriorCache -> WrapperModule -> agent._pretrain ----
+    ds = SyntheticPriorDataset(prior_model_type=model_type, prior_model_args=model_args, **dataset_args)
+    ds.__prior_cache__.key_seed = seed          # image k starts from the same parameters on 1 rank and on 8
+    mine = list(parallel.shard_range(len(ds), rank, world))
+    wrapper = WrapperModule(ForwardModule(), model_type(**model_args), use_segmentation_output_inversion=True).to(device)
+    kw = dict(pre)
+    kw["num_epochs"] = num_epochs
+    kw.setdefault("lr", float(opt_args.get("lr", 1e-3)))
+    kw.setdefault("optimizer", opt_type)
+    kw.setdefault("weight_decay", float(opt_args.get("weight_decay", 0.0)))
+    kw.setdefault("reuse_state", False)         # the synthetic images are unrelated fits (FBMS sequence configs set it true)
+    if criterion is not None and _fusable(criterion):
+        kw.setdefault("criterion", criterion)
+    if kw.get("zoo") and not hasattr(kw["zoo"], "load_model_state"):
+        from awesome_amd.model import Zoo
+        kw["zoo"] = Zoo(None if kw["zoo"] == "memory" else str(kw["zoo"]))
+    agent = PretrainAgent(ds, device=device, agent_folder=os.path.join(out_dir, f"rank{rank}"), pretrain_args=kw)
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if not flow_prior:
-        fitter = BatchedPriorFitter(lambda: model_type(**model_args), num_epochs=num_epochs, lr=lr,
-                                    optimizer=opt_type, weight_decay=float(opt_args.get("weight_decay", 0.0)), criterion=criterion,
-                                    plateau=pre.get("plateau", None if pre.get("use_plateau", True) else False),
-                                    proper_prior_fit_threshold=thr, proper_prior_fit_retrys=retrys,
-                                    reuse_state=bool(pre.get("reuse_state", False)),
-                                    reuse_state_epochs=int(pre.get("reuse_state_epochs", 200)))
-        rep = fitter.fit_batch(grid, unaries)
-        iou, retries = rep.iou, rep.retries
-        cache_state = lambda: fitter.prior_cache_state(rep, indices=mine, model_args=model_args)  # noqa: E731
-    else:
-        # _prior_based_pretrain / ConvexDiffeomorphismNet.pretrain semantics (path_connected_net.py:897-985): fit, IoU gate,
-        # reset_parameters + full refit of the images that failed it
-        from awesome_amd.measures import criterion_to_desc
-        kind, wmode, _ = criterion_to_desc(criterion) if criterion is not None else ("se", "none", 1.0)
-        kw = dict(num_epochs=num_epochs, lr=lr, loss=kind)
-        if hasattr(probe, "flow_net"):
-            kw.update(weight_mode=wmode, flow_weight_decay=float(pre.get("flow_weight_decay", 1e-5)), optimizer=opt_type)
-            kw.update({k: v for k, v in pre.items() if k.startswith("prefit_")})   # the reference's pre-fit stage kwargs
-            if pre.get("zoo"):   # pretrain_args.zoo: a folder (or "memory"): reuse the flow-identity pre-fit (path_connected_net.py:560)
-                from awesome_amd.model import Zoo
-                kw["zoo"] = Zoo(None if pre["zoo"] == "memory" else str(pre["zoo"]))
-        model = probe.to(device)
-        res = model.fit_images(grid, unaries, **kw)
-        iou = A.miou(torch.sigmoid(res.logits), unaries)
-        retries = [0] * len(mine)
-        for attempt in range(retrys):
-            bad = [i for i in range(len(mine)) if float(iou[i]) < thr]
-            if not bad:
-                break
-            # the reference calls self.reset_parameters() here (path_connected_net.py:978), which re-draws the zero-initialised
-            # output layers of a RealNVP flow and keeps its ActNorm statistics; a freshly built model is the same retry with a
-            # well-defined start (identity deformation)
-            model = model_type(**model_args).to(device)
-            sub = model.fit_images(grid, unaries[bad].contiguous(), **kw)
-            sub_iou = A.miou(torch.sigmoid(sub.logits), unaries[bad].contiguous())
-            for n, i in enumerate(bad):
-                res.icnn_params[i], res.flow_params[i], res.logits[i] = sub.icnn_params[n], sub.flow_params[n], sub.logits[n]
-                iou[i] = sub_iou[n]
-                retries[i] += 1
-
-        def cache_state():
-            from awesome_amd import flow as FL, rnvp as R
-            cache = {}
-            for n, i in enumerate(mine):
-                ispec, fspec = model._specs()
-                sd = {"convex_net." + k: v for k, v in A.unpack_params(ispec, res.icnn_params[n].cpu()).items()}
-                un = R.unpack_rnvp_params if hasattr(model, "flow_net") else FL.unpack_flow_params
-                sd.update(un(fspec, res.flow_params[n].cpu()))
-                cache[str(i)] = sd
-            return {"model_type": cfg.get("prior_model_type"), "model_args": json.dumps(model_args), "store_device": "cpu",
-                    "cache": cache}
+    report = []
+    if mine:                                    # a rank without images still joins every collective below
+        agent._pretrain(wrapper, torch.utils.data.Subset(ds, mine), None, use_progress_bar=False)
+        report = wrapper.prior_module.pretrain_report
     torch.cuda.synchronize()
     dt = parallel.max_over_ranks(time.perf_counter() - t0, device)
-    iou_all = parallel.gather_per_image(iou, len(dataset), rank, world)
-    gt_all = None
-    if hasattr(dataset, "ground_truth_batch"):   # refinement configs: score the fitted prior against the clean mask too
-        logits = rep.logits if not flow_prior else res.logits
-        if logits is not None:
-            gt = dataset.ground_truth_batch(mine).to(device)
-            gt_all = parallel.gather_per_image(A.miou(torch.sigmoid(logits), gt), len(dataset), rank, world)
-            noisy_all = parallel.gather_per_image(A.miou(unaries, gt), len(dataset), rank, world)
+
+    cache = ds.__prior_cache__
+    f32 = lambda xs: torch.tensor(xs, dtype=torch.float32, device=device).reshape(len(mine))  # noqa: E731
+    iou = f32([0.0 if r["skipped"] else r["iou"] for r in report])
+    retries = f32([r["retries"] for r in report])
+    gt_iou = noisy_iou = None
+    if hasattr(ds, "ground_truth_batch") and dataset_args.get("kind") == "noisy_blob":
+        # refinement configs: score the fitted prior (and the input labels) against the clean mask
+        prior, size = wrapper.prior_module, ds.size
+        vals, nvals = [], []
+        for k in mine:
+            prior.load_state_dict({n: v.to(device) for n, v in cache[k].items()})
+            (_, _), ((_, _, xy), _) = ds[k]
+            with torch.no_grad():
+                p = torch.sigmoid(prior(xy[None].to(device))).reshape(1, -1)
+            gt = ds.ground_truth(k).reshape(1, -1).to(device)
+            vals.append(float(A.miou(p, gt)[0]))
+            nvals.append(float(A.miou(ds.unaries(k).reshape(1, -1).to(device), gt)[0]))
+        gt_iou, noisy_iou = f32(vals), f32(nvals)
+    iou_all = parallel.gather_per_image(iou, len(ds), rank, world)
+    retries_all = parallel.gather_per_image(retries, len(ds), rank, world)
+    if gt_iou is not None:
+        gt_all = parallel.gather_per_image(gt_iou, len(ds), rank, world)
+        noisy_all = parallel.gather_per_image(noisy_iou, len(ds), rank, world)
+
+    # every rank's priors reach the saved cache: one shard file per rank, merged by rank 0 (single node, shared folder)
+    shard = os.path.join(out_dir, f"prior_cache_rank{rank}.pth")
+    cache.__cache__ = {k: v for k, v in cache.__cache__.items() if k in set(mine)}   # only what this rank fitted
+    cache.save(shard + ".tmp")
+    os.replace(shard + ".tmp", shard)
+    parallel.barrier()
     if rank == 0:
-        out_dir = os.path.join(cfg.get("output_folder", "runs"), cfg.get("name_experiment", "inr_fit"))
-        os.makedirs(out_dir, exist_ok=True)
-        torch.save(cache_state(), os.path.join(out_dir, "prior_cache_epoch_0.pth"))
-        summary = {"images": len(dataset), "ranks": world, "epochs": num_epochs, "seconds": round(dt, 4),
-                   "fits_per_s": round(len(dataset) / dt, 4), "ForegroundBinaryMIOU_vs_unaries": round(float(iou_all.mean()), 5),
-                   "retries": retries, "output": out_dir}
-        if gt_all is not None:
+        merged = None
+        for r in range(world):
+            path = os.path.join(out_dir, f"prior_cache_rank{r}.pth")
+            st = torch.load(path, map_location="cpu", weights_only=False)
+            if merged is None:
+                merged = st
+            else:
+                merged["cache"].update(st["cache"])
+            os.remove(path)
+        merged["cache"] = dict(sorted(merged["cache"].items(), key=lambda kv: int(kv[0])))
+        torch.save(merged, os.path.join(out_dir, "prior_cache_epoch_0.pth"))
+        torch.save(merged, os.path.join(out_dir, "pretrain_state.pth"))
+        summary = {"images": len(ds), "ranks": world, "epochs": num_epochs, "seconds": round(dt, 4),
+                   "fits_per_s": round(len(ds) / dt, 4), "ForegroundBinaryMIOU_vs_unaries": round(float(iou_all.mean()), 5),
+                   "retries": [int(v) for v in retries_all.tolist()], "priors_saved": len(merged["cache"]), "output": out_dir}
+        if gt_iou is not None:
             summary["ForegroundBinaryMIOU_vs_ground_truth"] = round(float(gt_all.mean()), 5)
             summary["input_labels_MIOU_vs_ground_truth"] = round(float(noisy_all.mean()), 5)
+        with open(os.path.join(out_dir, "summary.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+        print(json.dumps(summary))
+    parallel.barrier()
+
+
+def _run_sequence(cfg, A, parallel, rank, world, device, model_type, model_args, dataset, pre, num_epochs, criterion, opt_type,
+                  opt_args, out_dir):
+    """(x, y, t) sequences: ONE network over all frames of a sequence (the spatio-temporal mode, path_connected_net.py:511-728);
+    whole sequences are the unit that is sharded over the ranks."""
+    import torch
+    from awesome_amd.measures import criterion_to_desc
+    mine = list(parallel.shard_range(len(dataset), rank, world))
+    grid = A.Grid.explicit(dataset.coords().to(device))
+    lr = float(opt_args.get("lr", pre.get("lr", 1e-3)))
+    kind, wmode, _ = criterion_to_desc(criterion) if criterion is not None else ("se", "none", 1.0)
+    kw = dict(num_epochs=num_epochs, lr=lr, loss=kind, weight_mode=wmode, flow_weight_decay=float(pre.get("flow_weight_decay", 1e-5)),
+              optimizer=opt_type)
+    kw.update({k: v for k, v in pre.items() if k.startswith("prefit_")})
+    if pre.get("zoo"):
+        from awesome_amd.model import Zoo
+        kw["zoo"] = Zoo(None if pre["zoo"] == "memory" else str(pre["zoo"]))
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cache, ious = {}, []
+    for i in mine:
+        torch.manual_seed(int(cfg.get("seed", 42)) + i)
+        model = model_type(**model_args).to(device)
+        un = dataset.batch([i]).to(device)
+        res = model.fit_images(grid, un, **kw)
+        ious.append(float(A.miou(torch.sigmoid(res.logits), un)[0]))
+        model.load_flat(res.icnn_params[0], res.flow_params[0])
+        cache[str(i)] = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    torch.cuda.synchronize()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, device)
+    iou_all = parallel.gather_per_image(torch.tensor(ious, dtype=torch.float32, device=device).reshape(len(mine)), len(dataset), rank, world)
+    shard = os.path.join(out_dir, f"prior_cache_rank{rank}.pth")
+    torch.save({"model_type": cfg.get("prior_model_type"), "model_args": json.dumps(model_args, indent=4), "store_device": "cpu",
+                "cache": cache}, shard)
+    parallel.barrier()
+    if rank == 0:
+        merged = None
+        for r in range(world):
+            path = os.path.join(out_dir, f"prior_cache_rank{r}.pth")
+            st = torch.load(path, map_location="cpu", weights_only=False)
+            if merged is None:
+                merged = st
+            else:
+                merged["cache"].update(st["cache"])
+            os.remove(path)
+        torch.save(merged, os.path.join(out_dir, "prior_cache_epoch_0.pth"))
+        summary = {"images": len(dataset), "ranks": world, "epochs": num_epochs, "seconds": round(dt, 4),
+                   "fits_per_s": round(len(dataset) / dt, 4), "ForegroundBinaryMIOU_vs_unaries": round(float(iou_all.mean()), 5),
+                   "retries": [0] * len(dataset), "priors_saved": len(merged["cache"]), "output": out_dir}
         with open(os.path.join(out_dir, "summary.json"), "w") as f:
             json.dump(summary, f, indent=1)
         print(json.dumps(summary))

@@ -1,0 +1,124 @@
+"""Host-side mirrors of the reference's boundary classes against fixtures dumped from the REAL classes
+(tools/gen_golden_boundary.py): PriorCache layout, PriorManager swap, FBMSJointLoss (both clip branches), the centre-of-mass
+translate of ConvexDiffeomorphismNet, and the oracle's restatement of the same pieces.  CPU only (no kernel runs here)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import inr_oracle as O  # checker only
+
+
+def _z(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_prior_cache_state_layout_matches_reference(golden_dir):
+    from awesome_amd.dataset.prior_dataset import PriorManager
+    from awesome_amd.model import ConvexNextNet
+    from awesome_amd.util.prior_cache import PriorCache
+    z = _z(golden_dir, "prior_cache_state.npz")
+    model_args = dict(n_hidden=16, in_features=2, n_hidden_layers=1)
+    torch.manual_seed(41)   # gen_prior_cache seeds the same way (seed_all(41)); numpy / random are not consumed
+    cache = PriorCache(ConvexNextNet, model_args)
+    model = ConvexNextNet(**model_args)
+    s3, s7 = cache[3], cache[7]
+    with PriorManager(model, prior_state=(3, s3), prior_cache=cache, model_device=torch.device("cpu")):
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.25)
+    st = cache.get_state()
+    assert set(st) == {"model_type", "model_args", "store_device", "cache"}
+    assert st["model_args"] == str(z["model_args"])                     # same JSON text (indent 4)
+    assert st["store_device"] == str(z["store_device"])
+    assert str(z["model_type"]).rsplit(".", 1)[-1] == st["model_type"].rsplit(".", 1)[-1] == "ConvexNextNet"
+    assert sorted(st["cache"].keys()) == json.loads(str(z["cache_keys"]))
+    assert list(st["cache"]["3"].keys()) == json.loads(str(z["state_keys"]))
+    # same seeded construction order -> the very same generated priors, and the swap stored the modified state under key 3
+    for k in ("3", "7"):
+        for n, v in st["cache"][k].items():
+            np.testing.assert_array_equal(v.numpy(), z[f"cache.{k}.{n}"], err_msg=f"{k}.{n}")
+            assert v.dtype == torch.float32 and v.device.type == "cpu"
+    # round trip
+    c2 = PriorCache(None, None)
+    c2.set_state(st)
+    assert c2.model_args == model_args and sorted(c2.keys()) == [3, 7]
+    assert torch.equal(c2[3]["input.weight"], st["cache"]["3"]["input.weight"])
+
+
+def test_reference_prior_cache_file_roundtrip(tmp_path, golden_dir):
+    """A cache written here loads through the reference's `PriorCache.load` recipe (torch.load + set_state): plain dict of CPU
+    tensors, string keys, dotted model_type, JSON model_args."""
+    from awesome_amd.model import ConvexNextNet
+    from awesome_amd.util.prior_cache import PriorCache, dynamic_import
+    cache = PriorCache(ConvexNextNet, dict(n_hidden=16))
+    cache[5] = ConvexNextNet(n_hidden=16).state_dict()
+    f = tmp_path / "prior_cache_epoch_0.pth"
+    cache.save(str(f))
+    raw = torch.load(str(f), weights_only=False)
+    assert isinstance(raw["model_args"], str) and json.loads(raw["model_args"]) == {"n_hidden": 16}
+    assert dynamic_import(raw["model_type"]) is ConvexNextNet
+    back = PriorCache.load(str(f))
+    assert list(back.keys()) == [5] and back.model_type is ConvexNextNet
+
+
+def test_fbms_joint_loss_matches_reference(golden_dir):
+    from awesome_amd.measures import FBMSJointLoss
+    z = _z(golden_dir, "fbms_joint_loss.npz")
+    branches = []
+    for case in range(3):
+        out = torch.from_numpy(z[f"c{case}.output"]).requires_grad_(True)
+        tgt = torch.from_numpy(z[f"c{case}.target"])
+        crit = FBMSJointLoss(criterion=torch.nn.BCELoss(), alpha=1.0, beta=float(z[f"c{case}.beta"]))
+        loss = crit(out, tgt)
+        loss.backward()
+        assert float(loss) == pytest.approx(float(z[f"c{case}.loss"]), rel=1e-6)
+        np.testing.assert_allclose(out.grad.numpy(), z[f"c{case}.grad"], rtol=1e-5, atol=1e-9)
+        seg, prior = out.detach()[:, :1], out.detach()[:, 1:]
+        branches.append(bool(float(z[f"c{case}.beta"]) * ((seg - prior) ** 2).mean() > torch.nn.BCELoss()(seg, tgt)))
+        # the oracle's restatement
+        o2 = torch.from_numpy(z[f"c{case}.output"]).requires_grad_(True)
+        l2 = O.fbms_joint_loss(o2, tgt, alpha=1.0, beta=float(z[f"c{case}.beta"]), kind="bce", mode="none")
+        l2.backward()
+        assert float(l2) == pytest.approx(float(z[f"c{case}.loss"]), rel=1e-6)
+        np.testing.assert_allclose(o2.grad.numpy(), z[f"c{case}.grad"], rtol=1e-5, atol=1e-9)
+    assert True in branches and False in branches        # both sides of the penalty clip are covered
+
+
+@pytest.mark.parametrize("tag", ["l2_w130_k6", "l1_w24_k4"])
+def test_cdn_translate_matches_reference(golden_dir, tag):
+    """ConvexDiffeomorphismNet.translate_only_point (the centre-of-mass warm start): same new linear layer as the class."""
+    from awesome_amd.model.diffeomorphism_net import translate_linear, translate_only_point_args
+    z = _z(golden_dir, f"cdn_class_{tag}.npz")
+    w0, b0 = torch.from_numpy(z["sd.linear.weight"]), torch.from_numpy(z["sd.linear.bias"])
+    grid = torch.from_numpy(z["grid"])
+    pts = translate_only_point_args(torch.from_numpy(z["tr_src"]), torch.from_numpy(z["tr_dst"]), grid.squeeze(), 2)
+    w1, b1 = translate_linear(w0, b0, *pts)
+    np.testing.assert_allclose(w1.numpy(), z["sd_tr.linear.weight"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(b1.numpy(), z["sd_tr.linear.bias"], rtol=1e-5, atol=1e-6)
+    # and nothing else moved
+    for k in z.files:
+        if k.startswith("sd_tr.") and not k.startswith("sd_tr.linear."):
+            np.testing.assert_array_equal(z[k], z["sd." + k[6:]])
+
+
+@pytest.mark.parametrize("tag,k", [("l2_w130_k6", 6), ("l1_w24_k4", 4)])
+def test_oracle_cdn_forward_matches_the_class(golden_dir, tag, k):
+    """The oracle's ICNN(flow(Ax + b)) against ConvexDiffeomorphismNet.forward / get_deformation / BCE gradients of the class
+    itself (round 1 pinned it on a hand composition of the sub-modules)."""
+    z = _z(golden_dir, f"cdn_class_{tag}.npz")
+    sd = {n[3:]: torch.from_numpy(z[n]).clone().requires_grad_(True) for n in z.files if n.startswith("sd.")}
+    grid, un = torch.from_numpy(z["grid"]), torch.from_numpy(z["unaries"])
+    rows = grid[0].reshape(2, -1).t()
+    logits = O.convex_diffeo_forward(sd, rows, k)
+    np.testing.assert_allclose(logits.detach().numpy().reshape(z["logits"].shape), z["logits"], rtol=1e-5, atol=2e-6)
+    loss = torch.nn.BCELoss()(torch.sigmoid(logits).reshape(un.shape), un)
+    assert float(loss) == pytest.approx(float(z["loss"]), rel=1e-6)
+    loss.backward()
+    for n, p in sd.items():
+        ref = z["grad." + n]
+        # (weight_v of a weight-normed 1x1 layer has an analytically zero gradient: 1e-9 of rounding on both sides)
+        np.testing.assert_allclose(p.grad.numpy().reshape(ref.shape), ref, rtol=2e-4, atol=2e-6 * float(np.abs(ref).max()) + 1e-8,
+                                   err_msg=n)

@@ -83,7 +83,8 @@ def test_flow_priors_bitwise_with_poisoned_workspaces(amd, poison):
     dev = torch.device("cuda:0")
     un = (convex_blob_unaries(256, 3).reshape(256, 256)[::4, ::4] > 0.5).float().reshape(1, -1).to(dev)
     grid = amd.Grid.linspace(64, 64, dev)
-    for make in (lambda: ConvexDiffeomorphismNet(n_hidden=130, n_hidden_layers=2, nf_layers=6, nf_hidden=130),
+    for make in (lambda: ConvexDiffeomorphismNet(n_hidden=130, n_hidden_layers=2, nf_layers=6, nf_hidden=130,
+                                                 diffeo_args=dict(backbone="normal_block")),
                  lambda: real_nvp_path_connected_net(channels=2, hidden_units=32, flow_n_flows=12, flow_output_fn="tanh")):
         outs = []
         for k in range(2):

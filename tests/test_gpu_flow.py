@@ -61,7 +61,8 @@ def test_convex_diffeomorphism_net(dev, layers):
     drives the flow) against the oracle's restatement with autograd."""
     from awesome_amd.model import ConvexDiffeomorphismNet
     torch.manual_seed(11)
-    m = ConvexDiffeomorphismNet(n_hidden=130, n_hidden_layers=layers, nf_layers=6, nf_hidden=24, in_features=2)
+    m = ConvexDiffeomorphismNet(n_hidden=130, n_hidden_layers=layers, nf_layers=6, nf_hidden=24, in_features=2,
+                                diffeo_args=dict(backbone="normal_block"))
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     H, W = 12, 10
     grid = O.positional_grid(W, H)[None]
@@ -90,7 +91,8 @@ def test_convex_diffeomorphism_net(dev, layers):
 def _cdn_case(layers, width, K, h=130, seed=5):
     from awesome_amd.model import ConvexDiffeomorphismNet
     torch.manual_seed(seed)
-    m = ConvexDiffeomorphismNet(n_hidden=h, n_hidden_layers=layers, nf_layers=K, nf_hidden=width, in_features=2)
+    m = ConvexDiffeomorphismNet(n_hidden=h, n_hidden_layers=layers, nf_layers=K, nf_hidden=width, in_features=2,
+                                diffeo_args=dict(backbone="normal_block"))
     with torch.no_grad():   # move the weight_g / scale parameters off their init values so every chain-rule term is exercised
         for k, p in m.named_parameters():
             if k.endswith("weight_g") or "scale" in k:

@@ -101,6 +101,38 @@ def test_run_py_config_entrypoint(tmp_path):
     assert "0" in cache["cache"] and "skip.0.ln.weight" in cache["cache"]["0"]
 
 
+def test_run_py_two_ranks_save_every_prior(tmp_path):
+    """scripts/run.py on 2 ranks (gloo for the few bytes of collectives, both ranks on this one GPU): every image's prior - not just
+    rank 0's shard - must be in prior_cache_epoch_0.pth, with the same parameters as the 1-rank run (per-key seeding)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cfg = os.path.join(ROOT, "config", "c3_blobs512.yaml")
+    common = ["--config-path", cfg, "--num-epochs", "40", "--dataset-args", json.dumps({"n_images": 5, "size": 64})]
+    env = dict(os.environ, INRFIT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "scripts", "run.py"), *common,
+                          "--output-folder", str(tmp_path / "two")], env=env, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    s2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run.py"), *common, "--output-folder", str(tmp_path / "one")],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    s1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert s2["images"] == s1["images"] == 5 and s2["ranks"] == 2 and s2["priors_saved"] == s1["priors_saved"] == 5
+    c2 = torch.load(os.path.join(s2["output"], "prior_cache_epoch_0.pth"), weights_only=False)
+    c1 = torch.load(os.path.join(s1["output"], "prior_cache_epoch_0.pth"), weights_only=False)
+    assert sorted(c2["cache"]) == sorted(c1["cache"]) == [str(i) for i in range(5)]
+    assert not any(f.startswith("prior_cache_rank") for f in os.listdir(s2["output"]))     # the shards were merged away
+    # same initial parameters per image whatever the sharding; the fits differ only by the slab count of the batch they ran in
+    for i in range(5):
+        a, b = c1["cache"][str(i)]["out.ln.weight"], c2["cache"][str(i)]["out.ln.weight"]
+        assert torch.allclose(a, b, rtol=5e-3, atol=5e-4), i
+
+
 def test_wrapper_module_joint_step(dev):
     """WrapperModule(ForwardModule, ConvexNextNet) + AwesomeImageLoss: one joint training step like TorchAgent._perform_step
     (forward -> (B,2,H,W), criterion, backward, step, enforce_convexity) against the oracle."""

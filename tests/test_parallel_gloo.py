@@ -48,3 +48,32 @@ def test_shard_and_gather_world2(n_images):
         assert p.exitcode == 0
     assert full == [[float(i), float(i) ** 2] for i in range(n_images)]   # every image exactly once, in global order
     assert t == 2.0                                                      # max over ranks
+
+
+def test_bench_launcher_starts_the_ranks_and_relays_one_line():
+    """`python bench.py --gpus 2` with no torch.distributed environment must start 2 ranks itself (torch.distributed.run as a child,
+    before any GPU call), run every collective of the bench (barrier, MAX of the time, all_gather of the per-image metric, SUM of
+    the failure count) and relay rank 0's JSON line with the child's exit code.  On this CPU-only box the fit is replaced by
+    bench.py's labelled rehearsal stand-in (BENCH_REHEARSAL=1 + gloo): the line carries no value."""
+    import json
+    import subprocess
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_REHEARSAL="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--images-per-gpu", "3"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["rehearsal"] is True and out["value"] is None and out["n_gpus"] == 2 and out["steps"] == 2
+    assert out["gathered_image_seeds"] == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]      # rank r owns seeds r*B .. r*B+B-1, gathered in order
+    assert out["nonfinite_fits"] == 0
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", BENCH_BACKEND="gloo", BENCH_REHEARSAL="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE 2" in (r.stderr + r.stdout)

@@ -75,10 +75,14 @@ def linspace_grid(h, w):
 def gen_cdn_class(ref, out):
     """The class itself (fixture 3): forward on a (1,2,H,W) grid, BCE(sigmoid) loss gradients w.r.t. every parameter, and
     translate / translate_only_point (the centre-of-mass warm start, :43-128)."""
-    for tag, kw, hw in (("l2_w130_k6", dict(n_hidden=130, n_hidden_layers=2, nf_layers=6, nf_hidden=130), (24, 20)),
+    # the configs' form (diffeo_args: backbone normal_block, 6 couplings, width 130: config/path-connectedness/refit-unet-prior-
+    # only/*.yaml:144-148) and the class's own default (NormalizingFlow1D's 'default' backbone = SimpleBackbone)
+    for tag, kw, hw in (("l2_w130_k6", dict(n_hidden=130, n_hidden_layers=2, nf_layers=6, nf_hidden=130,
+                                            diffeo_args=dict(backbone="normal_block")), (24, 20)),
                         ("l1_w24_k4", dict(n_hidden=64, n_hidden_layers=1, nf_layers=4, nf_hidden=24), (16, 16))):
         seed_all(21)
-        m = ref.cdn.ConvexDiffeomorphismNet(**kw)
+        import copy
+        m = ref.cdn.ConvexDiffeomorphismNet(**copy.deepcopy(kw))
         grid = linspace_grid(*hw)
         un = torch.from_numpy(blob_unaries(hw[0], hw[1], 3))[None, None]
         logits = m(grid)

@@ -17,7 +17,7 @@ ap.add_argument("--images", type=int, default=1)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-m = ConvexDiffeomorphismNet(n_hidden=130, n_hidden_layers=a.layers, nf_layers=6, nf_hidden=130)
+m = ConvexDiffeomorphismNet(n_hidden=130, n_hidden_layers=a.layers, nf_layers=6, nf_hidden=130, diffeo_args=dict(backbone="normal_block"))
 ispec, fspec = A.IcnnSpec(130, 2, a.layers), FL.FlowSpec(130, 6)
 ip, fp = FL.split_cdn_state_dict(ispec, fspec, m.state_dict(), dev)
 ip, fp = ip[None].repeat(a.images, 1).contiguous(), fp[None].repeat(a.images, 1).contiguous()

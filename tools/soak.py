@@ -38,7 +38,7 @@ for L in (1, 2):
     check(f"ConvexNextNet L={L}", run)
 
 torch.manual_seed(0)
-cdn = ConvexDiffeomorphismNet(n_hidden=130, n_hidden_layers=2, nf_layers=6, nf_hidden=130).to(dev)
+cdn = ConvexDiffeomorphismNet(n_hidden=130, n_hidden_layers=2, nf_layers=6, nf_hidden=130, diffeo_args=dict(backbone="normal_block")).to(dev)
 
 
 def run_cdn():
