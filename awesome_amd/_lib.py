@@ -15,7 +15,9 @@ INR_LOSS_SE, INR_LOSS_BCE = 0, 1
 INR_WEIGHT_NONE, INR_WEIGHT_EQUAL, INR_WEIGHT_RATIO, INR_WEIGHT_SSSDMS, INR_WEIGHT_EXPLICIT = 0, 1, 2, 3, 4
 INR_OPT_ADAM, INR_OPT_ADAMAX = 0, 1
 INR_OPT_HEADER_FLOATS = 8
-INRFIT_ABI_VERSION = 2
+INRFIT_ABI_VERSION = 3
+INR_ACT_RELU, INR_ACT_COS, INR_ACT_SIN = 0, 1, 2
+ACT_KINDS = {"relu": INR_ACT_RELU, "cos": INR_ACT_COS, "sin": INR_ACT_SIN}
 INR_FLOW_NORMAL_BLOCK, INR_FLOW_SIMPLE = 0, 1
 
 INR_LOSS_EXTERNAL = 2
@@ -26,7 +28,8 @@ OPT_KINDS = {"adam": INR_OPT_ADAM, "adamax": INR_OPT_ADAMAX}
 
 
 class InrModelDesc(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("n_hidden", C.c_int32), ("in_features", C.c_int32), ("n_layers", C.c_int32)]
+    _fields_ = [("kind", C.c_int32), ("n_hidden", C.c_int32), ("in_features", C.c_int32), ("n_layers", C.c_int32),
+                ("act0", C.c_int32), ("act_omega", C.c_float)]
 
 
 class InrGridDesc(C.Structure):
@@ -53,11 +56,16 @@ class InrLossDesc(C.Structure):
                 ("c_bg", C.c_float)]
 
 
+class InrJointLossDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("weight_mode", C.c_int32), ("ratio", C.c_float), ("alpha", C.c_float), ("beta", C.c_float),
+                ("clip_penalty", C.c_int32)]
+
+
 class InrOptDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("weight_decay", C.c_float), ("clamp", C.c_int32), ("plateau", C.c_int32), ("plateau_patience", C.c_int32),
                 ("plateau_factor", C.c_float), ("plateau_threshold", C.c_float), ("plateau_min_lr", C.c_float),
-                ("plateau_eps", C.c_float), ("freeze_skips", C.c_int32)]
+                ("plateau_eps", C.c_float), ("freeze_skips", C.c_int32), ("freeze_input", C.c_int32)]
 
 
 EXPORTS = {
@@ -119,6 +127,9 @@ EXPORTS = {
     "inrfit_fit": (C.c_int, [C.POINTER(InrModelDesc), C.c_void_p, C.c_void_p, C.POINTER(InrGridDesc), C.c_void_p,
                              C.POINTER(InrLossDesc), C.POINTER(InrOptDesc), C.c_int, C.c_int, C.c_int, C.c_void_p,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_joint_loss_workspace_bytes": (C.c_int64, [C.c_int64]),
+    "inrfit_joint_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.POINTER(InrJointLossDesc), C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_int64, C.c_void_p]),
     "inrfit_miou": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_void_p,
                               C.c_void_p]),
     "inrfit_timing_begin": (C.c_int, [C.c_int]),

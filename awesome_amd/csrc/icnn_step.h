@@ -32,6 +32,23 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // become +0).  fmaxf / fmed3 cost two (hipcc first quiets a possible signalling NaN with v_max x, x), and inline asm is not an
 // option: the hazard recogniser does not insert the MFMA-write -> VALU-read wait states in front of an asm statement.
 __device__ __forceinline__ float relu0(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+// Layer-0 activation = the encode stage (include/inrfit.h INR_ACT_*).  sin / cos: one v_fract_f32 range reduction on the
+// argument in revolutions, then v_sin_f32 / v_cos_f32 (which take revolutions).
+constexpr float INV_2PI = 0.15915494309189535f;
+__device__ __forceinline__ float hw_sin(float x) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x * INV_2PI)); }
+__device__ __forceinline__ float hw_cos(float x) { return __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(x * INV_2PI)); }
+template <int ACT>
+__device__ __forceinline__ float act0_f(float pre, float omega) {
+    if constexpr (ACT == INR_ACT_COS) return hw_cos(pre);
+    else if constexpr (ACT == INR_ACT_SIN) return hw_sin(omega * pre);
+    else return relu0(pre);
+}
+template <int ACT>
+__device__ __forceinline__ float dact0_f(float pre, float omega) {   // d act / d pre
+    if constexpr (ACT == INR_ACT_COS) return -hw_sin(pre);
+    else if constexpr (ACT == INR_ACT_SIN) return omega * hw_cos(omega * pre);
+    else return pre > 0.f ? 1.f : 0.f;
+}
 // LLVM SchedGroupMask bits for __builtin_amdgcn_sched_group_barrier
 #define SG_VALU 0x2
 #define SG_MFMA 0x8
@@ -173,6 +190,7 @@ struct StepArgs {
     InrGridDesc grid;
     long long N;
     int n_images, wgs, PS, loss_kind;
+    float act_omega;       // INR_ACT_SIN kernels
 };
 
 // Cross-lane sums on the VALU (DPP / permlane swaps): no LDS round trip, no s_waitcnt.
@@ -252,9 +270,10 @@ __device__ unsigned long long g_wgtimes[1024][4];   // per workgroup, s_memrealt
 #endif
 
 // DX: additionally write dL/d(coordinates) (needed when the ICNN sits behind a learned deformation of the grid).
-template <int H, int C, bool TRAIN, bool DX = false>
+template <int H, int C, bool TRAIN, bool DX = false, int ACT0 = INR_ACT_RELU>
 __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs a) {
     static_assert(!DX || TRAIN, "coordinate gradients are a by-product of the backward pass");
+    static_assert(!DX || ACT0 == INR_ACT_RELU, "the coordinate-gradient kernels are built for relu networks only");
     using G = Cfg<H, C>;
     constexpr int TM = G::TM, KG = G::KG, HM = G::HM, HR = G::HR, S = G::S, PT = G::PT, RPW = G::RPW, NEXT = G::NEXT;
     constexpr int HRA = HR > 0 ? HR : 1;  // array extent (zero-length arrays are not allowed)
@@ -413,17 +432,26 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
         auto z0_tile = [&](int tk) -> f32x4 {
             f32x4 z = MFMA16(WinE[g * PT + 16 * tk + l15], xe, (f32x4{0.f, 0.f, 0.f, 0.f}));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z[r] = relu0(z[r]);
+            for (int r = 0; r < 4; ++r) z[r] = act0_f<ACT0>(z[r], a.act_omega);
             return z;
         };
+        f32x4 z0lpre;   // pre-activations of the last k-group (its leftover hidden units: lane group 0, k-step u)
         {
             const int q = 4 * g;
             f32x4 v = *(const f32x4*)&binT[q];
 #pragma unroll
             for (int c = 0; c < C; ++c) v += *(const f32x4*)&WinT[c * 16 + q] * x[c];
             const f32x4 fl = *(const f32x4*)&floorT[q];
+            z0lpre = v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z0[TM][r] = fmaxf(v[r], fl[r]);
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (ACT0 == INR_ACT_RELU) {
+                    z0[TM][r] = fmaxf(v[r], fl[r]);
+                } else {   // hidden leftovers: the activation; ext inputs (floor -inf): identity; unused slots stay 0 (cos(0) is not)
+                    const bool hid = g == 0 && r < HR;
+                    z0[TM][r] = hid ? act0_f<ACT0>(v[r], a.act_omega) : (fl[r] < 0.f ? v[r] : 0.f);
+                }
+            }
         }
 
         STAMP(1);
@@ -492,7 +520,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 for (int r = 0; r < G::nr_in(tk); ++r) la[u] = fmaf(wlq[cur][u][r], z0[tk][r], la[u]);
             if (tk + 1 < TM) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) z0[tk + 1][r] = relu0(zn[r]);
+                for (int r = 0; r < 4; ++r) z0[tk + 1][r] = act0_f<ACT0>(zn[r], a.act_omega);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -658,7 +686,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
 #pragma unroll
                 for (int t = 0; t < TM; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dz0[t][r] = z0p[t][r] > 0.f ? dz0[t][r] : 0.f;
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (ACT0 == INR_ACT_RELU) dz0[t][r] = z0p[t][r] > 0.f ? dz0[t][r] : 0.f;
+                        else dz0[t][r] *= dact0_f<ACT0>(z0p[t][r], a.act_omega);
+                    }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -675,7 +706,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 const float d = sum_over_groups(dz0l[u]);
                 // position HM + u lives in lane group 0, k-step u (DX needs it in every lane group)
                 const float z0u = DX ? __shfl(z0[TM][u], l15) : z0[TM][u];
-                const float dm = z0u > 0.f ? d : 0.f;
+                float dm;
+                if constexpr (ACT0 == INR_ACT_RELU) dm = z0u > 0.f ? d : 0.f;
+                else dm = d * dact0_f<ACT0>(z0lpre[u], a.act_omega);   // (used in lane group 0 only, where z0lpre[u] is unit HM + u)
                 if (DX) {
 #pragma unroll
                     for (int c = 0; c < C; ++c) hx[c] = fmaf(WinT[c * 16 + u], dm, hx[c]);

@@ -56,7 +56,7 @@ struct Cfg2 {
     static constexpr int P = P_SO + C;
 };
 
-template <int H, int C, bool TRAIN, bool DX = false>
+template <int H, int C, bool TRAIN, bool DX = false, int ACT0 = INR_ACT_RELU>
 __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArgs a) {
     static_assert(!DX || TRAIN, "coordinate gradients are a by-product of the backward pass");
     using G = Cfg2<H, C>;
@@ -365,17 +365,26 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
 #pragma unroll
             for (int t = 0; t < TM; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) z[t][r] = relu0(z[t][r]);
+                for (int r = 0; r < 4; ++r) z[t][r] = act0_f<ACT0>(z[t][r], a.act_omega);
         };
         f32x4 z0last;  // last k-group of z0ext: leftover hidden units (lane group 0) + ext inputs (lane groups 1-2)
+        f32x4 z0lpre;  // ... and its pre-activations (layer-0 activations other than relu need them in the backward pass)
         {
             const int q = 4 * g;
             f32x4 v = *(const f32x4*)&binT[q];
 #pragma unroll
             for (int c = 0; c < C; ++c) v += *(const f32x4*)&WinT[c * 16 + q] * x[c];
             const f32x4 fl = *(const f32x4*)&floorT[q];
+            z0lpre = v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z0last[r] = fmaxf(v[r], fl[r]);
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (ACT0 == INR_ACT_RELU) {
+                    z0last[r] = fmaxf(v[r], fl[r]);
+                } else {   // hidden leftovers: the activation; ext inputs (floor -inf): identity; unused slots stay 0
+                    const bool hid = g == 0 && r < HR;
+                    z0last[r] = hid ? act0_f<ACT0>(v[r], a.act_omega) : (fl[r] < 0.f ? v[r] : 0.f);
+                }
+            }
         }
         // ---- layer 1 (needs only the W1 image; the W2 re-fetch of the previous chunk may still be in flight) -------------
         f32x4 z1[KG];
@@ -505,7 +514,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
 #pragma unroll
                 for (int t = 0; t < TM; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dz0[t][r] = z0p[t][r] > 0.f ? dz0[t][r] : 0.f;
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (ACT0 == INR_ACT_RELU) dz0[t][r] = z0p[t][r] > 0.f ? dz0[t][r] : 0.f;
+                        else dz0[t][r] *= dact0_f<ACT0>(z0p[t][r], a.act_omega);
+                    }
                 // ext columns of this wave's own points: (1, x_c) by slot of k-group TM - built in registers (no stage yet)
                 float bfe[4];
 #pragma unroll
@@ -541,7 +553,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
                 for (int u = 0; u < HR; ++u) {
                     const float d = sum_over_groups(dz0l[u]);
                     const float z0u = DX ? __shfl(z0last[u], l15) : z0last[u];
-                    const float dm = z0u > 0.f ? d : 0.f;
+                    float dm;
+                    if constexpr (ACT0 == INR_ACT_RELU) dm = z0u > 0.f ? d : 0.f;
+                    else dm = d * dact0_f<ACT0>(z0lpre[u], a.act_omega);
                     if (DX) {
 #pragma unroll
                         for (int c = 0; c < C; ++c) hx[c] = fmaf(WinT[c * 16 + u], dm, hx[c]);

@@ -22,10 +22,9 @@
 //   * fp32 everywhere (exact-f32 MFMA == fmaf chain), fixed-order reductions, no atomics: results are reproducible.
 #include "icnn_step.h"
 #include "icnn_step2.h"
-#include "icnn_step8.h"
-#include "icnn_step_rw.h"
 #include "flow.h"
 #include "rnvp.h"
+#include "joint_loss.h"
 
 #include <vector>
 
@@ -54,6 +53,7 @@ struct UpdArgs {
     int mode;             // 0 = optimizer step, 1 = write reduced grads + loss only
     int clamp_lo[3], clamp_hi[3];  // flat ranges projected onto >= 0 (ln.weight of every hidden layer, out.ln.weight)
     int freeze_lo[3], freeze_hi[3];  // flat ranges that are never updated (the skip weights when opt.freeze_skips)
+    int input_hi;                    // opt.freeze_input: flat range [0, input_hi) = input.weight | input.bias is never updated
 };
 
 constexpr int UPD_MAX_PARAMS = 256;  // most parameters per block
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
         for (int k = 0; k < 3; ++k)
             if (j >= u.freeze_lo[k] && j < u.freeze_hi[k]) return;
     }
+    if (u.opt.freeze_input && j < u.input_hi) return;
 
     const float lr = lr_now;
     float p = p_old, m = m_old, v = v_old;
@@ -362,43 +363,13 @@ struct KernelEntry {
     int h, c, l;
     void (*train)(const StepArgs);
     void (*train_dx)(const StepArgs);  // also writes dL/dcoords
-    void (*train8)(const StepArgs);    // 8-wave variant (two waves per SIMD) or null
+    void (*train_act[3])(const StepArgs);   // by layer-0 activation (INR_ACT_*): [0] == train
+    void (*fwd_act[3])(const StepArgs);
     void (*fwd)(const StepArgs);
-    int lds8_bytes;                    // dynamic LDS of train8
     int lds_bytes;
     int P;
     ImgMap img;
 };
-
-// 8-wave training kernels: icnn_step_rw.h (front / back roles, INR_USE_RW) or the older experiment icnn_step8.h (INR_USE_WG8:
-// correct, but 108 us vs 73 us at 256x256 - spills at 256 regs/wave and doubled VALU issue)
-#ifndef INR_USE_WG8
-#define INR_USE_WG8 0
-#endif
-#ifndef INR_USE_RW
-#define INR_USE_RW 1
-#endif
-template <int H, int C>
-auto train8_of() -> void (*)(const StepArgs) {
-    if constexpr (INR_USE_RW && 4 * Cfg<H, C>::RPW == Cfg<H, C>::TM) return icnn_step_rw_kernel<H, C>;
-    else if constexpr (INR_USE_WG8 && Cfg<H, C>::TM == 8 && Cfg<H, C>::HR <= 2) return icnn_step8_kernel<H, C>;
-    else return nullptr;
-}
-template <int H, int C>
-constexpr int lds8_of() {
-    if constexpr (INR_USE_RW && 4 * Cfg<H, C>::RPW == Cfg<H, C>::TM) return CfgRW<H, C>::LDS_BYTES;
-    else return Cfg<H, C>::LDS_BYTES + 1024;
-}
-// The 8-wave kernel is opt-in (INRFIT_RW=1 in the environment): correct (tests/test_gpu_icnn.py runs the parity tests on it), but at
-// 16.4 us per 64-point chunk against 15.0 us for the 4-wave kernel it is not the default.
-bool use_train8() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("INRFIT_RW");
-        v = (e && e[0] == '1') ? 1 : 0;
-    }
-    return v == 1;
-}
 
 template <int H, int C>
 KernelEntry make_entry() {
@@ -410,8 +381,12 @@ KernelEntry make_entry() {
     for (int e = 0; e < 4; ++e) m.ext[e] = e < G::NEXT ? G::ext_pos(e) : 0;
     m.p_bin = G::P_BIN; m.p_w[0] = G::P_W1; m.p_b[0] = G::P_B1; m.p_s[0] = G::P_S1; m.p_wo = G::P_WO; m.p_bo = G::P_BO;
     m.p_so = G::P_SO; m.P = G::P;
-    return KernelEntry{H, C, 1, icnn_step_kernel<H, C, true>, icnn_step_kernel<H, C, true, true>, train8_of<H, C>(),
-                       icnn_step_kernel<H, C, false>, lds8_of<H, C>(), G::LDS_BYTES, G::P, m};
+    return KernelEntry{H, C, 1, icnn_step_kernel<H, C, true>, icnn_step_kernel<H, C, true, true>,
+                       {icnn_step_kernel<H, C, true>, icnn_step_kernel<H, C, true, false, INR_ACT_COS>,
+                        icnn_step_kernel<H, C, true, false, INR_ACT_SIN>},
+                       {icnn_step_kernel<H, C, false>, icnn_step_kernel<H, C, false, false, INR_ACT_COS>,
+                        icnn_step_kernel<H, C, false, false, INR_ACT_SIN>},
+                       icnn_step_kernel<H, C, false>, G::LDS_BYTES, G::P, m};
 }
 
 template <int H, int C>
@@ -425,8 +400,12 @@ KernelEntry make_entry2() {
     for (int e = 0; e < 4; ++e) m.ext[e] = e < G::NEXT ? G::ext_pos(e) : 0;
     m.p_bin = G::P_BIN; m.p_w[0] = G::P_W1; m.p_b[0] = G::P_B1; m.p_s[0] = G::P_S1; m.p_w[1] = G::P_W2; m.p_b[1] = G::P_B2;
     m.p_s[1] = G::P_S2; m.p_wo = G::P_WO; m.p_bo = G::P_BO; m.p_so = G::P_SO; m.P = G::P;
-    return KernelEntry{H, C, 2, icnn2_step_kernel<H, C, true>, icnn2_step_kernel<H, C, true, true>, nullptr,
-                       icnn2_step_kernel<H, C, false>, 0, G::LDS_BYTES, G::P, m};
+    return KernelEntry{H, C, 2, icnn2_step_kernel<H, C, true>, icnn2_step_kernel<H, C, true, true>,
+                       {icnn2_step_kernel<H, C, true>, icnn2_step_kernel<H, C, true, false, INR_ACT_COS>,
+                        icnn2_step_kernel<H, C, true, false, INR_ACT_SIN>},
+                       {icnn2_step_kernel<H, C, false>, icnn2_step_kernel<H, C, false, false, INR_ACT_COS>,
+                        icnn2_step_kernel<H, C, false, false, INR_ACT_SIN>},
+                       icnn2_step_kernel<H, C, false>, G::LDS_BYTES, G::P, m};
 }
 
 const KernelEntry kEntries[] = {
@@ -479,9 +458,11 @@ int set_lds(const KernelEntry* e) {
         return INR_ELAUNCH;
     if (hipFuncSetAttribute((const void*)e->train_dx, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes) != hipSuccess)
         return INR_ELAUNCH;
-    if (e->train8 &&
-        hipFuncSetAttribute((const void*)e->train8, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds8_bytes) != hipSuccess)
-        return INR_ELAUNCH;
+    for (int k = 1; k < 3; ++k) {
+        if (hipFuncSetAttribute((const void*)e->train_act[k], hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute((const void*)e->fwd_act[k], hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes) != hipSuccess)
+            return INR_ELAUNCH;
+    }
     return INR_OK;
 }
 
@@ -491,6 +472,8 @@ struct Workspace {
     float* slabs;
     int wgs, PS;
     long long bytes;
+    int act0 = INR_ACT_RELU;     // layer-0 activation of the model this workspace was prepared for
+    float act_omega = 0.f;
 };
 
 Workspace carve(const KernelEntry* e, long long n_points, int n_images, void* base) {
@@ -553,7 +536,7 @@ int inrfit_query(int* abi_version, int* max_hidden, int* lds_bytes) {
 #define INRFIT_BUILD_FLAGS "unknown (not built by awesome_amd/build.py)"
 #endif
 const char* inrfit_build_info(void) {
-    return "libinrfit abi " "2" "; gfx950; slab_base 256; " __VERSION__ "; flags: " INRFIT_BUILD_FLAGS;
+    return "libinrfit abi " "3" "; gfx950; slab_base 256; " __VERSION__ "; flags: " INRFIT_BUILD_FLAGS;
 }
 
 int inrfit_debug_set_slab_base(int slab_base) {
@@ -608,12 +591,10 @@ static int launch_step(const KernelEntry* e, const Workspace& w, bool train, con
     a.wgs = w.wgs;
     a.PS = w.PS;
     a.loss_kind = loss_kind;
-    if (train && !dcoords && e->train8 && use_train8()) {
-        hipLaunchKernelGGL(e->train8, dim3((unsigned)(n_images * w.wgs)), dim3(WG8_THREADS), e->lds8_bytes, s, a);
-    } else {
-        hipLaunchKernelGGL(train ? (dcoords ? e->train_dx : e->train) : e->fwd, dim3((unsigned)(n_images * w.wgs)), dim3(WG_THREADS),
-                           e->lds_bytes, s, a);
-    }
+    a.act_omega = w.act_omega;
+    if (dcoords && w.act0 != INR_ACT_RELU) return INR_EUNSUPPORTED;   // coordinate gradients: relu networks only
+    hipLaunchKernelGGL(train ? (dcoords ? e->train_dx : e->train_act[w.act0]) : e->fwd_act[w.act0], dim3((unsigned)(n_images * w.wgs)),
+                       dim3(WG_THREADS), e->lds_bytes, s, a);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 
@@ -681,6 +662,7 @@ static UpdArgs make_upd_args(const KernelEntry* e, const Workspace& w, float* pa
     }
     u.freeze_lo[2] = e->img.p_so;
     u.freeze_hi[2] = e->img.p_so + e->img.C;
+    u.input_hi = e->img.p_w[0];
     return u;
 }
 
@@ -694,6 +676,9 @@ static int prepare(const InrModelDesc* model, const InrGridDesc* grid, int n_ima
     if (rc) return rc;
     *w_out = carve(e, grid->n_points, n_images, workspace);
     if (workspace_bytes < w_out->bytes) return INR_EWORKSPACE;
+    if (model->act0 < INR_ACT_RELU || model->act0 > INR_ACT_SIN) return INR_EINVAL;
+    w_out->act0 = model->act0;
+    w_out->act_omega = model->act_omega;
     if ((rc = set_lds(e))) return rc;
     *e_out = e;
     return INR_OK;
@@ -1598,6 +1583,36 @@ int inrfit_pcn_fit(const InrModelDesc* model, const InrRnvpDesc* rnvp, float* ic
         return launch_step(e, w.icnn, false, &w.dgrid, nullptr, 0, n_images, final_logits, s);
     }
     return INR_OK;
+}
+
+int64_t inrfit_joint_loss_workspace_bytes(int64_t n_elems) {
+    if (n_elems <= 0) return INR_EINVAL;
+    return (int64_t)(JL_MAX_BLOCKS * 4 + 8) * 4;
+}
+
+int inrfit_joint_loss(const float* output, const float* target, int batch, int64_t hw, const InrJointLossDesc* desc,
+                      float* loss_out, float* doutput, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!output || !target || !desc || !loss_out || !workspace || batch <= 0 || hw <= 0) return INR_EINVAL;
+    if (desc->kind != INR_LOSS_SE && desc->kind != INR_LOSS_BCE) return INR_EINVAL;
+    if (desc->weight_mode < INR_WEIGHT_NONE || desc->weight_mode > INR_WEIGHT_SSSDMS) return INR_EINVAL;
+    if (workspace_bytes < inrfit_joint_loss_workspace_bytes((int64_t)batch * hw)) return INR_EWORKSPACE;
+    JointLossArgs a{};
+    a.output = output;
+    a.target = target;
+    a.doutput = doutput;
+    a.part = (float*)workspace;
+    a.res = a.part + JL_MAX_BLOCKS * 4;
+    a.hw = hw;
+    a.n = (long long)batch * hw;
+    const long long want = (a.n + 1023) / 1024;   // >= 4 pixels per thread
+    a.blocks = (int)(want < 1 ? 1 : (want > JL_MAX_BLOCKS ? JL_MAX_BLOCKS : want));
+    a.d = *desc;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(joint_loss_partial_kernel, dim3(a.blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(joint_loss_finish_kernel, dim3(1), dim3(256), 0, s, a);
+    if (doutput) hipLaunchKernelGGL(joint_loss_grad_kernel, dim3(a.blocks), dim3(256), 0, s, a);
+    if (hipMemcpyAsync(loss_out, a.res, 4 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return INR_ELAUNCH;
+    return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 
 int inrfit_miou(const float* out, const float* tgt, int n_images, int64_t n_points, float thr_out, float thr_tgt, int invert,

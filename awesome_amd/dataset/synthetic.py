@@ -94,7 +94,15 @@ class SyntheticPriorDataset(PriorDataset):
     def __init__(self, n_images: int = 1, size: int = 256, kind: str = "blob", seed0: int = 0, prior_model_type=None,
                  prior_model_args=None, **kwargs):
         super().__init__(prior_model_type=prior_model_type, prior_model_args=prior_model_args)
-        self._inner = SyntheticUnariesDataset(n_images=n_images, size=size, kind=kind, seed0=seed0)
+        self.kind = kind
+        if kind == "sequence":
+            masks = dumbbell_sequence_masks(int(size), int(n_images), int(seed0))
+            frames = [torch.from_numpy(1.0 - m.astype(np.float32)) for m in masks]
+            self._inner = SyntheticUnariesDataset(n_images=n_images, size=size, kind="blob", seed0=seed0)
+            self._inner.unaries = lambda i: frames[int(i)]
+            self._inner.ground_truth = lambda i: frames[int(i)]
+        else:
+            self._inner = SyntheticUnariesDataset(n_images=n_images, size=size, kind=kind, seed0=seed0)
         self.size = int(size)
         xs = torch.linspace(0, 1, self.size)
         self._xy = torch.stack([xs[None, :].expand(self.size, self.size), xs[:, None].expand(self.size, self.size)], 0).contiguous()
@@ -117,7 +125,11 @@ class SyntheticPriorDataset(PriorDataset):
         fg_prob = 1.0 - un                                   # probability of "object" = what sigmoid(seg logits) is
         image = torch.log(fg_prob / (1.0 - fg_prob))[None]   # logits; sigmoid(image) = fg_prob
         target = (self._inner.ground_truth(int(i)) > 0.5).float()[None]
-        return (image, torch.zeros(1, 1, 1), self._xy), target
+        xy = self._xy
+        if self.kind == "sequence":
+            t = float(i) / float(max(len(self) - 1, 1))
+            xy = torch.cat([xy, torch.full((1, self.size, self.size), t)], 0)
+        return (image, torch.zeros(1, 1, 1), xy), target
 
 
 class SyntheticUnariesDataset:

@@ -133,15 +133,66 @@ class AwesomeLoss:
         return self.name or type(self).__name__
 
 
+class _FusedJointLoss(torch.autograd.Function):
+    """FBMSJointLoss value + gradient in three HIP launches (inrfit_joint_loss), no host sync."""
+
+    @staticmethod
+    def forward(ctx, output: torch.Tensor, target: torch.Tensor, desc):
+        import ctypes as C
+        from .. import _lib as L
+        out = output.detach().contiguous().to(torch.float32)
+        b, c2 = out.shape[0], out.shape[1]
+        hw = out.numel() // (b * c2)
+        tgt = target.detach().contiguous().to(torch.float32)
+        lib = L.load()
+        nbytes = int(lib.inrfit_joint_loss_workspace_bytes(b * hw))
+        ws = L.scratch(nbytes // 4 + 1, dtype=torch.float32, device=out.device)
+        res = L.scratch(4, dtype=torch.float32, device=out.device)
+        dout = L.scratch_like(out)
+        rc = lib.inrfit_joint_loss(out.data_ptr(), tgt.data_ptr(), b, hw, C.byref(desc), res.data_ptr(), dout.data_ptr(), ws.data_ptr(),
+                                   ws.numel() * 4, K._stream_ptr(out.device))
+        L.check(rc, "inrfit_joint_loss")
+        ctx.save_for_backward(dout)
+        ctx.terms = res
+        return res[0].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (dout,) = ctx.saved_tensors
+        return dout * grad_out, None, None
+
+
 class FBMSJointLoss:
-    """awesome/measures/fbms_joint_loss.py:35-59: alpha*crit(seg,t) + clip(beta*SE(prior, seg))."""
+    """awesome/measures/fbms_joint_loss.py:35-59: alpha*crit(seg,t) + clip(beta*SE(prior, seg)).
+
+    On CUDA tensors with a criterion the kernels know (BCELoss / SE, optionally inside UnariesWeightedLoss) and the default SE
+    'mean' penalty it runs as the fused HIP loss `inrfit_joint_loss` (value and gradient, the clip decided on the device);
+    any other criterion is composed from torch ops on whatever device the tensors live on."""
 
     def __init__(self, criterion=None, penalty_criterion=None, alpha=1.0, beta=1.0, clip_penalty=True, name=None, **kwargs):
         self.criterion = criterion or UnariesWeightedLoss(torch.nn.BCELoss(), mode="sssdms")
         self.penalty_criterion = penalty_criterion or SE("mean")
         self.alpha, self.beta, self.clip_penalty, self.name = alpha, beta, clip_penalty, name
 
+    def _fused_desc(self, output: torch.Tensor):
+        from .. import _lib as L
+        if not output.is_cuda or output.dim() != 4 or output.shape[1] != 2:
+            return None
+        if not (isinstance(self.penalty_criterion, SE) and self.penalty_criterion.reduction == "mean"):
+            return None
+        if isinstance(self.criterion, UnariesWeightedLoss) and self.criterion.reduction != "mean":
+            return None
+        try:
+            kind, mode, ratio = criterion_to_desc(self.criterion)
+        except TypeError:
+            return None
+        return L.InrJointLossDesc(L.LOSS_KINDS[kind], L.WEIGHT_MODES[mode], float(ratio), float(self.alpha), float(self.beta),
+                                  int(bool(self.clip_penalty)))
+
     def __call__(self, output: torch.Tensor, target: torch.Tensor, **kwargs) -> torch.Tensor:
+        desc = self._fused_desc(output)
+        if desc is not None:
+            return _FusedJointLoss.apply(output, target, desc)
         c = output.shape[1] // 2
         seg, prior = output[:, :c], output[:, c:]
         seg_loss = self.alpha * self.criterion(seg, target)

@@ -13,16 +13,38 @@ import torch
 import torch.nn as nn
 
 from .. import icnn as K
-from .convex_net import _IcnnFunction
+from .convex_net import _IcnnFunction, _IcnnModule
+from .pretrainable_module import PriorFitMixin
 
 
 def linear_relu(width: int) -> nn.Sequential:
     return nn.Sequential(nn.Linear(width, width), nn.ReLU())
 
 
-class FCNet(nn.Module):
+class FCNet(nn.Module, PriorFitMixin):
     #: options the fitters pass to `awesome_amd.fit` for this model (BatchedPriorFitter reads them)
     fit_options = dict(clamp=False, freeze_skips=True)
+
+    # -- PriorFitMixin engine (the same per-image loop as the ICNN priors, on this module's own key layout) -------------------
+    _pretrain_defaults = _IcnnModule._pretrain_defaults
+    _engine_fit = _IcnnModule._engine_fit
+
+    def _engine_pack(self, sd):
+        keep = {k: v.detach().clone() for k, v in self.state_dict().items()}
+        self.load_state_dict({k: v.to(self.model[0].weight.device) for k, v in sd.items()})
+        flat = self.flat_parameters().cpu()
+        self.load_state_dict(keep)
+        return flat
+
+    def _engine_unpack(self, flat):
+        return self.unpack_flat(flat)
+
+    def reset_parameters(self) -> None:
+        for lin in self._linears():
+            lin.reset_parameters()
+
+    def enforce_convexity(self) -> None:   # nothing is constrained in the "no prior" network
+        return None
 
     def __init__(self, in_chn: int = 2, out_chn: int = 1, width: int = 130, depth: int = 1, in_type: str = "xy", **kwargs):
         super().__init__()

@@ -252,6 +252,61 @@ class PathConnectedNet(nn.Module, PriorFitMixin):
                         record_loss=False, want_logits=True)
         return torch.cat([res.icnn_params, res.flow_params], 1), res.logits, res.status
 
+    def _non_prior_based_pretrain(self, train_set, test_set, device, agent, use_progress_bar: bool = True,
+                                  wrapper_module=None, **kwargs):
+        """Spatio-temporal pretraining (path_connected_net.py:511-728): the data set has no per-image priors - ONE network
+        is fitted to all frames, whose clean grids carry t / t_max as a third channel.  Unaries of every frame from the
+        segmentation module (prior off), optional pre-fits (flow towards the identity on the frames' grid, convex net on the
+        deformed grid), then `num_epochs` epochs of mini-batches of `batch_size` frames (fit_sequence).  Returns
+        self.state_dict() like the reference (:721)."""
+        if wrapper_module is None:
+            raise ValueError("Wrapper model must be provided for pretraining.")
+        from .pretrainable_module import decompose_training_item
+        opts = dict(self._pretrain_defaults(), batch_size=1, dataloader_shuffle=False)
+        opts.update(kwargs)
+        ds = agent.training_dataset
+        device = torch.device(device)
+        was, training_state = getattr(wrapper_module, "evaluate_prior", True), wrapper_module.training
+        coords, unaries = [], []
+        try:
+            wrapper_module.eval()
+            wrapper_module.evaluate_prior = False
+            for pos in range(len(train_set)):
+                inputs, _, _, _ = decompose_training_item(train_set[pos], ds)
+                dev_in = [t.to(device)[None] if isinstance(t, torch.Tensor) else t for t in inputs]
+                with torch.no_grad():
+                    un = wrapper_module(*dev_in)
+                    pargs, _ = wrapper_module.get_prior_args(dev_in[0], *dev_in[1:], segm=un[0, ...])
+                g = pargs[0] if pargs[0].dim() == 4 else pargs[0][None]
+                coords.append(g[0].reshape(g.shape[1], -1).to(torch.float32))
+                unaries.append(un.reshape(-1).to(torch.float32))
+        finally:
+            wrapper_module.evaluate_prior = was
+            wrapper_module.train(training_state)
+        frame_coords, frame_unaries = torch.stack(coords), torch.stack(unaries)          # (T, C, HW), (T, HW)
+        T = frame_coords.shape[0]
+        whole = K.Grid.explicit(frame_coords.permute(1, 0, 2).reshape(frame_coords.shape[1], -1).contiguous())
+        if opts.get("prefit_flow_net_identity", False):
+            self.learn_flow_identity(whole, lr=float(opts["prefit_flow_net_identity_lr"]),
+                                     weight_decay=float(opts["prefit_flow_net_identity_weight_decay"]),
+                                     max_iter=int(opts["prefit_flow_net_identity_num_epochs"]), zoo=opts.get("zoo"))
+        if opts.get("prefit_convex_net", False):
+            self.learn_convex_net(whole, frame_unaries.reshape(1, -1), lr=float(opts["prefit_convex_net_lr"]),
+                                  weight_decay=float(opts["prefit_convex_net_weight_decay"]),
+                                  max_iter=int(opts["prefit_convex_net_num_epochs"]))
+        from ..measures import criterion_to_desc
+        crit = opts.get("criterion")
+        kind, wmode, _ = criterion_to_desc(crit) if crit is not None else ("se", "none", 1.0)
+        self.pretrain_epoch_losses = self.fit_sequence(frame_coords, frame_unaries, num_epochs=int(opts["num_epochs"]),
+                                                       lr=float(opts["lr"]), flow_weight_decay=float(opts["flow_weight_decay"]),
+                                                       batch_size=min(int(opts["batch_size"]), T),
+                                                       dataloader_shuffle=bool(opts["dataloader_shuffle"]), loss=kind,
+                                                       weight_mode=wmode, optimizer=opts.get("optimizer", "adamax"))
+        for m in self.flow_net.net.network.flows:
+            if hasattr(m, "data_dep_init_done"):
+                m.data_dep_init_done.fill_(1.0)
+        return self.state_dict()
+
     def __init__(self, convex_net: ConvexNextNet, flow_net: NormNet, in_channels: int = 2, **kwargs):
         super().__init__()
         self.convex_net = convex_net

@@ -25,6 +25,23 @@ class ForwardModule(nn.Module):
         return fwd_input if fwd_input.dim() >= 4 else fwd_input[None]
 
 
+class ConvSegStandIn(nn.Module):
+    """A trainable stand-in for the segmentation backbone in the synthetic refinement configs (BASELINE configs[4]): one 3x3
+    convolution over the (noisy) logit image, initialised to the identity.  The reference's backbones (UNet / CNNNet) are out
+    of scope of the HIP path and plug in unchanged - anything that maps (image, *extra) -> logits does."""
+
+    def __init__(self, channels: int = 1, kernel_size: int = 3, **kwargs):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, 1, kernel_size, padding=kernel_size // 2)
+        with torch.no_grad():
+            self.conv.weight.zero_()
+            self.conv.weight[:, 0, kernel_size // 2, kernel_size // 2] = 1.0
+            self.conv.bias.zero_()
+
+    def forward(self, image: torch.Tensor, *args, **kwargs) -> torch.Tensor:
+        return self.conv(image if image.dim() == 4 else image[None])
+
+
 class WrapperModule(nn.Module, PretrainableModule):
     def __init__(self, segmentation_module: nn.Module = None, prior_module: Optional[nn.Module] = None, mode: str = "single",
                  prior_arg_mode: str = "param_clean_grid", input_mode: str = "image", use_segmentation_sigmoid: bool = True,

@@ -56,7 +56,7 @@ class Zoo:
             return e["state_dict"], e["context"]
         p = self._path(h)
         if p is not None and os.path.isfile(p):
-            e = torch.load(p, map_location="cpu", weights_only=False)
+            e = torch.load(p, map_location="cpu", weights_only=True)   # tensors, strings, numbers only: nothing is unpickled
             self._mem[h] = e
             return e["state_dict"], e["context"]
         return None, None
@@ -77,4 +77,7 @@ class Zoo:
         self._mem[h] = e
         p = self._path(h)
         if p is not None:
-            torch.save(e, p)
+            # ranks of one job can reach the same entry at once: write to a private temp file, then rename (atomic on POSIX)
+            tmp = f"{p}.{os.getpid()}.tmp"
+            torch.save(e, tmp)
+            os.replace(tmp, p)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define INRFIT_ABI_VERSION 2
+#define INRFIT_ABI_VERSION 3
 
 enum {
     INR_OK = 0,
@@ -49,12 +49,25 @@ enum { INR_WEIGHT_NONE = 0, INR_WEIGHT_EQUAL = 1, INR_WEIGHT_RATIO = 2, INR_WEIG
 enum { INR_OPT_ADAM = 0, INR_OPT_ADAMAX = 1 };
 enum { INR_STATUS_OK = 0, INR_STATUS_NONFINITE = 1 };
 
+/* Activation of layer 0 = the ENCODE stage of the coordinate network (the hidden skip layers are always relu):
+ *   INR_ACT_RELU  z0 = relu(W_in x + b_in)                  the packaged models (convex_net.py:205-214; FCNet)
+ *   INR_ACT_COS   z0 = cos(W_in x + b_in)                   random Fourier features cos(x @ A + b) with W_in = A^T, b_in = b
+ *                                                           frozen (InrOptDesc.freeze_input) - notebooks/imageRepresentationTest.ipynb
+ *                                                           cell 5, `ourSimpleNetwork` (features -> relu layers -> sigmoid)
+ *   INR_ACT_SIN   z0 = sin(act_omega (W_in x + b_in))       learnable sine layer, act_omega = 10 pi in
+ *                                                           notebooks/icml_teaser_code/repeating/repeating.ipynb cell 3 (`myNet`)
+ * Evaluated in registers where relu is (the D tile of the layer-0 MFMA); sin / cos are v_sin_f32 / v_cos_f32 after a v_fract_f32
+ * range reduction (|argument| <~ 1e3: absolute error <~ 1e-5).  The coordinate-gradient (DX) kernels exist for relu only. */
+enum { INR_ACT_RELU = 0, INR_ACT_COS = 1, INR_ACT_SIN = 2 };
+
 /* awesome/model/convex_net.py:177-203 constructor arguments (n_hidden, in_features, n_hidden_layers). */
 typedef struct InrModelDesc {
     int32_t kind;        /* INR_MODEL_ICNN */
     int32_t n_hidden;    /* h */
     int32_t in_features; /* C: 2 (x,y) or 3 (x,y,t) */
     int32_t n_layers;    /* L hidden skip layers (ConvexNet: 1) */
+    int32_t act0;        /* INR_ACT_* (0 = relu: a zero-initialised tail keeps old callers' meaning) */
+    float act_omega;     /* INR_ACT_SIN only */
 } InrModelDesc;
 
 /* The dense coordinate grid every image is evaluated on.
@@ -101,6 +114,8 @@ typedef struct InrOptDesc {
     int32_t freeze_skips; /* 1: no skp.weight (incl. out.skp) is ever updated.  With zero skips and clamp = 0 the ICNN is the plain
                              relu MLP Linear(C,h) [Linear(h,h)]xL Linear(h,1) = FCNet(in_type='xy') (awesome/model/fc_net.py:10-59),
                              the "no prior" coordinate network of configs[0]. */
+    int32_t freeze_input; /* 1: input.weight / input.bias are never updated: fixed random Fourier features (buffers A, b of
+                             `ourSimpleNetwork`, imageRepresentationTest.ipynb cell 5). */
 } InrOptDesc;
 
 /* Per-image optimizer state, `opt_state` = n_images * inrfit_opt_state_floats(model) floats:
@@ -282,6 +297,25 @@ int inrfit_pcn_fit(const InrModelDesc* model, const InrRnvpDesc* rnvp, float* ic
                    const InrLossDesc* loss, const InrOptDesc* opt, float flow_weight_decay, int n_images, int steps, int step0,
                    float* loss_hist, float* final_logits, int32_t* status, void* workspace, int64_t workspace_bytes,
                    void* stream);
+
+/* ---- joint segmentation + prior training step: FBMSJointLoss (awesome/measures/fbms_joint_loss.py:35-59) on the device.
+ * output [batch][2][hw] = [seg, prior] probabilities (the WrapperModule's output, image mode), target [batch][hw]:
+ *     loss = alpha * mean(w (.) crit(seg, target)) + clip(beta * mean((seg - prior)^2))
+ * crit = kind (INR_LOSS_SE | INR_LOSS_BCE = torch.nn.BCELoss), w = UnariesWeightedLoss weights by weight_mode / ratio with the
+ * fg/bg counts taken over the whole batch (unaries_weighted_loss.py:35-69), clip: the penalty is rescaled to the segmentation
+ * loss when it exceeds it (factor detached).  The reference takes that decision on the host - one sync per training step; here
+ * nothing leaves the device.  loss_out [4] (device): loss, mean weighted crit (before alpha), mean penalty (before beta), the
+ * clip factor.  doutput (optional) [batch][2][hw]: d loss / d output, BOTH channels (the penalty pulls seg and prior together). */
+typedef struct InrJointLossDesc {
+    int32_t kind;
+    int32_t weight_mode;
+    float ratio;
+    float alpha, beta;
+    int32_t clip_penalty;
+} InrJointLossDesc;
+int64_t inrfit_joint_loss_workspace_bytes(int64_t n_elems);
+int inrfit_joint_loss(const float* output, const float* target, int batch, int64_t hw, const InrJointLossDesc* desc,
+                      float* loss_out, float* doutput, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Measurement hook (bench.py, rocprof): launch ONLY the fused forward+loss+backward step kernel `iters` times
  * back-to-back on `stream` (no optimizer step), so its average duration can be bracketed with events. */

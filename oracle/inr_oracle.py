@@ -86,19 +86,49 @@ def icnn_num_layers(p: Dict[str, Tensor]) -> int:
     return sum(1 for k in p if k.startswith("skip.") and k.endswith(".ln.weight"))
 
 
-def icnn_forward(p: Dict[str, Tensor], x: Tensor) -> Tensor:
-    """ConvexNextNet.forward (convex_net.py:205-214) on (N,C) rows -> (N,1) logits."""
+def encode_layer(pre: Tensor, act0: str = "relu", omega: float = 1.0) -> Tensor:
+    """Layer 0's activation = the encode stage: relu (the packaged models), cos (random Fourier features cos(x @ A + b),
+    notebooks/imageRepresentationTest.ipynb cell 5) or sin(omega .) (the sine layer sin(10 pi W1(x + offset)),
+    notebooks/icml_teaser_code/repeating/repeating.ipynb cell 3).  Pinned by tests/golden/encode_notebooks.npz (the two cells'
+    own classes executed in the build container)."""
+    if act0 == "relu":
+        return F.relu(pre)
+    if act0 == "cos":
+        return torch.cos(pre)
+    if act0 == "sin":
+        return torch.sin(omega * pre)
+    raise ValueError(act0)
+
+
+def fourier_mlp_forward(sd: Dict[str, Tensor], x: Tensor) -> Tensor:
+    """`ourSimpleNetwork.forward` (imageRepresentationTest.ipynb cell 5) restated: cos(x @ A + b) -> relu(fc1) -> relu(fc2) ->
+    relu(fc3) -> sigmoid(fc4), any number of fcK layers (the last one is the output layer)."""
+    z = torch.cos(x @ sd["A"] + sd["b"])
+    n = sum(1 for k in sd if k.startswith("fc") and k.endswith(".weight"))
+    for k in range(1, n):
+        z = F.relu(F.linear(z, sd[f"fc{k}.weight"], sd[f"fc{k}.bias"]))
+    return torch.sigmoid(F.linear(z, sd[f"fc{n}.weight"], sd[f"fc{n}.bias"]))
+
+
+def sine_net_forward(sd: Dict[str, Tensor], x: Tensor) -> Tensor:
+    """`myNet.forward` (repeating.ipynb cell 3) restated: W2(sin(10 * 3.141592 * W1(x + offset)))."""
+    z = 10 * 3.141592 * F.linear(x + sd["offset"], sd["W1.weight"], sd["W1.bias"])
+    return F.linear(torch.sin(z), sd["W2.weight"], sd["W2.bias"])
+
+
+def icnn_forward(p: Dict[str, Tensor], x: Tensor, act0: str = "relu", omega: float = 1.0) -> Tensor:
+    """ConvexNextNet.forward (convex_net.py:205-214) on (N,C) rows -> (N,1) logits; `act0`: layer 0's activation (encode_layer)."""
     x_in = x
-    z = F.relu(F.linear(x_in, p["input.weight"], p["input.bias"]))
+    z = encode_layer(F.linear(x_in, p["input.weight"], p["input.bias"]), act0, omega)
     for k in range(icnn_num_layers(p)):
         z = F.relu(F.linear(z, p[f"skip.{k}.ln.weight"], p[f"skip.{k}.ln.bias"]) + F.linear(x_in, p[f"skip.{k}.skp.weight"]))
     return F.linear(z, p["out.ln.weight"], p["out.ln.bias"]) + F.linear(x_in, p["out.skp.weight"])
 
 
-def icnn_forward_image(p: Dict[str, Tensor], grid: Tensor) -> Tensor:
+def icnn_forward_image(p: Dict[str, Tensor], grid: Tensor, act0: str = "relu", omega: float = 1.0) -> Tensor:
     """@pixelize wrapper: (B,C,H,W) -> (B,1,H,W)."""
     b, c, h, w = grid.shape
-    return unpixelize(icnn_forward(p, pixelize(grid)), b, h, w)
+    return unpixelize(icnn_forward(p, pixelize(grid), act0, omega), b, h, w)
 
 
 def icnn_clamp_keys(p: Dict[str, Tensor]) -> List[str]:

@@ -32,6 +32,10 @@ ALIASES = {
     "awesome.model.fc_net.FCNet": "awesome_amd.model.FCNet",
     "awesome.measures.se.SE": "awesome_amd.measures.SE",
     "awesome.measures.unaries_weighted_loss.UnariesWeightedLoss": "awesome_amd.measures.UnariesWeightedLoss",
+    "awesome.measures.fbms_joint_loss.FBMSJointLoss": "awesome_amd.measures.FBMSJointLoss",
+    "awesome.measures.awesome_image_loss.AwesomeImageLoss": "awesome_amd.measures.AwesomeImageLoss",
+    "awesome.model.forward_module.ForwardModule": "awesome_amd.model.ForwardModule",
+    "awesome.model.wrapper_module.WrapperModule": "awesome_amd.model.WrapperModule",
 }
 
 
@@ -74,6 +78,7 @@ def get_config():
     ap.add_argument("--name-experiment", type=str, default=None)
     ap.add_argument("--dataset-args", type=str, default=None, help="JSON dict merged into the config's dataset_args")
     ap.add_argument("--prior-model-args", type=str, default=None, help="JSON dict merged into the config's prior_model_args")
+    ap.add_argument("--override", type=str, default=None, help="JSON dict deep-merged into the whole config (e.g. agent_args)")
     args = ap.parse_args()
     with open(args.config_path) as f:
         cfg = yaml.safe_load(f)
@@ -86,6 +91,15 @@ def get_config():
         v = getattr(args, k)
         if v is not None:
             cfg[k] = dict(cfg.get(k) or {}, **json.loads(v))
+
+    def deep_merge(dst, src):
+        for k, v in src.items():
+            if isinstance(v, dict) and isinstance(dst.get(k), dict):
+                deep_merge(dst[k], v)
+            else:
+                dst[k] = v
+    if args.override:
+        deep_merge(cfg, json.loads(args.override))
     return cfg
 
 
@@ -160,6 +174,37 @@ def main(cfg):
     if mine:                                    # a rank without images still joins every collective below
         agent._pretrain(wrapper, torch.utils.data.Subset(ds, mine), None, use_progress_bar=False)
         report = wrapper.prior_module.pretrain_report
+    # ---- joint training epochs (TorchAgent._perform_step, torch_agent.py:428-551): segmentation module + per-image priors +
+    # the composite loss (FBMSJointLoss / AwesomeImageLoss), the priors resident on the device in a PriorBank.  Each rank trains
+    # its own copy of the segmentation stand-in on its shard (sharing a backbone over ranks is ordinary DDP, out of scope §8e).
+    joint_epochs = int((cfg.get("agent_args") or {}).get("joint_epochs", 0))
+    joint_losses = []
+    if joint_epochs > 0 and mine and criterion is not None and not _fusable(criterion):
+        from awesome_amd.agent import JointTrainer
+        from awesome_amd.prior_bank import PriorBank
+        seg_type = dynamic_import(cfg.get("segmentation_model_type", "awesome_amd.model.ConvSegStandIn"))
+        seg = seg_type(**dict(cfg.get("segmentation_model_args") or {})).to(device)
+        prior = wrapper.prior_module
+        jw = WrapperModule(seg, prior, use_segmentation_output_inversion=True).to(device)
+        bank = PriorBank(lambda: model_type(**model_args).to(device), n_images=len(mine), device=device, keys=mine)
+        cache0 = ds.__prior_cache__
+        for k in mine:
+            prior.load_state_dict({n: v.to(device) for n, v in cache0[k].items()})
+            bank.row(k).copy_(torch.cat([p.detach().reshape(-1) for p in bank_params(prior)]))
+        params = [p for p in seg.parameters()] + bank_params(prior)
+        opt = torch.optim.Adam(params, lr=float(opt_args.get("lr", 1e-3)))
+        trainer = JointTrainer(jw, bank, criterion, opt)
+        for _ in range(joint_epochs):
+            acc = torch.zeros((), device=device)
+            for k in mine:
+                (_, _), ((image, feat, xy), target) = ds[k]
+                loss, _ = trainer.perform_step(k, (image[None].to(device), feat[None].to(device), xy[None].to(device)),
+                                               target[None].to(device))
+                acc = acc + loss
+            joint_losses.append(float(acc) / len(mine))
+        for k in mine:   # the jointly trained priors replace the pretrained ones in the cache
+            with bank.manager(prior, k):
+                cache0[k] = {n: v.detach().cpu().clone() for n, v in prior.state_dict().items()}
     torch.cuda.synchronize()
     dt = parallel.max_over_ranks(time.perf_counter() - t0, device)
 
@@ -212,10 +257,19 @@ def main(cfg):
         if gt_iou is not None:
             summary["ForegroundBinaryMIOU_vs_ground_truth"] = round(float(gt_all.mean()), 5)
             summary["input_labels_MIOU_vs_ground_truth"] = round(float(noisy_all.mean()), 5)
+        if joint_losses:
+            summary["joint_epochs"] = joint_epochs
+            summary["joint_loss_first_last"] = [round(joint_losses[0], 6), round(joint_losses[-1], 6)]
         with open(os.path.join(out_dir, "summary.json"), "w") as f:
             json.dump(summary, f, indent=1)
         print(json.dumps(summary))
     parallel.barrier()
+
+
+def bank_params(prior):
+    """The prior module's Parameter objects in the order of its flat vector (what PriorBank rows hold)."""
+    op = prior._ordered_params()
+    return (list(op[2]) + list(op[3])) if isinstance(op, tuple) and len(op) == 4 else list(op)
 
 
 def _run_sequence(cfg, A, parallel, rank, world, device, model_type, model_args, dataset, pre, num_epochs, criterion, opt_type,

@@ -122,3 +122,39 @@ def test_oracle_cdn_forward_matches_the_class(golden_dir, tag, k):
         # (weight_v of a weight-normed 1x1 layer has an analytically zero gradient: 1e-9 of rounding on both sides)
         np.testing.assert_allclose(p.grad.numpy().reshape(ref.shape), ref, rtol=2e-4, atol=2e-6 * float(np.abs(ref).max()) + 1e-8,
                                    err_msg=n)
+
+
+def test_oracle_encode_stage_matches_the_notebook_classes(golden_dir):
+    """The encode networks (Fourier features; sine layer) restated in the oracle against the notebooks' own classes executed in the
+    build container (tests/golden/encode_notebooks.npz): outputs, input gradients, parameter gradients."""
+    z = _z(golden_dir, "encode_notebooks.npz")
+    for tag, fwd, post in (("fourier", O.fourier_mlp_forward, lambda y: (y ** 2).mean()),
+                           ("sine", O.sine_net_forward, lambda y: (torch.sigmoid(y) ** 2).mean())):
+        sd = {k[len(tag) + 4:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith(tag + ".sd.")}
+        for k, v in sd.items():
+            if v.is_floating_point() and k not in ("A", "b", "offset"):
+                v.requires_grad_(True)
+        x = torch.from_numpy(z[tag + ".x"]).clone().requires_grad_(True)
+        y = fwd(sd, x)
+        np.testing.assert_allclose(y.detach().numpy(), z[tag + ".y"], rtol=1e-5, atol=1e-6)
+        post(y).backward()
+        np.testing.assert_allclose(x.grad.numpy(), z[tag + ".dx"], rtol=1e-4, atol=1e-8)
+        for k in z.files:
+            if k.startswith(tag + ".grad."):
+                name = k[len(tag) + 6:]
+                np.testing.assert_allclose(sd[name].grad.numpy(), z[k], rtol=1e-4, atol=1e-8, err_msg=k)
+    # the generic form the kernels are checked against (icnn_forward with act0) IS that arithmetic: same features, same first layer
+    sd = {k[11:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("fourier.sd.")}
+    x = torch.from_numpy(z["fourier.x"])
+    feats = torch.cos(x @ sd["A"] + sd["b"])
+    np.testing.assert_allclose(O.encode_layer(torch.nn.functional.linear(x, sd["A"].t(), sd["b"]), "cos").numpy(), feats.numpy(), rtol=1e-6, atol=1e-6)
+    p = {"input.weight": sd["A"].t().contiguous(), "input.bias": sd["b"],
+         "skip.0.ln.weight": torch.nn.functional.pad(sd["fc1.weight"], (0, 0, 0, 0))[:20, :], "skip.0.ln.bias": sd["fc1.bias"][:20],
+         "skip.0.skp.weight": torch.zeros(20, 2), "out.ln.weight": torch.ones(1, 20), "out.ln.bias": torch.zeros(1),
+         "out.skp.weight": torch.zeros(1, 2)}
+    ref = torch.relu(torch.nn.functional.linear(feats, sd["fc1.weight"][:20], sd["fc1.bias"][:20])).sum(1, keepdim=True)
+    np.testing.assert_allclose(O.icnn_forward(p, x, act0="cos").numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    sds = {k[8:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sine.sd.")}
+    xs = torch.from_numpy(z["sine.x"])
+    pre = torch.nn.functional.linear(xs + sds["offset"], sds["W1.weight"], sds["W1.bias"])
+    np.testing.assert_allclose(O.encode_layer(pre, "sin", 10 * 3.141592).numpy(), torch.sin(10 * 3.141592 * pre).numpy(), rtol=0, atol=0)

@@ -133,6 +133,32 @@ def test_run_py_two_ranks_save_every_prior(tmp_path):
         assert torch.allclose(a, b, rtol=5e-3, atol=5e-4), i
 
 
+@pytest.mark.parametrize("config,override,checks", [
+    ("c5_refine_noisy256.yaml", {"dataset_args": {"n_images": 2, "size": 64}, "agent_args": {"joint_epochs": 3, "pretrain_args": {"num_epochs": 80}}},
+     dict(images=2, joint_epochs=3)),
+    ("c2_blob256_path_connected.yaml", {"dataset_args": {"size": 64}, "agent_args": {"pretrain_args": {"num_epochs": 80}}}, dict(images=1)),
+    ("c4_sequence128x16.yaml", {"dataset_args": {"size": 32, "frames": 4}, "num_epochs": 60}, dict(images=1)),
+    ("c1_disc64_siren.yaml", {}, dict(images=1)),
+    ("c1_disc64_no_prior.yaml", {}, dict(images=1)),
+])
+def test_run_py_configs_of_the_flow_priors(tmp_path, config, override, checks):
+    """The configs of BASELINE configs[4] (noisy pseudo-labels: per-image pre-fit, then joint epochs with FBMSJointLoss through
+    WrapperModule + PriorBank), of the path-connected prior on one image and of the (x, y, t) sequence, at reduced size."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run.py"), "--config-path", os.path.join(ROOT, "config", config),
+                          "--output-folder", str(tmp_path), "--override", json.dumps(override)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    summary = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    for k, v in checks.items():
+        assert summary[k] == v, (k, summary)
+    assert summary["priors_saved"] == summary["images"]
+    cache = torch.load(os.path.join(summary["output"], "prior_cache_epoch_0.pth"), weights_only=False)
+    assert all(torch.isfinite(v).all() for sd in cache["cache"].values() for v in sd.values() if v.is_floating_point())
+    if "joint_epochs" in checks:
+        first, last = summary["joint_loss_first_last"]
+        assert np.isfinite(first) and np.isfinite(last) and last <= first * 1.05
+        assert "ForegroundBinaryMIOU_vs_ground_truth" in summary
+
+
 def test_wrapper_module_joint_step(dev):
     """WrapperModule(ForwardModule, ConvexNextNet) + AwesomeImageLoss: one joint training step like TorchAgent._perform_step
     (forward -> (B,2,H,W), criterion, backward, step, enforce_convexity) against the oracle."""

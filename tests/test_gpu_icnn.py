@@ -357,18 +357,3 @@ def test_full_fit_two_hidden_layers_matches_reference(amd, golden_dir):
     h = res.loss_hist[0].cpu().numpy()
     np.testing.assert_allclose(h[:100], z["losses"][:100], rtol=5e-4)          # same trajectory while rounding has not piled up
     assert abs(h[-1] - z["losses"][-1]) <= 0.1 * z["losses"][-1]               # and the same end point
-
-
-def test_role_split_kernel_parity():
-    """The opt-in 8-wave kernel (icnn_step_rw.h, INRFIT_RW=1: front / back roles, two waves per SIMD) through the same parity
-    tests: gradients vs the reference's golden vectors, the Adam trajectory, ragged/batched grids and the fp64 accuracy check.
-    The switch is read once per process, hence the child process."""
-    import subprocess
-    import sys
-    env = dict(os.environ, INRFIT_RW="1")
-    here = os.path.abspath(__file__)
-    sel = "loss_and_grads or adam_clamp or batched_ragged or float64 or large_grid or fit_disc64"
-    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-q", "-x", "-k", sel, "-p", "no:cacheprovider"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout

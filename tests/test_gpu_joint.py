@@ -1,0 +1,226 @@
+"""GPU parity of the joint-training step path (BASELINE configs[4]) and of configs[3] at full size.
+
+configs[4]: UNet-logit refinement - noisy 256x256 pseudo-labels, a segmentation module, a per-image shape prior and
+FBMSJointLoss, stepped like TorchAgent._perform_step (awesome/agent/torch_agent.py:428-551) with the per-image prior swap of
+PriorManager (awesome/dataset/prior_dataset.py:96-110).  HIP path: WrapperModule -> prior forward/backward kernels, the fused
+FBMSJointLoss (`inrfit_joint_loss`), PriorBank's zero-copy swap.  Checker: the CPU oracle (pure torch restatement pinned on
+fixtures of the real WrapperModule / FBMSJointLoss / ConvexNextNet classes), never a copy of the HIP path itself."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import inr_oracle as O  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_fused_fbms_joint_loss_matches_reference_class(dev, golden_dir):
+    """inrfit_joint_loss (value, both gradient channels, both clip branches) against the reference class's fixture, and the
+    class-weighted default criterion (UnariesWeightedLoss(BCELoss, 'sssdms'), counts over the batch) against the oracle."""
+    from awesome_amd.measures import FBMSJointLoss, SE, UnariesWeightedLoss
+    z = np.load(os.path.join(golden_dir, "fbms_joint_loss.npz"))
+    for case in range(3):
+        out = torch.from_numpy(z[f"c{case}.output"]).to(dev).requires_grad_(True)
+        tgt = torch.from_numpy(z[f"c{case}.target"]).to(dev)
+        crit = FBMSJointLoss(criterion=torch.nn.BCELoss(), alpha=1.0, beta=float(z[f"c{case}.beta"]))
+        assert crit._fused_desc(out) is not None                      # the HIP loss is what runs
+        loss = crit(out, tgt)
+        loss.backward()
+        assert float(loss.detach()) == pytest.approx(float(z[f"c{case}.loss"]), rel=2e-6)
+        np.testing.assert_allclose(out.grad.cpu().numpy(), z[f"c{case}.grad"], rtol=2e-5, atol=1e-9)
+    torch.manual_seed(3)
+    for kind, mode, alpha, beta in (("bce", "sssdms", 0.7, 3.0), ("se", "equal", 1.0, 0.2), ("se", "ratio", 1.3, 40.0), ("bce", "none", 1.0, 1.0)):
+        out_c = torch.rand(3, 2, 17, 13) * 0.96 + 0.02
+        tgt_c = (torch.rand(3, 1, 17, 13) > 0.8).float()              # few foreground pixels: a non-trivial class weight
+        inner = torch.nn.BCELoss() if kind == "bce" else SE("mean")
+        crit = FBMSJointLoss(criterion=UnariesWeightedLoss(inner, mode=mode, ratio=0.5), alpha=alpha, beta=beta)
+        o_h = out_c.to(dev).requires_grad_(True)
+        l_h = crit(o_h, tgt_c.to(dev))
+        l_h.backward()
+        o_r = out_c.clone().requires_grad_(True)
+        l_r = O.fbms_joint_loss(o_r, tgt_c, alpha=alpha, beta=beta, kind=kind, mode=mode, ratio=0.5)
+        l_r.backward()
+        assert float(l_h.detach()) == pytest.approx(float(l_r.detach()), rel=5e-6), (kind, mode)
+        np.testing.assert_allclose(o_h.grad.cpu().numpy(), o_r.grad.numpy(), rtol=5e-5, atol=1e-9, err_msg=f"{kind} {mode}")
+
+
+def _oracle_joint_epochs(conv_w, conv_b, prior_states, images, grid, targets, order, lr, alpha, beta):
+    """TorchAgent._perform_step restated on the CPU: ONE torch Adam over (segmentation conv, the single prior model's
+    parameters); the prior's parameter VALUES are swapped per image (PriorManager), its Adam moments are shared - exactly what
+    the reference's single optimizer over model.parameters() does."""
+    conv = torch.nn.Conv2d(1, 1, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(conv_w)
+        conv.bias.copy_(conv_b)
+    keys = list(prior_states[0].keys())
+    prior = {k: torch.nn.Parameter(prior_states[0][k].clone()) for k in keys}
+    opt = torch.optim.Adam(list(conv.parameters()) + [prior[k] for k in keys], lr=lr)
+    states = [{k: v.clone() for k, v in st.items()} for st in prior_states]
+    losses = []
+    for i in order:
+        with torch.no_grad():
+            for k in keys:
+                prior[k].copy_(states[i][k])                                  # PriorManager.__enter__
+        opt.zero_grad()
+        seg_logits = conv(images[i][None])
+        out = O.wrapper_forward(seg_logits, O.icnn_forward_image(prior, grid), invert_seg=True)
+        loss = O.fbms_joint_loss(out, targets[i][None], alpha=alpha, beta=beta, kind="bce", mode="sssdms")
+        loss.backward()
+        opt.step()
+        O.icnn_enforce_convexity(prior)                                       # batch_processed hook
+        losses.append(float(loss.detach()))
+        states[i] = {k: prior[k].detach().clone() for k in keys}              # PriorManager.__exit__
+    return conv, states, losses
+
+
+class _SegStandIn(torch.nn.Module):
+    """Stand-in for the UNet (out of scope: the backbone runs on torch / MIOpen as it is): one 3x3 convolution over the noisy
+    logit image; like the reference's backbones it is called with the image plus the extra inputs (features ...)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv = torch.nn.Conv2d(1, 1, 3, padding=1)
+
+    def forward(self, image, *args, **kwargs):
+        return self.conv(image)
+
+
+def test_configs4_joint_steps_on_noisy_pseudo_labels(dev):
+    """BASELINE configs[4] in miniature (64x64 so the CPU oracle finishes in seconds; the kernels are size-agnostic and the
+    256x256 case is timed by scripts/run.py config/c5): two epochs over three noisy-blob images, every step = swap the image's
+    prior in, WrapperModule forward, FBMSJointLoss, backward, Adam, enforce_convexity.  HIP vs the oracle: losses, the shared
+    segmentation weights and every image's prior parameters."""
+    from awesome_amd.agent import JointTrainer
+    from awesome_amd.dataset import SyntheticPriorDataset
+    from awesome_amd.measures import FBMSJointLoss
+    from awesome_amd.model import ConvexNextNet, WrapperModule
+    from awesome_amd.prior_bank import PriorBank
+    S, n, lr, alpha, beta = 64, 3, 2e-3, 1.0, 2.0
+    torch.manual_seed(21)
+    ds = SyntheticPriorDataset(n_images=n, size=S, kind="noisy_blob")
+    items = [ds[i] for i in range(n)]                       # no prior attached: ((image, feat, xy), target)
+    images = [it[0][0] for it in items]
+    targets = [it[1] for it in items]
+    xy = items[0][0][2]
+    seg = _SegStandIn()
+    conv_w, conv_b = seg.conv.weight.detach().clone(), seg.conv.bias.detach().clone()
+    factory_states = []
+
+    def factory():
+        m = ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=1)
+        factory_states.append({k: v.detach().clone() for k, v in m.state_dict().items()})
+        return m
+
+    wrapper = WrapperModule(seg, ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=1), use_segmentation_output_inversion=True).to(dev)
+    bank = PriorBank(lambda: factory().to(dev), n_images=n, device=dev)
+    factory_states.clear()                                    # (the bank's probe model)
+    for k in range(n):
+        bank.row(k)                                           # generate the three priors in key order
+    init_states = [dict(s) for s in factory_states[:n]]
+    crit = FBMSJointLoss(alpha=alpha, beta=beta)              # default criterion: UnariesWeightedLoss(BCELoss, 'sssdms')
+    opt = torch.optim.Adam(list(seg.parameters()) + list(wrapper.prior_module._ordered_params()), lr=lr)
+    trainer = JointTrainer(wrapper, bank, crit, opt)
+    order = [0, 1, 2, 0, 1, 2]
+    feat = torch.zeros(1, 1, 1, 1, device=dev)
+    losses = []
+    for i in order:
+        loss, out = trainer.perform_step(i, (images[i][None].to(dev), feat, xy[None].to(dev)), targets[i][None].to(dev))
+        assert out.shape == (1, 2, S, S)
+        losses.append(float(loss))
+    conv_ref, states_ref, losses_ref = _oracle_joint_epochs(conv_w, conv_b, init_states, images, xy[None], targets, order, lr, alpha, beta)
+    np.testing.assert_allclose(losses, losses_ref, rtol=2e-5)
+    np.testing.assert_allclose(seg.conv.weight.detach().cpu().numpy(), conv_ref.weight.detach().numpy(), rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(seg.conv.bias.detach().cpu().numpy(), conv_ref.bias.detach().numpy(), rtol=2e-4, atol=2e-6)
+    for k in range(n):
+        got = bank.state_dict(k)
+        for name, ref in states_ref[k].items():
+            np.testing.assert_allclose(got[name].numpy(), ref.numpy(), rtol=5e-4, atol=5e-6, err_msg=f"image {k} {name}")
+    # the bank exports the reference's cache layout
+    st = bank.get_state(model_args=dict(n_hidden=130))
+    assert sorted(st["cache"]) == ["0", "1", "2"] and list(st["cache"]["0"]) == list(init_states[0])
+
+
+def test_prior_bank_with_path_connected_prior_joint_step(dev):
+    """The configs[4] prior proper (convexity + path-connectedness: PathConnectedNet) in the bank: one joint step through
+    WrapperModule + FBMSJointLoss vs the oracle's RealNVP restatement with autograd (loss and every prior gradient)."""
+    from awesome_amd.dataset import SyntheticPriorDataset
+    from awesome_amd.measures import FBMSJointLoss
+    from awesome_amd.model import ForwardModule, WrapperModule, real_nvp_path_connected_net
+    from awesome_amd.prior_bank import PriorBank
+    S = 32
+    torch.manual_seed(8)
+    args = dict(channels=2, hidden_units=16, flow_n_flows=4, flow_output_fn="tanh", convex_net_hidden_units=64, convex_net_hidden_layers=2)
+    ds = SyntheticPriorDataset(n_images=2, size=S, kind="noisy_blob")
+    (image, _, xy), target = ds[1]
+    bank = PriorBank(lambda: real_nvp_path_connected_net(**args).to(dev), n_images=2, device=dev)
+    model = real_nvp_path_connected_net(**args).to(dev)
+    wrapper = WrapperModule(ForwardModule(), model, use_segmentation_output_inversion=True).to(dev)
+    with torch.no_grad():                                     # non-trivial last layers (they are zero-initialised)
+        for name, p in model.named_parameters():
+            if ".net.2." in name:
+                p.add_(0.05 * torch.randn_like(p))
+    with bank.manager(model, 1):
+        with torch.no_grad():
+            for name, p in model.named_parameters():          # the bank row now holds the perturbed values too
+                if ".net.2." in name:
+                    p.add_(0.05 * torch.randn_like(p))
+        out = wrapper(image[None].to(dev), torch.zeros(1, 1, 1, 1, device=dev), xy[None].to(dev))
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}     # after ActNorm's data-dependent init
+        loss = FBMSJointLoss(alpha=1.0, beta=2.0)(out, target[None].to(dev))
+        loss.backward()
+        grads = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
+    _, rspec = model._specs()
+    sdo = {k: v.clone().requires_grad_(v.is_floating_point() and k in grads) for k, v in sd.items()}
+    rows = O.pixelize(xy[None])
+    masks = O.rnvp_masks(2, args["flow_n_flows"])
+    y = O.pcn_forward(sdo, rows, masks, torch.tensor(rspec.vmin), torch.tensor(rspec.vmax), output_fn="tanh", output_scale=None)
+    out_ref = O.wrapper_forward(image[None], O.unpixelize(y, 1, S, S), invert_seg=True)
+    loss_ref = O.fbms_joint_loss(out_ref, target[None], alpha=1.0, beta=2.0, kind="bce", mode="sssdms")
+    loss_ref.backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), out_ref.detach().numpy(), atol=5e-6, rtol=1e-4)
+    assert float(loss.detach()) == pytest.approx(float(loss_ref.detach()), rel=2e-5)
+    for k, g in grads.items():
+        ref = sdo[k].grad
+        if ref is None:
+            continue
+        ref = ref.numpy()
+        np.testing.assert_allclose(g.numpy().reshape(ref.shape), ref, rtol=2e-3, atol=2e-5 * float(np.abs(ref).max()) + 1e-8, err_msg=k)
+
+
+def test_configs3_full_size_xyt_loss_and_gradients(dev):
+    """BASELINE configs[3] at FULL size: PathConnectedNet (C = 3, 18 flows x 32 hidden units, tanh outputs, ICNN 130 x 2) on the
+    128 x 128 x 16 (x, y, t) grid = 262 144 points in one launch sequence - loss and the gradient of every parameter against
+    the oracle's autograd (parity for this variant is UNPINNED: the oracle restates normflows' published definitions)."""
+    import awesome_amd as A
+    from awesome_amd import rnvp as R
+    from awesome_amd.dataset import SyntheticSequenceDataset
+    from tests.test_gpu_rnvp import _case, _merge, _split
+    ispec, rspec, sd = _case(3, 32, 18, 2, seed=33)
+    rspec = R.RnvpSpec(3, 32, 18, "tanh", None, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))   # the factory's MinMax: [0, 1] per channel
+    ds = SyntheticSequenceDataset(1, 128, 16)
+    coords, un = ds.coords(), ds.batch([0])
+    assert coords.shape == (3, 262144)
+    masks = O.rnvp_masks(3, 18)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    torch.set_num_threads(8)
+    y = O.pcn_forward(sdo, coords.t(), masks, torch.tensor(rspec.vmin), torch.tensor(rspec.vmax), output_fn="tanh", output_scale=None)
+    lo = O.weighted_loss(torch.sigmoid(y).reshape(1, 1, -1, 1), un.reshape(1, 1, -1, 1), "se", "none")
+    lo.backward()
+    ip, fp = _split(ispec, rspec, sd, dev)
+    grid = A.Grid.explicit(coords.to(dev))
+    logits = R.pcn_forward(ispec, rspec, ip, fp, grid)
+    np.testing.assert_allclose(logits[0].cpu().numpy(), y.detach().reshape(-1).numpy(), atol=2e-4, rtol=1e-3)
+    loss, gi, gf = R.pcn_loss_grad(ispec, rspec, ip, fp, grid, un.to(dev), loss="se")
+    assert float(loss[0]) == pytest.approx(float(lo.detach()), rel=2e-5)
+    got = _merge(ispec, rspec, gi[0].cpu(), gf[0].cpu())
+    for k, v in got.items():
+        ref = sdo[k].grad.numpy()
+        np.testing.assert_allclose(v.numpy().reshape(ref.shape), ref, rtol=5e-3, atol=5e-5 * float(np.abs(ref).max()) + 1e-9, err_msg=k)

@@ -298,3 +298,37 @@ def test_pretrain_agent_saves_and_reloads_pretrain_state(dev, tmp_path):
     assert not hasattr(wrapper2.prior_module, "pretrain_report")          # nothing was fitted
     for k, v in state["cache"]["1"].items():
         assert torch.equal(ds2.__prior_cache__[1][k].cpu(), v.cpu())
+
+
+def test_pretrain_spatio_temporal_dispatch(dev):
+    """A prior data set WITHOUT per-image priors sends PathConnectedNet.pretrain down the spatio-temporal branch
+    (path_connected_net.py:472-509 -> :511-728): one (x, y, t) network over all frames, mini-batches of frames, the module's own
+    state_dict as the returned state - against the same stages called by hand."""
+    from awesome_amd.dataset import SyntheticPriorDataset
+    from awesome_amd.model import ForwardModule, WrapperModule, real_nvp_path_connected_net
+    args = dict(channels=3, hidden_units=16, flow_n_flows=6, flow_output_fn="tanh", convex_net_hidden_units=64, convex_net_hidden_layers=2)
+    pre = dict(num_epochs=6, lr=1e-3, batch_size=2, prefit_flow_net_identity=True, prefit_flow_net_identity_num_epochs=10,
+               prefit_convex_net=True, prefit_convex_net_num_epochs=15)
+    ds = SyntheticPriorDataset(n_images=4, size=24, kind="sequence")           # 4 frames, no prior_model_type
+    assert not ds.has_prior and ds[2][0][2].shape == (3, 24, 24)
+    torch.manual_seed(17)
+    model = real_nvp_path_connected_net(**args).to(dev)
+    start = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    wrapper = WrapperModule(ForwardModule(), model, use_segmentation_output_inversion=True).to(dev)
+    state = wrapper.pretrain(train_set=ds, test_set=None, device=dev, agent=_Agent(ds, dev), use_progress_bar=False, **pre)
+    assert list(state.keys()) == list(start.keys()) and len(model.pretrain_epoch_losses) == 6
+    assert model.pretrain_epoch_losses[-1] < model.pretrain_epoch_losses[0]
+    # by hand
+    import awesome_amd as A
+    twin = real_nvp_path_connected_net(**args).to(dev)
+    twin.load_state_dict(start)
+    frames = [(1 - torch.sigmoid(ds[i][0][0].to(dev))).reshape(-1) for i in range(4)]
+    coords = torch.stack([ds[i][0][2].reshape(3, -1) for i in range(4)]).to(dev)
+    whole = A.Grid.explicit(coords.permute(1, 0, 2).reshape(3, -1).contiguous())
+    twin.learn_flow_identity(whole, lr=1e-2, weight_decay=1e-5, max_iter=10)
+    twin.learn_convex_net(whole, torch.stack(frames).reshape(1, -1), lr=1e-3, weight_decay=0.0, max_iter=15)
+    losses = twin.fit_sequence(coords, torch.stack(frames), num_epochs=6, lr=1e-3, flow_weight_decay=1e-5, batch_size=2)
+    np.testing.assert_allclose(model.pretrain_epoch_losses, losses, rtol=1e-6)
+    for k, v in twin.state_dict().items():
+        if v.is_floating_point() and not k.endswith("data_dep_init_done"):
+            assert torch.equal(v, state[k]), k

@@ -196,6 +196,50 @@ def gen_prior_cache(ref, out):
     print("prior_cache", rec["model_type"], rec["model_args"], rec["cache_keys"])
 
 
+def _notebook_class(path, cell, name):
+    """Execute ONE code cell of a reference notebook in an empty namespace and return the class it defines.  The cell text is read
+    from the read-only reference checkout at generation time; it is not copied into this repository."""
+    with open(os.path.join(REF, path)) as f:
+        src = "".join(json.load(f)["cells"][cell]["source"])
+    import torch.nn as nn
+    import torch.nn.functional as F
+    ns = {"np": np, "torch": torch, "nn": nn, "F": F}   # the names the notebook's import cell provides
+    exec(compile(src, f"{path}#cell{cell}", "exec"), ns)   # noqa: S102 - the reference's own class definition
+    return ns[name]
+
+
+def gen_encode_notebooks(out):
+    """The two encode networks of the notebooks, run as written: forward outputs and input/parameter gradients
+    on a small grid of coordinates."""
+    import warnings
+    rec = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Net = _notebook_class("notebooks/imageRepresentationTest.ipynb", 5, "ourSimpleNetwork")
+        seed_all(51)
+        net = Net(2, 20, 24, 1, 30)       # d_in, d_features, d_hidden, d_out, factor (the notebook: 2, 20, 350, 3, 30)
+    ys, xs = torch.meshgrid(torch.arange(0, 12), torch.arange(0, 10), indexing="ij")
+    x = (torch.stack([ys.reshape(-1), xs.reshape(-1)], 1).float() / 10.0).requires_grad_(True)   # cell 7's x_test convention
+    y = net(x)
+    (y ** 2).mean().backward()
+    rec["fourier.x"], rec["fourier.y"], rec["fourier.dx"] = x.detach().numpy(), y.detach().numpy(), x.grad.numpy().copy()
+    rec.update(sd_np(net, "fourier.sd."))
+    rec.update(grads_np(net, "fourier.grad."))
+    Sine = _notebook_class("notebooks/icml_teaser_code/repeating/repeating.ipynb", 3, "myNet")
+    seed_all(52)
+    sn = Sine(16)
+    with torch.no_grad():
+        sn.offset.copy_(torch.tensor([[0.05, -0.1]]))
+    x2 = (torch.rand(90, 2) - 0.5).requires_grad_(True)                                         # cell 4: coordinates in [-0.5, 0.5)
+    y2 = sn(x2)
+    (torch.sigmoid(y2) ** 2).mean().backward()
+    rec["sine.x"], rec["sine.y"], rec["sine.dx"] = x2.detach().numpy(), y2.detach().numpy(), x2.grad.numpy().copy()
+    rec.update(sd_np(sn, "sine.sd."))
+    rec.update({"sine.grad." + k: p.grad.detach().numpy().copy() for k, p in sn.named_parameters() if p.grad is not None})
+    np.savez_compressed(os.path.join(out, "encode_notebooks.npz"), **rec)
+    print("encode notebooks", rec["fourier.y"].shape, rec["sine.y"].shape)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
@@ -203,6 +247,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(4)
     ref = _import_reference()
+    gen_encode_notebooks(args.out)
     gen_fbms_joint_loss(ref, args.out)
     gen_wrapper(ref, args.out)
     gen_prior_cache(ref, args.out)
