@@ -412,6 +412,7 @@ struct FlowUpdArgs {
     double bc1;
     float bc2_sqrt, one_minus_b1, one_minus_b2, wd_g;
     int mode;             // 0 = Adam step + effective weights, 1 = gradients only, 2 = effective weights only (prep)
+    const int32_t* status;   // per image (mode 0): frozen by a non-finite loss -> no step, like the ICNN and RealNVP updates
 };
 
 __device__ __forceinline__ float block_sum256(float v, float* sm) {  // fixed-order sum over a 256-thread block
@@ -439,6 +440,9 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
     __shared__ float sm[4];
     const int img = blockIdx.y, nb = blockIdx.x, tid = threadIdx.x;
     const FlowMap& m = u.m;
+    // an image the ICNN update of this step has frozen (non-finite loss: status set one launch earlier) takes no optimizer step:
+    // its effective weights are rebuilt from the unchanged parameters
+    const int mode = (u.mode == 0 && u.status != nullptr && u.status[img] != INR_STATUS_OK) ? 2 : u.mode;
     const int W = m.W, K = m.K;
     float* __restrict__ fp = u.FP + (size_t)img * m.FP;
     float* __restrict__ fe = u.FE + (size_t)img * m.FE;
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
         const bool on = tid < W;
         float v1 = on ? fp[pb + tid] : 0.f, b1 = on ? fp[pb + W + 1 + tid] : 0.f, v2 = on ? fp[pb + 2 * W + 1 + tid] : 0.f;
         float g1 = fp[pb + W], g2 = fp[pb + 3 * W + 1], b2 = fp[pb + 3 * W + 2];
-        if (u.mode != 2) {
+        if (mode != 2) {
             // effective-weight gradients: fixed-order sums over the chunks / blocks
             float dw1 = 0.f, db1 = 0.f, dw2 = 0.f;
             if (on) {
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
             const float dot1 = block_sum256(dw1 * v1, sm), dot2 = block_sum256(dw2 * v2, sm);
             const float dg1 = dot1 / n1, dg2 = dot2 / n2;
             const float dv1 = g1 / n1 * (dw1 - v1 * dot1 / (n1 * n1)), dv2 = g2 / n2 * (dw2 - v2 * dot2 / (n2 * n2));
-            if (u.mode == 1) {
+            if (mode == 1) {
                 if (on) {
                     go[pb + tid] = dv1;
                     go[pb + W + 1 + tid] = db1;
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
     }
     // last block: WNScale parameters of every coupling + the 2x2 linear: first reduce their per-block partial sums
     __shared__ float tot[64];
-    if (u.mode != 2) {
+    if (mode != 2) {
         for (int k = 0; k < 3 * K + 6; ++k) {
             if (k >= K && k < 3 * K) continue;   // db2 sums belong to the coupling-net blocks
             float part = 0.f;
@@ -545,11 +549,11 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
     if (tid < K) {
         const int i = tid, pb = m.p_scale + 4 * i;  // weight, sc_bias, sc_g, sc_v
         float w = fp[pb], sb = fp[pb + 1], sg = fp[pb + 2], sv = fp[pb + 3];
-        if (u.mode != 2) {
+        if (mode != 2) {
             const float dsc = tot[i];
             const float sgn = sv / fabsf(sv);        // weight_norm(dim=0) of a 1x1 weight: v / |v|
             const float dw = dsc * sg * sgn, dsb = dsc, dsg = dsc * w * sgn, dsv = 0.f;
-            if (u.mode == 1) {
+            if (mode == 1) {
                 go[pb] = dw; go[pb + 1] = dsb; go[pb + 2] = dsg; go[pb + 3] = dsv;
             } else {
                 w = adam_apply(u, w, dw, lr, 0.f, &om[pb], &ov[pb]);
@@ -559,19 +563,19 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
                 fp[pb] = w; fp[pb + 1] = sb; fp[pb + 2] = sg; fp[pb + 3] = sv;
             }
         }
-        if (u.mode != 1) fe[m.e_scale + i] = sg * (sv / fabsf(sv)) * w + sb;
+        if (mode != 1) fe[m.e_scale + i] = sg * (sv / fabsf(sv)) * w + sb;
     } else if (tid >= 64 && tid < 70) {
         const int k = tid - 64;  // A[0][0], A[0][1], A[1][0], A[1][1], b[0], b[1]
         float p = fp[k];
-        if (u.mode != 2) {
+        if (mode != 2) {
             const float d = tot[3 * K + k];
-            if (u.mode == 1) go[k] = d;
+            if (mode == 1) go[k] = d;
             else {
                 p = adam_apply(u, p, d, lr, 0.f, &om[k], &ov[k]);
                 fp[k] = p;
             }
         }
-        if (u.mode != 1) fe[k] = p;
+        if (mode != 1) fe[k] = p;
     }
 }
 

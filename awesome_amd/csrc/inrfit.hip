@@ -899,8 +899,10 @@ CdnWs carve_cdn(const KernelEntry* e, const InrFlowDesc* f, const InrGridDesc* g
 }
 
 void launch_flow_update(const CdnWs& w, const InrFlowDesc* f, int n_images, int mode, float* FP, float* opt, float* grads_out,
-                        const InrOptDesc* od, float wd_g, int t, const float* lr_hdr, long long hdr_stride, hipStream_t s) {
+                        const InrOptDesc* od, float wd_g, int t, const float* lr_hdr, long long hdr_stride, hipStream_t s,
+                        const int32_t* status = nullptr) {
     FlowUpdArgs u{};
+    u.status = status;
     u.FP = FP;
     u.FE = w.FE;
     u.opt = opt;
@@ -1113,7 +1115,7 @@ int inrfit_cdn_fit(const InrModelDesc* model, const InrFlowDesc* flow, float* ic
         launch_flow_bwd(w, flow, grid, n_images, s);
         // the learning rate of THIS step sits in header[t & 1] (the plateau thread wrote the next one into the other slot)
         launch_flow_update(w, flow, n_images, 0, flow_params, flow_opt_state, nullptr, opt, wd_on_weight_g, u.t,
-                           icnn_opt_state + 2 * (size_t)e->P, hdr_stride, s);
+                           icnn_opt_state + 2 * (size_t)e->P, hdr_stride, s, status);
     }
     if (hipGetLastError() != hipSuccess) return INR_ELAUNCH;
     if (final_logits) {
@@ -1183,7 +1185,7 @@ PcnWs carve_pcn(const KernelEntry* e, const InrRnvpDesc* r, const InrGridDesc* g
     w.Q = 1;   // two points per lane (half the record reads per point) measured slower even at 262144 points: 73 vs 70 us
                // forward, 155 vs 137 us backward - the loops are VALU-bound, not LDS-bound
     w.blocks1 = (int)((N + 256 * w.Q - 1) / (256 * w.Q));
-    w.chunks = 32;   // x F flows x 4 waves: enough waves for the 1024 SIMDs
+    w.chunks = 64;   // x F flows x 4 waves: enough waves for the 1024 SIMDs
     while (w.chunks > 1 && N / w.chunks < 1024) w.chunks /= 2;
     w.S1 = F * 4 * C + 2 * C;
     char* b = (char*)base;

@@ -237,9 +237,9 @@ def main():
     flop_per_launch = STEP_FLOP_PER_POINT * N * B
     achieved = flop_per_launch / (kernel_ms * 1e-3) / 1e12
     # HBM bytes per launch of this kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes of
-    # this same command; profiles/r01_c_pmc_traffic.json) - only quoted for the configuration it was measured on
+    # this same command; profiles/r02_a_pmc_step_kernel.json) - only quoted for the configuration it was measured on
     traffic = None
-    tf = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+    tf = os.path.join(ROOT, "profiles", "r02_a_pmc_step_kernel.json")
     if B == 1 and S == 256 and os.path.exists(tf):
         with open(tf) as f:
             traffic = json.load(f).get("traffic_bytes_per_launch")
@@ -325,37 +325,60 @@ def main():
 
 
 def path_variants(dev, S, steps=300):
-    """Extra, never part of `value`: microseconds per optimizer step of the other priors on the same path (one image /
-    sequence on this GPU): ICNN L=2, ConvexDiffeomorphismNet, PathConnectedNet (RealNVP) on (x, y) and on (x, y, t)."""
+    """Extra, never part of `value`: the other priors on the same path (one image / sequence on this GPU): ICNN L=2,
+    ConvexDiffeomorphismNet, PathConnectedNet (RealNVP) on (x, y) and on (x, y, t).  Per variant: microseconds per optimizer
+    step of the fused fit (wall clock over `steps` steps), a `roofline` object on the ALGORITHMIC flops of one step (3 x the
+    forward flops of the ICNN and of the deformation, SURVEY.md 8d's convention; bound = the fp32 matrix/vector peak, which are
+    the same number on this chip) and a `check`: the loss of the timed fit is finite and falls."""
     import torch
     import awesome_amd as A
     from awesome_amd.dataset import SyntheticSequenceDataset, convex_blob_unaries
     from awesome_amd.model import ConvexDiffeomorphismNet, ConvexNextNet, real_nvp_path_connected_net
 
+    def icnn_fwd_flop(h, c, layers):          # SURVEY.md 8a a4: 4h + L(2h^2 + 4h) + 2h + 4 for c = 2 (2hc + L(2h^2 + 2hc) + 2h + 2c in general)
+        return 2 * h * c + layers * (2 * h * h + 2 * h * c) + 2 * h + 2 * c
+
+    def entry(us, n_points, fwd_flop_icnn, fwd_flop_flow, hist):
+        flop = 3.0 * (fwd_flop_icnn + fwd_flop_flow) * n_points
+        tf = flop / (us * 1e-6) / 1e12
+        h = hist.float().cpu()
+        return {"us_per_step": us,
+                "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4), "flop_per_step": int(flop),
+                             "flop_per_point_icnn_fwd": fwd_flop_icnn, "flop_per_point_flow_fwd": fwd_flop_flow,
+                             "basis": "wall clock per optimizer step (all kernels of the step), not one kernel"},
+                "check": {"loss_first": round(float(h[0]), 6), "loss_last": round(float(h[-1]), 6),
+                          "ok": bool(torch.isfinite(h).all() and h[-1] < h[0])}}
+
     def timed(fn):
         fn(10)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        fn(steps)
+        res = fn(steps)
         torch.cuda.synchronize()
-        return round((time.perf_counter() - t0) / steps * 1e6, 1)
+        return round((time.perf_counter() - t0) / steps * 1e6, 1), res.loss_hist[0]
 
     torch.manual_seed(0)
+    N = S * S
     un = convex_blob_unaries(S, 0).reshape(1, -1).to(dev)
     grid = A.Grid.linspace(S, S, dev)
     out = {"unit": "us per optimizer step", "steps": steps}
     m2 = ConvexNextNet(n_hidden=130, n_hidden_layers=2, in_features=2)
     p2 = m2.flat_parameters()[None].to(dev)
-    out[f"ConvexNextNet_L2_{S}x{S}"] = timed(lambda n: A.fit(m2.spec, p2.clone(), grid, un, n, lr=2e-3, record_loss=False, want_logits=False))
+    us, h = timed(lambda n: A.fit(m2.spec, p2.clone(), grid, un, n, lr=2e-3, record_loss=True, want_logits=False))
+    out[f"ConvexNextNet_L2_{S}x{S}"] = entry(us, N, icnn_fwd_flop(130, 2, 2), 0, h)
     cdn = ConvexDiffeomorphismNet(n_hidden=130, n_hidden_layers=2, nf_layers=6, nf_hidden=130,
                                   diffeo_args=dict(backbone="normal_block")).to(dev)   # the reference configs' form
-    out[f"ConvexDiffeomorphismNet_K6_w130_L2_{S}x{S}"] = timed(lambda n: cdn.fit_images(grid, un, num_epochs=n))
+    us, h = timed(lambda n: cdn.fit_images(grid, un, num_epochs=n))
+    out[f"ConvexDiffeomorphismNet_K6_w130_L2_{S}x{S}"] = entry(us, N, icnn_fwd_flop(130, 2, 2), 6 * 8 * 130, h)   # 8 w flop per coupling
     pc2 = real_nvp_path_connected_net(channels=2, hidden_units=32, flow_n_flows=12, flow_output_fn="tanh").to(dev)
-    out[f"PathConnectedNet_RealNVP_C2_F12_L2_{S}x{S}"] = timed(lambda n: pc2.fit_images(grid, un, num_epochs=n))
+    us, h = timed(lambda n: pc2.fit_images(grid, un, num_epochs=n))
+    out[f"PathConnectedNet_RealNVP_C2_F12_L2_{S}x{S}"] = entry(us, N, icnn_fwd_flop(130, 2, 2), 12 * 32 * 2 * 2 * 2, h)   # F hid 2 nets C 2
     ds = SyntheticSequenceDataset(1, 128, 16)
     g3, u3 = A.Grid.explicit(ds.coords().to(dev)), ds.batch([0]).to(dev)
     pc3 = real_nvp_path_connected_net(channels=3, hidden_units=32, flow_n_flows=18, flow_output_fn="tanh").to(dev)
-    out["PathConnectedNet_RealNVP_C3_F18_L2_128x128x16"] = timed(lambda n: pc3.fit_images(g3, u3, num_epochs=n))
+    us, h = timed(lambda n: pc3.fit_images(g3, u3, num_epochs=n))
+    out["PathConnectedNet_RealNVP_C3_F18_L2_128x128x16"] = entry(us, 128 * 128 * 16, icnn_fwd_flop(130, 3, 2), 18 * 32 * 2 * 3 * 2, h)
     return out
 
 

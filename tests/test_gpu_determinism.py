@@ -154,6 +154,26 @@ def test_nonfinite_loss_freezes_the_image_and_is_surfaced(amd):
     finally:
         amd._lib.load().inrfit_debug_set_slab_base(0)
     assert torch.equal(both.params[1], alone.params[0])
+    # the flow priors freeze BOTH their parameter sets (ICNN and deformation) the same way
+    from awesome_amd import flow as FL, rnvp as R
+    from awesome_amd.model import ConvexDiffeomorphismNet, real_nvp_path_connected_net
+    g64 = amd.Grid.linspace(64, 64, torch.device("cuda:0"))
+    u64 = un[:1, ::16].contiguous().clone()
+    u64[0, 7] = float("nan")
+    torch.manual_seed(4)
+    cdn = ConvexDiffeomorphismNet(n_hidden=64, n_hidden_layers=1, nf_layers=4, nf_hidden=24, diffeo_args=dict(backbone="normal_block"))
+    ispec, fspec = cdn._specs()
+    flat = cdn._engine_pack(cdn.state_dict()).to("cuda:0")[None]
+    ip, fp = flat[:, :ispec.n_params].contiguous(), flat[:, ispec.n_params:].contiguous()
+    r = FL.cdn_fit(ispec, fspec, ip.clone(), fp.clone(), g64, u64, 5)
+    assert int(r.status[0]) == 1 and torch.equal(r.icnn_params, ip) and torch.equal(r.flow_params, fp)
+    pcn = real_nvp_path_connected_net(channels=2, hidden_units=16, flow_n_flows=4, flow_output_fn="tanh", convex_net_hidden_units=64)
+    ispec, rspec = pcn._specs()
+    flat = pcn._engine_pack(pcn.state_dict()).to("cuda:0")[None]
+    ip, fp = flat[:, :ispec.n_params].contiguous(), flat[:, ispec.n_params:].contiguous()
+    R.actnorm_init(rspec, fp, g64)
+    r = R.pcn_fit(ispec, rspec, ip.clone(), fp.clone(), g64, u64, 5)
+    assert int(r.status[0]) == 1 and torch.equal(r.icnn_params, ip) and torch.equal(r.flow_params, fp)
     # host reaction
     torch.manual_seed(0)
     fitter = BatchedPriorFitter(lambda: ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=1), num_epochs=20,

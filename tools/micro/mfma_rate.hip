@@ -83,6 +83,41 @@ __global__ __launch_bounds__(512) void rate_kernel(float* out, unsigned long lon
                 }
             return;
         }
+        if (MODE >= 30 && MODE < 40) {   // the SAME 2 v_fma per MFMA as mode 12, but issued in bursts: after every B-th MFMA a block of 2B v_fma
+            constexpr int B = MODE == 30 ? 1 : (MODE == 31 ? 4 : (MODE == 32 ? 8 : (MODE == 33 ? 16 : 32)));
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    acc[t] = MFMA16(a4[cur][t][r], b[r], acc[t]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (((8 * r + t) % B) == B - 1) {
+#pragma unroll
+                        for (int k = 0; k < 2 * B; ++k) vf[k & 7] = fmaf(vf[k & 7], 1.0001f, b[(k + r) & 3]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            return;
+        }
+        if (MODE >= 40 && MODE < 50) {   // 1 v_fma per MFMA (the step kernel's ratio), spread (40) or in bursts of 8 (41) / 32 (42); + one b128 read per 4 MFMAs
+            constexpr int B = MODE == 40 ? 1 : (MODE == 41 ? 8 : 32);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    acc[t] = MFMA16(a4[cur][t][r], b[r], acc[t]);
+                    const int q = 8 * r + t;
+                    const float* base = &lds[((lane & 15) * 140 + 4 * (lane >> 4) + 16 * (it & 31)) & 8191];
+                    if ((q & 3) == 3) a4[nx][q >> 2] = *(const f32x4*)(base + 2240 * (q >> 2));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if ((q % B) == B - 1) {
+#pragma unroll
+                        for (int k = 0; k < B; ++k) vf[k & 7] = fmaf(vf[k & 7], 1.0001f, b[(k + r) & 3]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            return;
+        }
         if (MODE != 0) __builtin_amdgcn_sched_barrier(0x676);
         if (MODE == 5 || MODE == 6 || MODE == 7 || MODE == 20) {   // the same reads, one after every 4th (5: b128) / 2nd (6: b64) / every (7: b32) MFMA, pinned
 #pragma unroll
@@ -171,6 +206,14 @@ int main() {
         run<8, 14>("8 acc + 4 v_fma per MFMA", blocks, 256);
         run<8, 16>("8 acc + 6 v_fma per MFMA", blocks, 256);
         run<8, 18>("8 acc + 8 v_fma per MFMA", blocks, 256);
+        run<8, 30>("2 v_fma per MFMA, after every MFMA", blocks, 256);
+        run<8, 31>("2 v_fma per MFMA, 8 after every 4th MFMA", blocks, 256);
+        run<8, 32>("2 v_fma per MFMA, 16 after every 8th MFMA", blocks, 256);
+        run<8, 33>("2 v_fma per MFMA, 32 after every 16th MFMA", blocks, 256);
+        run<8, 34>("2 v_fma per MFMA, 64 after every 32nd MFMA", blocks, 256);
+        run<8, 40>("1 v_fma per MFMA spread + b128 per 4", blocks, 256);
+        run<8, 41>("1 v_fma per MFMA, 8 after every 8th + b128 per 4", blocks, 256);
+        run<8, 42>("1 v_fma per MFMA, 32 after every 32nd + b128 per 4", blocks, 256);
         run<8, 1>("8 acc + 8 ds_read_b128 burst, 1 wave", blocks, 64);
         run<8, 5>("8 acc + 8 b128 spread, 1 wave", blocks, 64);
         run<8, 0>("8 acc, no fillers, 1 wave", blocks, 64);
