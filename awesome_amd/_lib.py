@@ -15,7 +15,7 @@ INR_LOSS_SE, INR_LOSS_BCE = 0, 1
 INR_WEIGHT_NONE, INR_WEIGHT_EQUAL, INR_WEIGHT_RATIO, INR_WEIGHT_SSSDMS, INR_WEIGHT_EXPLICIT = 0, 1, 2, 3, 4
 INR_OPT_ADAM, INR_OPT_ADAMAX = 0, 1
 INR_OPT_HEADER_FLOATS = 8
-INRFIT_ABI_VERSION = 3
+INRFIT_ABI_VERSION = 4
 INR_ACT_RELU, INR_ACT_COS, INR_ACT_SIN = 0, 1, 2
 ACT_KINDS = {"relu": INR_ACT_RELU, "cos": INR_ACT_COS, "sin": INR_ACT_SIN}
 INR_FLOW_NORMAL_BLOCK, INR_FLOW_SIMPLE = 0, 1
@@ -65,7 +65,8 @@ class InrOptDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("weight_decay", C.c_float), ("clamp", C.c_int32), ("plateau", C.c_int32), ("plateau_patience", C.c_int32),
                 ("plateau_factor", C.c_float), ("plateau_threshold", C.c_float), ("plateau_min_lr", C.c_float),
-                ("plateau_eps", C.c_float), ("freeze_skips", C.c_int32), ("freeze_input", C.c_int32)]
+                ("plateau_eps", C.c_float), ("freeze_skips", C.c_int32), ("freeze_input", C.c_int32),
+                ("logits_at_last_forward", C.c_int32)]
 
 
 EXPORTS = {

@@ -536,7 +536,7 @@ int inrfit_query(int* abi_version, int* max_hidden, int* lds_bytes) {
 #define INRFIT_BUILD_FLAGS "unknown (not built by awesome_amd/build.py)"
 #endif
 const char* inrfit_build_info(void) {
-    return "libinrfit abi " "3" "; gfx950; slab_base 256; " __VERSION__ "; flags: " INRFIT_BUILD_FLAGS;
+    return "libinrfit abi " "4" "; gfx950; slab_base 256; " __VERSION__ "; flags: " INRFIT_BUILD_FLAGS;
 }
 
 int inrfit_debug_set_slab_base(int slab_base) {
@@ -608,13 +608,13 @@ struct StepTiming {
 static thread_local StepTiming g_timing;
 
 static int launch_step_timed(const KernelEntry* e, const Workspace& w, const InrGridDesc* grid, const float* targets, int loss_kind,
-                             int n_images, hipStream_t s) {
+                             int n_images, hipStream_t s, float* logits = nullptr) {
     if (!g_timing.on || (int)g_timing.ev.size() >= 2 * g_timing.max_samples)
-        return launch_step(e, w, true, grid, targets, loss_kind, n_images, nullptr, s);
+        return launch_step(e, w, true, grid, targets, loss_kind, n_images, logits, s);
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return INR_ELAUNCH;
     (void)hipEventRecord(a, s);
-    const int rc = launch_step(e, w, true, grid, targets, loss_kind, n_images, nullptr, s);
+    const int rc = launch_step(e, w, true, grid, targets, loss_kind, n_images, logits, s);
     (void)hipEventRecord(b, s);
     g_timing.ev.push_back(a);
     g_timing.ev.push_back(b);
@@ -824,8 +824,12 @@ int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const
     if ((rc = launch_pack(e, w, params, n_images, s))) return rc;
     UpdArgs u = make_upd_args(e, w, params, opt_state, loss_hist, status, opt, n_images, steps);
     const dim3 ugrid = upd_grid(e->P, n_images), ublock = upd_block(e->P);
+    // opt->logits_at_last_forward: final_logits = the output of the LAST training forward (parameters before the last optimizer
+    // step) - what the reference's IoU gate looks at (path_connected_net.py:939-972) - written by that step's launch itself
+    const bool gate_logits = final_logits && opt->logits_at_last_forward && steps > 0;
     for (int it = 0; it < steps; ++it) {
-        if ((rc = launch_step_timed(e, w, grid, targets, loss->kind, n_images, s))) return rc;
+        if ((rc = launch_step_timed(e, w, grid, targets, loss->kind, n_images, s, gate_logits && it == steps - 1 ? final_logits : nullptr)))
+            return rc;
         u.t = step0 + it + 1;
         u.bc1 = 1.0 - pow((double)opt->beta1, (double)u.t);
         u.bc2_sqrt = (float)sqrt(1.0 - pow((double)opt->beta2, (double)u.t));
@@ -843,7 +847,7 @@ int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const
         }
     }
     if (hipGetLastError() != hipSuccess) return INR_ELAUNCH;
-    if (final_logits) return launch_step(e, w, false, grid, nullptr, 0, n_images, final_logits, s);
+    if (final_logits && !gate_logits) return launch_step(e, w, false, grid, nullptr, 0, n_images, final_logits, s);
     return INR_OK;
 }
 
@@ -1104,9 +1108,11 @@ int inrfit_cdn_fit(const InrModelDesc* model, const InrFlowDesc* flow, float* ic
     UpdArgs u = make_upd_args(e, w.icnn, icnn_params, icnn_opt_state, loss_hist, status, opt, n_images, steps);
     const dim3 ugrid = upd_grid(e->P, n_images), ublock = upd_block(e->P);
     const long long hdr_stride = 2 * (long long)e->P + INR_OPT_HEADER_FLOATS;
+    const bool gate_logits = final_logits && opt->logits_at_last_forward && steps > 0;   // see inrfit_fit
     for (int it = 0; it < steps; ++it) {
         launch_flow_fwd(w, grid, n_images, w.xd, s);
-        if ((rc = launch_step(e, w.icnn, true, &w.dgrid, targets, loss->kind, n_images, nullptr, s, w.dxd))) return rc;
+        if ((rc = launch_step(e, w.icnn, true, &w.dgrid, targets, loss->kind, n_images,
+                              gate_logits && it == steps - 1 ? final_logits : nullptr, s, w.dxd))) return rc;
         u.t = step0 + it + 1;
         u.bc1 = 1.0 - pow((double)opt->beta1, (double)u.t);
         u.bc2_sqrt = (float)sqrt(1.0 - pow((double)opt->beta2, (double)u.t));
@@ -1118,7 +1124,7 @@ int inrfit_cdn_fit(const InrModelDesc* model, const InrFlowDesc* flow, float* ic
                            icnn_opt_state + 2 * (size_t)e->P, hdr_stride, s, status);
     }
     if (hipGetLastError() != hipSuccess) return INR_ELAUNCH;
-    if (final_logits) {
+    if (final_logits && !gate_logits) {
         launch_flow_fwd(w, grid, n_images, w.xd, s);
         return launch_step(e, w.icnn, false, &w.dgrid, nullptr, 0, n_images, final_logits, s);
     }
@@ -1564,9 +1570,11 @@ int inrfit_pcn_fit(const InrModelDesc* model, const InrRnvpDesc* rnvp, float* ic
     UpdArgs u = make_upd_args(e, w.icnn, icnn_params, icnn_opt_state, loss_hist, status, opt, n_images, steps);
     const dim3 ugrid = upd_grid(e->P, n_images), ublock = upd_block(e->P);
     const long long hdr_stride = 2 * (long long)e->P + INR_OPT_HEADER_FLOATS;
+    const bool gate_logits = final_logits && opt->logits_at_last_forward && steps > 0;   // see inrfit_fit
     for (int it = 0; it < steps; ++it) {
         launch_rnvp_fwd(w, flow_params, grid, n_images, w.xd, true, s, false, it > 0);
-        if ((rc = launch_step(e, w.icnn, true, &w.dgrid, targets, loss->kind, n_images, nullptr, s, w.dxd))) return rc;
+        if ((rc = launch_step(e, w.icnn, true, &w.dgrid, targets, loss->kind, n_images,
+                              gate_logits && it == steps - 1 ? final_logits : nullptr, s, w.dxd))) return rc;
         u.t = step0 + it + 1;
         u.bc1 = 1.0 - pow((double)opt->beta1, (double)u.t);
         u.bc2_sqrt = (float)sqrt(1.0 - pow((double)opt->beta2, (double)u.t));
@@ -1580,7 +1588,7 @@ int inrfit_pcn_fit(const InrModelDesc* model, const InrRnvpDesc* rnvp, float* ic
         launch_rnvp_update_args(w, n_images, ru, s);
     }
     if (hipGetLastError() != hipSuccess) return INR_ELAUNCH;
-    if (final_logits) {
+    if (final_logits && !gate_logits) {
         launch_rnvp_fwd(w, flow_params, grid, n_images, w.xd, false, s);
         return launch_step(e, w.icnn, false, &w.dgrid, nullptr, 0, n_images, final_logits, s);
     }

@@ -173,7 +173,7 @@ def cdn_fit(ispec: K.IcnnSpec, fspec: FlowSpec, icnn_params: Tensor, flow_params
             steps: int, lr: float = 3e-3, loss: str = "bce", weight_mode: str = "none", ratio: float = 1.0,
             weight_decay_on_weight_g: float = 5e-5, betas=(0.9, 0.999), eps: float = 1e-8, plateau: Optional[dict] = None,
             icnn_opt_state: Optional[Tensor] = None, flow_opt_state: Optional[Tensor] = None, step0: int = 0,
-            record_loss: bool = True, want_logits: bool = True) -> CdnFitResult:
+            record_loss: bool = True, want_logits: bool = True, gate_logits: bool = False) -> CdnFitResult:
     """ConvexDiffeomorphismNet.pretrain's inner loop on the device (defaults: Adam lr 3e-3, BCE, wd 5e-5 on weight_g)."""
     ip, fp = K._check_dev(icnn_params, "icnn_params"), K._check_dev(flow_params, "flow_params")
     n, dev = ip.shape[0], ip.device
@@ -188,7 +188,7 @@ def cdn_fit(ispec: K.IcnnSpec, fspec: FlowSpec, icnn_params: Tensor, flow_params
     pl = plateau or {}
     od = L.InrOptDesc(L.INR_OPT_ADAM, float(lr), float(betas[0]), float(betas[1]), float(eps), 0.0, 1, int(plateau is not None),
                       int(pl.get("patience", 200)), float(pl.get("factor", 0.5)), float(pl.get("threshold", 1e-4)),
-                      float(pl.get("min_lr", 0.0)), float(pl.get("eps", 1e-8)))
+                      float(pl.get("min_lr", 0.0)), float(pl.get("eps", 1e-8)), 0, 0, int(bool(gate_logits)))
     ws = _ws(ispec, fspec, grid, n)
     md, fd, gd, ld = ispec.desc(), fspec.desc(), grid.desc(), K._loss_desc(loss, weight_mode, ratio, 0.0, 0.0)
     rc = L.load().inrfit_cdn_fit(C.byref(md), C.byref(fd), ip.data_ptr(), fp.data_ptr(), icnn_opt_state.data_ptr(),

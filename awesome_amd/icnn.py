@@ -303,8 +303,10 @@ def fit(spec: IcnnSpec, params: Tensor, grid: Grid, targets: Tensor, steps: int,
         weight_mode: str = "none", ratio: float = 1.0, c_fg: float = 0.0, c_bg: float = 0.0, optimizer: str = "adam",
         betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, clamp: bool = True,
         plateau: Optional[dict] = None, opt_state: Optional[Tensor] = None, step0: int = 0, record_loss: bool = True,
-        want_logits: bool = True, freeze_skips: bool = False, freeze_input: bool = False) -> FitResult:
-    """`steps` optimisation steps of n_images independent fits on the device (params updated IN PLACE)."""
+        want_logits: bool = True, freeze_skips: bool = False, freeze_input: bool = False, gate_logits: bool = False) -> FitResult:
+    """`steps` optimisation steps of n_images independent fits on the device (params updated IN PLACE).
+    gate_logits: `logits` = the output of the last training forward (what the reference's IoU gate reads) instead of the logits at
+    the final parameters."""
     _check_spec(spec)
     params = _check_dev(params, "params")
     targets = _check_dev(targets, "targets")
@@ -324,7 +326,7 @@ def fit(spec: IcnnSpec, params: Tensor, grid: Grid, targets: Tensor, steps: int,
     od = L.InrOptDesc(L.OPT_KINDS[optimizer], float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
                       int(bool(clamp)), int(plateau is not None), int(pl.get("patience", 200)), float(pl.get("factor", 0.5)),
                       float(pl.get("threshold", 1e-4)), float(pl.get("min_lr", 0.0)), float(pl.get("eps", 1e-8)),
-                      int(bool(freeze_skips)), int(bool(freeze_input)))
+                      int(bool(freeze_skips)), int(bool(freeze_input)), int(bool(gate_logits)))
     md, gd, ld = spec.desc(), grid.desc(), _loss_desc(loss, weight_mode, ratio, c_fg, c_bg)
     rc = L.load().inrfit_fit(C.byref(md), params.data_ptr(), opt_state.data_ptr(), C.byref(gd), targets.data_ptr(),
                              C.byref(ld), C.byref(od), n_images, int(steps), int(step0),

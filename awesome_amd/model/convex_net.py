@@ -97,7 +97,7 @@ class _IcnnModule(nn.Module, PriorFitMixin):
         res = K.fit(self.spec, flat, grid, unaries, epochs, lr=float(opts.get("lr", 1e-3)), loss=kind, weight_mode=wmode, ratio=ratio,
                     optimizer=opts.get("optimizer", "adamax"), weight_decay=float(opts.get("weight_decay", 0.0)),
                     plateau=dict(patience=200, factor=0.5) if opts.get("use_plateau", True) else None, record_loss=False,
-                    want_logits=True,
+                    want_logits=True, gate_logits=True,
                     **dict(getattr(self, "fit_options", None) or dict(clamp=True)))
         return res.params, res.logits, res.status
 

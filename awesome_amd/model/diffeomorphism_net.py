@@ -282,7 +282,7 @@ class ConvexDiffeomorphismNet(nn.Module, PriorFitMixin):
                          lr=float(opts.get("lr", 0.003)), loss=kind, weight_mode=wmode, ratio=ratio,
                          weight_decay_on_weight_g=float(opts.get("weight_decay_on_weight_g", 5e-5)),
                          plateau=dict(patience=200, factor=0.5) if opts.get("use_plateau", True) else None, record_loss=False,
-                    want_logits=True)
+                    want_logits=True, gate_logits=True)
         return torch.cat([res.icnn_params, res.flow_params], 1), res.logits, res.status
 
     def _engine_warm_start(self, flat, ctx, image, opts):

@@ -249,7 +249,7 @@ class PathConnectedNet(nn.Module, PriorFitMixin):
                         optimizer=opts.get("optimizer", "adamax"), loss=kind, weight_mode=wmode, ratio=ratio,
                         flow_weight_decay=float(opts.get("flow_weight_decay", 1e-5)),
                         plateau=dict(patience=200, factor=0.5) if opts.get("use_plateau", True) else None,
-                        record_loss=False, want_logits=True)
+                        record_loss=False, want_logits=True, gate_logits=True)
         return torch.cat([res.icnn_params, res.flow_params], 1), res.logits, res.status
 
     def _non_prior_based_pretrain(self, train_set, test_set, device, agent, use_progress_bar: bool = True,

@@ -20,9 +20,10 @@ images of equal grid shape in batched device calls, gates them, re-fits the fail
 state back under its key.  With `reuse_state=True` the chain is inherently sequential: frame k starts from frame k-1's fit and
 trains `reuse_state_epochs`, exactly as in the reference.
 
-Deviations (documented, not hidden): the IoU gate reads the logits at the FINAL parameters (the reference gates on the output
-of the last training forward, one optimizer step earlier); a retry draws its fresh parameters after all first attempts of the
-batch, so the global RNG stream differs from the reference's image-by-image order from the first retry on."""
+The IoU gate reads what the reference's reads: the output of the LAST training forward (`InrOptDesc.logits_at_last_forward`; the
+stored state is the one after the last optimizer step, as in the reference).  One deviation (documented, not hidden): a retry
+draws its fresh parameters after all first attempts of the batch, so the global RNG stream differs from the reference's
+image-by-image order from the first retry on."""
 from __future__ import annotations
 
 import copy

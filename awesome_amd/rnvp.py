@@ -246,7 +246,7 @@ def pcn_fit(ispec: K.IcnnSpec, rspec: RnvpSpec, icnn_params: Tensor, flow_params
             steps: int, lr: float = 1e-3, optimizer: str = "adamax", loss: str = "se", weight_mode: str = "none",
             ratio: float = 1.0, flow_weight_decay: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8,
             plateau: Optional[dict] = None, icnn_opt_state: Optional[Tensor] = None, flow_opt_state: Optional[Tensor] = None,
-            step0: int = 0, record_loss: bool = True, want_logits: bool = True) -> PcnFitResult:
+            step0: int = 0, record_loss: bool = True, want_logits: bool = True, gate_logits: bool = False) -> PcnFitResult:
     """_prior_based_pretrain's inner loop for PathConnectedNet on the device (defaults of path_connected_net.py:756-760,
     922-933: Adamax lr 1e-3, flow weight decay 1e-5, UnariesWeightedLoss(SE); pass plateau={} for ReduceLROnPlateau(200, 0.5))."""
     ip, fp = K._check_dev(icnn_params, "icnn_params"), K._check_dev(flow_params, "flow_params")
@@ -262,7 +262,7 @@ def pcn_fit(ispec: K.IcnnSpec, rspec: RnvpSpec, icnn_params: Tensor, flow_params
     pl = plateau or {}
     od = L.InrOptDesc(L.OPT_KINDS[optimizer], float(lr), float(betas[0]), float(betas[1]), float(eps), 0.0, 1,
                       int(plateau is not None), int(pl.get("patience", 200)), float(pl.get("factor", 0.5)),
-                      float(pl.get("threshold", 1e-4)), float(pl.get("min_lr", 0.0)), float(pl.get("eps", 1e-8)))
+                      float(pl.get("threshold", 1e-4)), float(pl.get("min_lr", 0.0)), float(pl.get("eps", 1e-8)), 0, 0, int(bool(gate_logits)))
     ws = _ws(ispec, rspec, grid, n)
     md, rd, gd, ld = ispec.desc(), rspec.desc(), grid.desc(), K._loss_desc(loss, weight_mode, ratio, 0.0, 0.0)
     rc = L.load().inrfit_pcn_fit(C.byref(md), C.byref(rd), ip.data_ptr(), fp.data_ptr(), icnn_opt_state.data_ptr(),

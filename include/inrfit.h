@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define INRFIT_ABI_VERSION 3
+#define INRFIT_ABI_VERSION 4
 
 enum {
     INR_OK = 0,
@@ -116,6 +116,10 @@ typedef struct InrOptDesc {
                              the "no prior" coordinate network of configs[0]. */
     int32_t freeze_input; /* 1: input.weight / input.bias are never updated: fixed random Fourier features (buffers A, b of
                              `ourSimpleNetwork`, imageRepresentationTest.ipynb cell 5). */
+    int32_t logits_at_last_forward; /* 1: `final_logits` of the fit calls = the output of the LAST training forward, i.e. at the
+                             parameters before the last optimizer step - the tensor the reference's IoU gate reads
+                             (device_prior_output, path_connected_net.py:939-972; convex_diffeomorphism_net.py:405-438) - written
+                             by that step's launch (no extra forward launch).  0: logits at the final parameters. */
 } InrOptDesc;
 
 /* Per-image optimizer state, `opt_state` = n_images * inrfit_opt_state_floats(model) floats:

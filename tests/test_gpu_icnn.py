@@ -357,3 +357,25 @@ def test_full_fit_two_hidden_layers_matches_reference(amd, golden_dir):
     h = res.loss_hist[0].cpu().numpy()
     np.testing.assert_allclose(h[:100], z["losses"][:100], rtol=5e-4)          # same trajectory while rounding has not piled up
     assert abs(h[-1] - z["losses"][-1]) <= 0.1 * z["losses"][-1]               # and the same end point
+
+
+def test_gate_logits_are_the_last_training_forward(amd):
+    """InrOptDesc.logits_at_last_forward: the fit returns the output of its last TRAINING forward (parameters before the last
+    optimizer step) - the tensor the reference's IoU gate reads (path_connected_net.py:939-972) - instead of the logits at the
+    final parameters; the parameters themselves are the same either way."""
+    dev = torch.device("cuda:0")
+    for layers in (1, 2):
+        spec = amd.IcnnSpec(130, 2, layers)
+        torch.manual_seed(9)
+        p = {k: (torch.rand(shp) - 0.45) * 0.3 for k, shp in spec.keys_shapes()}
+        flat = amd.pack_state_dict(spec, p, dev)[None]
+        grid = amd.Grid.linspace(40, 33, dev)
+        un = (torch.rand(1, 40 * 33, device=dev) > 0.5).float()
+        four = amd.fit(spec, flat.clone(), grid, un, 4, lr=2e-3)
+        before_last = amd.forward(spec, four.params, grid)
+        five_gate = amd.fit(spec, flat.clone(), grid, un, 5, lr=2e-3, gate_logits=True)
+        five = amd.fit(spec, flat.clone(), grid, un, 5, lr=2e-3)
+        assert torch.equal(five_gate.params, five.params)
+        np.testing.assert_allclose(five_gate.logits.cpu().numpy(), before_last.cpu().numpy(), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(five.logits.cpu().numpy(), amd.forward(spec, five.params, grid).cpu().numpy(), rtol=0, atol=1e-6)
+        assert float((five.logits - five_gate.logits).abs().max()) > 1e-5      # one optimizer step apart

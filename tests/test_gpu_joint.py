@@ -94,16 +94,15 @@ class _SegStandIn(torch.nn.Module):
 
 
 def test_configs4_joint_steps_on_noisy_pseudo_labels(dev):
-    """BASELINE configs[4] in miniature (64x64 so the CPU oracle finishes in seconds; the kernels are size-agnostic and the
-    256x256 case is timed by scripts/run.py config/c5): two epochs over three noisy-blob images, every step = swap the image's
-    prior in, WrapperModule forward, FBMSJointLoss, backward, Adam, enforce_convexity.  HIP vs the oracle: losses, the shared
-    segmentation weights and every image's prior parameters."""
+    """BASELINE configs[4] at its full grid size (256x256 noisy pseudo-labels): two epochs over three images, every step = swap
+    the image's prior in, WrapperModule forward, FBMSJointLoss, backward, Adam, enforce_convexity.  HIP vs the oracle (six CPU
+    steps at 65 536 points): losses, the shared segmentation weights and every image's prior parameters."""
     from awesome_amd.agent import JointTrainer
     from awesome_amd.dataset import SyntheticPriorDataset
     from awesome_amd.measures import FBMSJointLoss
     from awesome_amd.model import ConvexNextNet, WrapperModule
     from awesome_amd.prior_bank import PriorBank
-    S, n, lr, alpha, beta = 64, 3, 2e-3, 1.0, 2.0
+    S, n, lr, alpha, beta = 256, 3, 2e-3, 1.0, 2.0
     torch.manual_seed(21)
     ds = SyntheticPriorDataset(n_images=n, size=S, kind="noisy_blob")
     items = [ds[i] for i in range(n)]                       # no prior attached: ((image, feat, xy), target)
