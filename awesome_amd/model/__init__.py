@@ -7,3 +7,4 @@ from .path_connected_net import PathConnectedNet, real_nvp_path_connected_net  #
 from .fc_net import FCNet  # noqa: F401
 from .zoo import Zoo  # noqa: F401
 from .encoded_mlp import FourierFeatureNet, SineLayerNet  # noqa: F401,E402
+from .symmetric_net import RotationSymmetricNet, polar_symmetry_features  # noqa: F401,E402

@@ -63,6 +63,12 @@ class _EncodedMLP(_IcnnModule):
     def enforce_convexity(self) -> None:   # the prior-module contract; nothing is constrained here
         return None
 
+    def reset_parameters(self) -> None:
+        """New draw of every linear layer (the retry of a failed fit, PriorFitMixin._engine_fresh_state); fixed features and poses stay."""
+        for m in self.children():
+            if isinstance(m, nn.Linear):
+                m.reset_parameters()
+
     # -- PriorFitMixin engine: state_dict <-> flat -----------------------------------------------------------------------------
     def _engine_pack(self, sd: Dict[str, torch.Tensor]) -> torch.Tensor:
         keep = {k: v.detach().clone() for k, v in self.state_dict().items()}

@@ -94,10 +94,6 @@ def main():
                          f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...` "
                          f"(or plainly, `python bench.py --gpus {args.gpus}`, which does that itself)")
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if rehearsal:
         dev = cdev = torch.device("cpu")
     else:
@@ -105,9 +101,14 @@ def main():
             raise SystemExit("bench.py needs an MI355X (the product has no CPU path)")
         if backend != "nccl":
             local_rank = local_rank % torch.cuda.device_count()
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank)           # before the process group: RCCL binds the communicator to this device
         dev = torch.device("cuda", local_rank)
         cdev = dev if backend == "nccl" else torch.device("cpu")   # where the (tiny) collective payloads live
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = dict(device_id=dev) if (backend == "nccl" and not rehearsal) else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
 
     def sync():
         if dev.type == "cuda":
@@ -116,7 +117,7 @@ def main():
     def barrier():
         sync()
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[dev.index]) if (backend == "nccl" and not rehearsal) else dist.barrier()
         sync()
 
     def max_over_ranks(x: float) -> float:

@@ -116,6 +116,27 @@ def sine_net_forward(sd: Dict[str, Tensor], x: Tensor) -> Tensor:
     return F.linear(torch.sin(z), sd["W2.weight"], sd["W2.bias"])
 
 
+def rotation_symmetric_features(x: Tensor, offset: Tensor, orientation: Tensor, symmetry_prior: bool) -> Tensor:
+    """First half of `myNet.forward` (icml_teaser_code/rotation_symmetric/rotation_symmetric.ipynb cell 2): centre, polar split,
+    rotate by `orientation`, mirror the second direction component (the symmetry prior) -> (N, 3) = [direction, radius]."""
+    x = x + offset
+    r = (x * x).sum(1, keepdim=True).sqrt()
+    x = x / (0.001 + r)
+    c, s = torch.cos(orientation), torch.sin(orientation)
+    u, v = x[:, 0] * c - x[:, 1] * s, x[:, 0] * s + x[:, 1] * c
+    if symmetry_prior:
+        v = v.abs()
+    return torch.stack((u, v, r[:, 0]), 1)
+
+
+def rotation_symmetric_forward(sd: Dict[str, Tensor], x: Tensor, symmetry_prior: bool) -> Tensor:
+    """`myNet.forward` of the same cell: W2(relu(W1(relu(W0([direction, radius])))))."""
+    z = rotation_symmetric_features(x, sd["offset"], sd["orientation"], symmetry_prior)
+    z = F.relu(F.linear(z, sd["W0.weight"], sd["W0.bias"]))
+    z = F.relu(F.linear(z, sd["W1.weight"], sd["W1.bias"]))
+    return F.linear(z, sd["W2.weight"], sd["W2.bias"])
+
+
 def icnn_forward(p: Dict[str, Tensor], x: Tensor, act0: str = "relu", omega: float = 1.0) -> Tensor:
     """ConvexNextNet.forward (convex_net.py:205-214) on (N,C) rows -> (N,1) logits; `act0`: layer 0's activation (encode_layer)."""
     x_in = x

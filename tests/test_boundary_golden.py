@@ -158,3 +158,37 @@ def test_oracle_encode_stage_matches_the_notebook_classes(golden_dir):
     xs = torch.from_numpy(z["sine.x"])
     pre = torch.nn.functional.linear(xs + sds["offset"], sds["W1.weight"], sds["W1.bias"])
     np.testing.assert_allclose(O.encode_layer(pre, "sin", 10 * 3.141592).numpy(), torch.sin(10 * 3.141592 * pre).numpy(), rtol=0, atol=0)
+
+
+def test_oracle_rotation_symmetric_net_matches_the_notebook_class(golden_dir):
+    """The rotational-symmetry teaser network (rotation_symmetric.ipynb cell 2) restated in the oracle against the notebook's own
+    class executed in the build container (tests/golden/teaser_rotation_symmetric.npz): outputs with and without the symmetry
+    prior, input gradients, gradients of every parameter (offset and orientation included), and 8 full-batch Adam steps of the
+    notebook's loss."""
+    z = _z(golden_dir, "teaser_rotation_symmetric.npz")
+    x0 = torch.from_numpy(z["x"])
+    for tag, sp in (("free", False), ("sym", True)):
+        sd = {k[3:]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith("sd.")}
+        x = x0.clone().requires_grad_(True)
+        y = O.rotation_symmetric_forward(sd, x, sp)
+        np.testing.assert_allclose(y.detach().numpy(), z[tag + ".y"], rtol=1e-5, atol=1e-6)
+        (torch.sigmoid(y) ** 2).mean().backward()
+        np.testing.assert_allclose(x.grad.numpy(), z[tag + ".dx"], rtol=1e-4, atol=1e-8)
+        for k, v in sd.items():
+            np.testing.assert_allclose(v.grad.numpy(), z[f"{tag}.grad.{k}"], rtol=1e-4, atol=1e-8, err_msg=k)
+    sd = {k[3:]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith("sd.")}
+    labels = torch.from_numpy(z["labels"])
+    back, fore = labels < 0.5, labels > 0.5
+    opt = torch.optim.Adam(list(sd.values()), lr=1e-3)
+    losses = []
+    for _ in range(8):
+        ob = torch.sigmoid(O.rotation_symmetric_forward(sd, x0[back], True)).squeeze()
+        of = torch.sigmoid(O.rotation_symmetric_forward(sd, x0[fore], True)).squeeze()
+        loss = 2 * ((ob - labels[back]) ** 2).mean() + ((of - labels[fore]) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    np.testing.assert_allclose(losses, z["adam8.loss"], rtol=1e-5)
+    for k, v in sd.items():
+        np.testing.assert_allclose(v.detach().numpy(), z["adam8.sd." + k], rtol=1e-4, atol=2e-6, err_msg=k)

@@ -240,6 +240,52 @@ def gen_encode_notebooks(out):
     print("encode notebooks", rec["fourier.y"].shape, rec["sine.y"].shape)
 
 
+def gen_teaser_rotation_symmetric(out):
+    """The rotational-symmetry teaser network, run as written in its notebook: outputs with and without the symmetry
+    prior, gradients of every parameter (pose included) and of the input, and a short full-batch Adam trajectory of the notebook's
+    loss (2 MSE(background) + MSE(foreground) on sigmoid outputs) on a mirror-symmetric shape."""
+    Net = _notebook_class("notebooks/icml_teaser_code/rotation_symmetric/rotation_symmetric.ipynb", 2, "myNet")
+    seed_all(53)
+    net = Net(130)
+    with torch.no_grad():
+        net.offset.copy_(torch.tensor([[0.04, -0.06]]))
+        net.orientation.fill_(0.3)
+    rec = {}
+    rec.update(sd_np(net, "sd."))
+    ii, jj = torch.meshgrid(torch.arange(0, 20), torch.arange(0, 18), indexing="ij")
+    x = torch.stack([ii.reshape(-1) / 20 - 0.5, jj.reshape(-1) / 18 - 0.5], 1).float()            # cell 3: indices / n - 0.5
+    rec["x"] = x.numpy()
+    for sp in (False, True):
+        xr = x.clone().requires_grad_(True)
+        net.zero_grad()
+        y = net(xr, sp)
+        (torch.sigmoid(y) ** 2).mean().backward()
+        tag = "sym" if sp else "free"
+        rec[f"{tag}.y"], rec[f"{tag}.dx"] = y.detach().numpy(), xr.grad.numpy().copy()
+        rec.update({f"{tag}.grad.{k}": p.grad.detach().numpy().copy() for k, p in net.named_parameters()})
+    # a heart-like shape, mirror-symmetric about an axis that is neither of the image axes and off-centre
+    ang, cx, cy = 0.6, 0.05, -0.03
+    u = (x[:, 0] - cx) * np.cos(ang) + (x[:, 1] - cy) * np.sin(ang)
+    v = -(x[:, 0] - cx) * np.sin(ang) + (x[:, 1] - cy) * np.cos(ang)
+    labels = (((u / 0.3) ** 2 + ((v.abs() - 0.08) / 0.16) ** 2) < 1.0).float()
+    rec["labels"] = labels.numpy()
+    back, fore = labels < 0.5, labels > 0.5
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    crit = torch.nn.MSELoss()
+    losses = []
+    for _ in range(8):
+        ob, of = torch.sigmoid(net(x[back], True)).squeeze(), torch.sigmoid(net(x[fore], True)).squeeze()
+        loss = 2 * crit(ob, labels[back]) + 1 * crit(of, labels[fore])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    rec["adam8.loss"] = np.asarray(losses, np.float32)
+    rec.update(sd_np(net, "adam8.sd."))
+    np.savez_compressed(os.path.join(out, "teaser_rotation_symmetric.npz"), **rec)
+    print("teaser rotation symmetric", rec["sym.y"].shape, losses[0], losses[-1], net.orientation.item(), net.offset.tolist())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
@@ -248,6 +294,7 @@ def main():
     torch.set_num_threads(4)
     ref = _import_reference()
     gen_encode_notebooks(args.out)
+    gen_teaser_rotation_symmetric(args.out)
     gen_fbms_joint_loss(ref, args.out)
     gen_wrapper(ref, args.out)
     gen_prior_cache(ref, args.out)
