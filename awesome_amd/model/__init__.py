@@ -8,3 +8,4 @@ from .fc_net import FCNet  # noqa: F401
 from .zoo import Zoo  # noqa: F401
 from .encoded_mlp import FourierFeatureNet, SineLayerNet  # noqa: F401,E402
 from .symmetric_net import RotationSymmetricNet, polar_symmetry_features  # noqa: F401,E402
+from .star_net import StarShapedNet  # noqa: F401,E402

@@ -17,9 +17,8 @@ reaches the pose.  Two ways to train, both on the MI355X path:
   * `fit(coords, targets, steps)`: the fused `inrfit_fit` of the network under the current, fixed pose - and
     `fit_alternating`, which interleaves it with pose steps through autograd.
 
-Only the kernels' widths are available (n_hidden in {32, 64, 130}; the notebook used 150).  The star-shaped prior of the same folder
-(star.ipynb: output r * (W2 x_old + W2_r r_aug) - 1, read-out from two layers) does not fit the step kernels' layer shape and is not
-built."""
+Only the kernels' widths are available (n_hidden in {32, 64, 130}; the notebook used 150).  The star-shape prior of the same folder
+is awesome_amd/model/star_net.py."""
 from __future__ import annotations
 
 from typing import Dict, List, Optional

@@ -137,6 +137,16 @@ def rotation_symmetric_forward(sd: Dict[str, Tensor], x: Tensor, symmetry_prior:
     return F.linear(z, sd["W2.weight"], sd["W2.bias"])
 
 
+def star_shaped_forward(sd: Dict[str, Tensor], x: Tensor) -> Tensor:
+    """`myNet.forward` (icml_teaser_code/star_shaped/star.ipynb cell 2): r * (W2 x_old + W2_r relu(W1 x_old + W1_r r)) - 1 with
+    x_old = relu(W0 (x / (0.01 + r))), r = |x + offset|."""
+    x = x + sd["offset"]
+    r = (x * x).sum(1, keepdim=True).sqrt()
+    x_old = F.relu(F.linear(x / (0.01 + r), sd["W0.weight"], sd["W0.bias"]))
+    r_aug = F.relu(F.linear(x_old, sd["W1.weight"], sd["W1.bias"]) + F.linear(r, sd["W1_r.weight"], sd["W1_r.bias"]))
+    return r * (F.linear(x_old, sd["W2.weight"], sd["W2.bias"]) + F.linear(r_aug, sd["W2_r.weight"], sd["W2_r.bias"])) - 1
+
+
 def icnn_forward(p: Dict[str, Tensor], x: Tensor, act0: str = "relu", omega: float = 1.0) -> Tensor:
     """ConvexNextNet.forward (convex_net.py:205-214) on (N,C) rows -> (N,1) logits; `act0`: layer 0's activation (encode_layer)."""
     x_in = x

@@ -192,3 +192,33 @@ def test_oracle_rotation_symmetric_net_matches_the_notebook_class(golden_dir):
     np.testing.assert_allclose(losses, z["adam8.loss"], rtol=1e-5)
     for k, v in sd.items():
         np.testing.assert_allclose(v.detach().numpy(), z["adam8.sd." + k], rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+def test_oracle_star_shaped_net_matches_the_notebook_class(golden_dir):
+    """The star-shape teaser network (star.ipynb cell 2) restated in the oracle against the notebook's own class
+    (tests/golden/teaser_star_shaped.npz): outputs, input gradients, all parameter gradients, 8 Adam steps + W2_r projection."""
+    z = _z(golden_dir, "teaser_star_shaped.npz")
+    x0 = torch.from_numpy(z["x"])
+    sd = {k[3:]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith("sd.")}
+    x = x0.clone().requires_grad_(True)
+    y = O.star_shaped_forward(sd, x)
+    np.testing.assert_allclose(y.detach().numpy(), z["y"], rtol=1e-5, atol=1e-6)
+    (torch.sigmoid(y) ** 2).mean().backward()
+    np.testing.assert_allclose(x.grad.numpy(), z["dx"], rtol=1e-4, atol=1e-8)
+    for k, v in sd.items():
+        np.testing.assert_allclose(v.grad.numpy(), z["grad." + k], rtol=1e-4, atol=1e-8, err_msg=k)
+    sd = {k[3:]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith("sd.")}
+    labels = torch.from_numpy(z["labels"])
+    opt = torch.optim.Adam(list(sd.values()), lr=1e-2)
+    losses = []
+    for _ in range(8):
+        loss = ((torch.sigmoid(O.star_shaped_forward(sd, x0)).squeeze() - labels) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            sd["W2_r.weight"].clamp_(min=0)
+        losses.append(float(loss.detach()))
+    np.testing.assert_allclose(losses, z["adam8.loss"], rtol=1e-4)
+    for k, v in sd.items():
+        np.testing.assert_allclose(v.detach().numpy(), z["adam8.sd." + k], rtol=1e-3, atol=1e-5, err_msg=k)

@@ -1,6 +1,7 @@
-"""GPU parity of the rotational-symmetry teaser prior (awesome_amd/model/symmetric_net.py): the module - pose in
-torch on the device, the 3 -> h -> h -> 1 network on the fused HIP kernels - against the notebook's own class
-(tests/golden/teaser_rotation_symmetric.npz) and against the oracle's loop.  fp32: logits 1e-5 absolute, gradients 2e-4 relative
+"""GPU parity of the teaser priors: rotational / mirror symmetry (awesome_amd/model/symmetric_net.py: pose in torch
+on the device, the 3 -> h -> h -> 1 network on the fused HIP kernels) and star shape (awesome_amd/model/star_net.py: two chains of
+the same kernels sharing W0) against the notebooks' own classes (tests/golden/teaser_rotation_symmetric.npz, teaser_star_shaped.npz)
+and against the oracle's loop.  fp32: logits 1e-5 absolute, gradients 2e-4 relative
 (of the tensor maximum), 8-step Adam trajectory 1e-4."""
 import os
 
@@ -123,3 +124,87 @@ def test_alternating_fit_finds_the_mirror_axis(dev):
         np.testing.assert_allclose(m(x_mirror).cpu().numpy(), logits.cpu().numpy(), atol=2e-3)
     iou = lambda a, b: float(((a > 0.5) & (b > 0.5)).sum()) / float(((a > 0.5) | (b > 0.5)).sum())  # noqa: E731
     assert iou(pred, clean) > iou(noisy, clean) - 0.02 and iou(pred, clean) > 0.85, (iou(pred, clean), iou(noisy, clean))
+
+
+# ---- star-shape prior (awesome_amd/model/star_net.py) ------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def zs(golden_dir):
+    return np.load(os.path.join(golden_dir, "teaser_star_shaped.npz"))
+
+
+def _star(zs, dev):
+    from awesome_amd.model import StarShapedNet
+    m = StarShapedNet(130)
+    m.load_state_dict({k[3:]: torch.from_numpy(zs[k]) for k in zs.files if k.startswith("sd.")})
+    m.offset.requires_grad = True
+    return m.to(dev)
+
+
+def test_star_forward_and_all_gradients_match_the_notebook_class(dev, zs):
+    m = _star(zs, dev)
+    x = torch.from_numpy(zs["x"]).to(dev).requires_grad_(True)
+    y = m(x)
+    assert y.shape == (x.shape[0], 1)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), zs["y"], rtol=1e-5, atol=1e-5)
+    (torch.sigmoid(y) ** 2).mean().backward()
+    chk = lambda got, ref, name: np.testing.assert_allclose(  # noqa: E731
+        got.cpu().numpy(), ref, rtol=2e-4, atol=2e-4 * float(np.abs(ref).max()) + 1e-9, err_msg=name)
+    chk(x.grad, zs["dx"], "dx")
+    for k, p in m.named_parameters():
+        chk(p.grad, zs["grad." + k], k)     # W0 is shared by the two kernel chains: its gradient is their sum
+
+
+def test_star_notebook_training_loop_through_autograd(dev, zs):
+    """8 full-batch Adam steps (lr 1e-2) of the notebook's loop - MSE on sigmoid outputs, then W2_r.weight <- relu(W2_r.weight) -
+    over all parameters, the centre included, against the recorded trajectory of the notebook's class."""
+    m = _star(zs, dev)
+    x, labels = torch.from_numpy(zs["x"]).to(dev), torch.from_numpy(zs["labels"]).to(dev)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    losses = []
+    for _ in range(8):
+        loss = ((torch.sigmoid(m(x)).squeeze() - labels) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        m.enforce_star_shape()
+        losses.append(float(loss.detach()))
+    np.testing.assert_allclose(losses, zs["adam8.loss"], rtol=2e-4)
+    assert float(m.W2_r.weight.detach().min()) >= 0.0
+    for k, v in m.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), zs["adam8.sd." + k], rtol=2e-3, atol=1e-4, err_msg=k)
+
+
+def test_star_net_fits_a_non_convex_star_and_stays_star_shaped(dev):
+    """The teaser's use: a five-armed star (not convex).  Minibatch Adam as in the notebook; the fitted region {out < 0} covers the
+    star and is star-shaped about the centre: along (nearly) every ray from -offset, once outside always outside."""
+    from awesome_amd.model import StarShapedNet
+    torch.manual_seed(9)
+    S = 64
+    ii, jj = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+    x = torch.stack([(ii.reshape(-1) + 0.5) / S - 0.5, (jj.reshape(-1) + 0.5) / S - 0.5], 1).float().to(dev)
+    rad, phi = (x ** 2).sum(1).sqrt(), torch.atan2(x[:, 1], x[:, 0])
+    inside = (rad < 0.24 + 0.11 * torch.cos(5 * phi)).float()
+    labels = 1 - inside
+    m = StarShapedNet(130).to(dev)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    for _ in range(400):
+        idx = torch.randperm(x.shape[0], device=dev)[:1000]
+        loss = ((torch.sigmoid(m(x[idx])).squeeze() - labels[idx]) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        m.enforce_star_shape()
+    with torch.no_grad():
+        pred_in = (m(x)[:, 0] < 0).float()
+        iou = float((pred_in * inside).sum() / ((pred_in + inside) > 0).float().sum())
+        assert iou > 0.8, iou
+        # rays from the centre (offset is frozen at 0 here): out along a ray changes sign at most once, from inside to outside
+        t = torch.linspace(0.01, 0.7, 200, device=dev)
+        ang = torch.linspace(0, 2 * np.pi, 91, device=dev)[:-1]
+        pts = torch.stack((t[None, :] * torch.cos(ang)[:, None], t[None, :] * torch.sin(ang)[:, None]), -1).reshape(-1, 2)
+        out = m(pts)[:, 0].reshape(90, 200)
+        outside = (out >= 0).int()
+        reenter = ((outside[:, 1:] - outside[:, :-1]).min(1).values < 0).float().mean()
+        # (the architecture makes the bracket convex in r, W2_r >= 0; monotone only where W1_r >= 0, which the notebook does not
+        # project - so this is a property of the trained network, checked with a small allowance)
+        assert float(reenter) <= 0.05, f"{float(reenter):.3f} of the rays re-enter the region: not star-shaped"

@@ -286,6 +286,49 @@ def gen_teaser_rotation_symmetric(out):
     print("teaser rotation symmetric", rec["sym.y"].shape, losses[0], losses[-1], net.orientation.item(), net.offset.tolist())
 
 
+def gen_teaser_star_shaped(out):
+    """The star-shape teaser network, run as written in its notebook: outputs, gradients of every parameter (the
+    centre included) and of the input, and a short full-batch Adam trajectory of the notebook's loop (MSE on sigmoid outputs, then the
+    projection W2_r.weight <- relu(W2_r.weight)) on a star-shaped, non-convex target."""
+    Net = _notebook_class("notebooks/icml_teaser_code/star_shaped/star.ipynb", 2, "myNet")
+    seed_all(54)
+    net = Net(130)
+    with torch.no_grad():
+        net.offset.copy_(torch.tensor([[-0.03, 0.05]]))
+    net.offset.requires_grad = True                                                               # cell 3 frees it at epoch 1000
+    rec = {}
+    rec.update(sd_np(net, "sd."))
+    ii, jj = torch.meshgrid(torch.arange(0, 20), torch.arange(0, 18), indexing="ij")
+    x = torch.stack([ii.reshape(-1) / 19 - 0.5, jj.reshape(-1) / 17 - 0.5], 1).float()            # cell 3: indices / (n - 1) - 0.5
+    rec["x"] = x.numpy()
+    xr = x.clone().requires_grad_(True)
+    y = net(xr)
+    (torch.sigmoid(y) ** 2).mean().backward()
+    rec["y"], rec["dx"] = y.detach().numpy(), xr.grad.numpy().copy()
+    rec.update({f"grad.{k}": p.grad.detach().numpy().copy() for k, p in net.named_parameters()})
+    # a five-armed star about (0.03, -0.05): inside <=> radius below a bound that depends on the direction
+    dx, dy = x[:, 0] - 0.03, x[:, 1] + 0.05
+    rad, phi = (dx ** 2 + dy ** 2).sqrt(), torch.atan2(dy, dx)
+    inside = (rad < 0.22 + 0.12 * torch.cos(5 * phi)).float()
+    labels = 1 - inside                                                                            # cell 3: labels = 1 - likelihood
+    rec["labels"] = labels.numpy()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    crit = torch.nn.MSELoss()
+    losses = []
+    for _ in range(8):
+        loss = crit(torch.sigmoid(net(x)).squeeze(), labels)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            net.W2_r.weight.data = torch.nn.functional.relu(net.W2_r.weight.data)
+        losses.append(float(loss.detach()))
+    rec["adam8.loss"] = np.asarray(losses, np.float32)
+    rec.update(sd_np(net, "adam8.sd."))
+    np.savez_compressed(os.path.join(out, "teaser_star_shaped.npz"), **rec)
+    print("teaser star shaped", rec["y"].shape, losses[0], losses[-1], net.offset.tolist(), float((net.W2_r.weight == 0).float().mean()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
@@ -295,6 +338,7 @@ def main():
     ref = _import_reference()
     gen_encode_notebooks(args.out)
     gen_teaser_rotation_symmetric(args.out)
+    gen_teaser_star_shaped(args.out)
     gen_fbms_joint_loss(ref, args.out)
     gen_wrapper(ref, args.out)
     gen_prior_cache(ref, args.out)
