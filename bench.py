@@ -18,6 +18,7 @@ Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (icnn_step
 stream.  `cpu_baseline` times the CPU oracle (torch, all host threads) on a bounded sample (rank 0, N = 1 only).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -71,6 +72,24 @@ def launch_ranks(args):
     return proc.returncode
 
 
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """File-descriptor level (C libraries included): everything written to stdout inside the block goes to stderr."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -104,11 +123,16 @@ def main():
         torch.cuda.set_device(local_rank)           # before the process group: RCCL binds the communicator to this device
         dev = torch.device("cuda", local_rank)
         cdev = dev if backend == "nccl" else torch.device("cpu")   # where the (tiny) collective payloads live
-    if world > 1:
+    # BENCH_FORCE_DIST=1: create the process group and run every collective even at WORLD_SIZE 1 - the RCCL code path of this file
+    # (device-bound init, barrier, all_reduce / all_gather on device tensors) on a one-GPU box.
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST", "0") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         kw = dict(device_id=dev) if (backend == "nccl" and not rehearsal) else {}
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        with _stdout_to_stderr():   # RCCL prints a version banner on stdout when the communicator is created; stdout carries the JSON line only
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+            (dist.barrier(device_ids=[dev.index]) if kw else dist.barrier())
 
     def sync():
         if dev.type == "cuda":
@@ -116,19 +140,19 @@ def main():
 
     def barrier():
         sync()
-        if world > 1:
+        if dist is not None:
             dist.barrier(device_ids=[dev.index]) if (backend == "nccl" and not rehearsal) else dist.barrier()
         sync()
 
     def max_over_ranks(x: float) -> float:
-        if world == 1:
+        if dist is None:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def sum_over_ranks(n: int) -> int:
-        if world == 1:
+        if dist is None:
             return n
         t = torch.tensor([n], dtype=torch.int64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -136,7 +160,7 @@ def main():
 
     def gather_cat(v):
         """the only data collective: a few bytes of per-image metrics"""
-        if world == 1:
+        if dist is None:
             return v
         vc = v.to(cdev)
         parts = [torch.zeros_like(vc) for _ in range(world)]
@@ -170,7 +194,7 @@ def main():
                               "rehearsal": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": round(elapsed / args.steps * 1e3, 3), "gathered_image_seeds": iou_all.tolist(),
                               "nonfinite_fits": bad, "backend": backend}), flush=True)
-        if world > 1:
+        if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -320,8 +344,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, init[0].cpu(), unaries[0].cpu(), spec)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
+    if dist is not None:
+        barrier()
         dist.destroy_process_group()
 
 
