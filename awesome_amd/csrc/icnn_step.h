@@ -117,6 +117,28 @@ struct Cfg {
     static constexpr int P_BO = P_WO + H;
     static constexpr int P_SO = P_BO + 1;
     static constexpr int P = P_SO + C;
+
+    // ---- gradient slab (one per workgroup and step; read by icnn_update_kernel through slab_param_of_col) ------------
+    // [0, SL_TILE): the dW1ext accumulator tiles exactly as the matrix pipe leaves them - tile (row tile rt, column tile b), lane, register
+    // r <-> row 16 rt + 4 (lane >> 4) + r, column position 16 b + (lane & 15) - so every lane stores ONE 16-byte vector per tile (72
+    // global_store_dwordx4 per lane instead of 288 dword stores: the 17 MB of slabs per launch leave 1.1 us sooner).
+    // Then every parameter the tiles do not carry, in parameter order (W_in, b_in | leftover rows of W1, b1, S1 | w_o, b_o, s_o), then the
+    // loss partial.  The ORDER in which slabs are summed is untouched, so results are bit-identical to the parameter-ordered layout.
+    static constexpr int SL_TILE = TM * KG * 256;
+    static constexpr int SL_W1L = SL_TILE + P_W1;
+    static constexpr int SL_B1L = SL_W1L + HR * H;
+    static constexpr int SL_S1L = SL_B1L + HR;
+    static constexpr int SL_WO = SL_S1L + HR * C;
+    static constexpr int SL_LOSS = SL_WO + (P - P_WO);
+    static constexpr int SL_COLS = SL_LOSS + 1;
+    // parameter j (or P = the loss) -> slab column, for everything outside the tiles
+    __host__ __device__ static constexpr int slab_col(int j) {
+        return j < P_W1 ? SL_TILE + j
+             : j < P_B1 ? SL_W1L + (j - P_W1 - HM * H)
+             : j < P_S1 ? SL_B1L + (j - P_B1 - HM)
+             : j < P_WO ? SL_S1L + (j - P_S1 - HM * C)
+                        : SL_WO + (j - P_WO);
+    }
 };
 
 // run-time description of the parameter image (same numbers as Cfg<H,C> / Cfg2<H,C>) for the untemplated kernels
@@ -127,7 +149,38 @@ struct ImgMap {
     int ext[4];
     int p_bin, p_wo, p_bo, p_so, P;
     int p_w[2], p_b[2], p_s[2]; // flat offsets of skip.k.ln.weight / ln.bias / skp.weight
+    int sl_tile;                // gradient slab: floats of the tile region (Cfg::SL_TILE), 0 = columns are parameters (L = 2 kernels)
+    int sl_cols;                // gradient slab: columns in use (Cfg::SL_COLS, or P + 1)
+    int KG, kg_magic;           // column tiles per row tile; 65536 / KG + 1 (tile index / KG without a division: exact below 2^13)
 };
+
+// Gradient slab column -> flat parameter index (P = the loss partial, -1 = padding); the inverse of the step kernel's stores.
+// Straight-line selects on fields read with constant indices: it sits in front of the update kernel's first loads.
+__device__ __forceinline__ int slab_param_of_col(const ImgMap& m, int col) {
+    const int H = m.H, HM = m.HM, C = m.C, KG = m.KG, kgm = m.kg_magic, T = m.sl_tile, pw = m.p_w[0], pb = m.p_b[0], ps = m.p_s[0];
+    const int e0 = m.ext[0], e1 = m.ext[1], e2 = m.ext[2], e3 = m.ext[3], pwo = m.p_wo, ncols = m.sl_cols;
+    // tile region
+    const int r = col & 3, lane = (col >> 2) & 63, tb = col >> 8;
+    const int rt = (tb * kgm) >> 16, b = tb - rt * KG;
+    const int o = 16 * rt + 4 * (lane >> 4) + r, pos = 16 * b + (lane & 15);
+    int tile = -1;
+    tile = (pos == e3 && C > 2) ? ps + o * C + 2 : tile;
+    tile = (pos == e2 && C > 1) ? ps + o * C + 1 : tile;
+    tile = pos == e1 ? ps + o * C : tile;
+    tile = pos == e0 ? pb + o : tile;
+    tile = pos < H ? pw + o * H + pos : tile;
+    // rest region: W_in, b_in | leftover rows of W1 | of b1 | of S1 | w_o, b_o, s_o, loss
+    const int HR = H - HM, c = col - T;
+    const int c1 = c - pw, c2 = c1 - HR * H, c3 = c2 - HR, c4 = c3 - HR * C;
+    int rest = pwo + c4;
+    rest = c4 < 0 ? ps + HM * C + c3 : rest;
+    rest = c3 < 0 ? pb + HM + c2 : rest;
+    rest = c2 < 0 ? pw + HM * H + c1 : rest;
+    rest = c1 < 0 ? c : rest;
+    int res = col < T ? tile : rest;
+    res = T == 0 ? col : res;           // parameter-ordered slabs (L = 2 kernels)
+    return col < ncols ? res : -1;
+}
 
 // Image slots of flat parameter j: every parameter has a primary slot; W_in/b_in of the leftover units and
 // W_k[:, HM+u] are mirrored into a second table.  Returns the number of slots (1 or 2).
@@ -227,13 +280,8 @@ __device__ __forceinline__ float sum_over_groups(float v) {  // the 4 lanes shar
 #endif
 // Keep successive k-steps of MFMAs in program order (everything else may still move across): without it hipcc regroups
 // the products per accumulator, i.e. into dependent chains that pay the 40-cycle latency instead of the 32-cycle issue.
-#ifndef INR_NT_SLAB
-#define INR_NT_SLAB 0
-#endif
-#if INR_NT_SLAB
-#define SLAB_ST(ptr, v) __builtin_nontemporal_store((v), (ptr))
-#else
-#define SLAB_ST(ptr, v) (*(ptr) = (v))
+#ifndef INR_SLAB_NT
+#define INR_SLAB_NT 1   // the slab tiles are written once and read once by another kernel: non-temporal stores (A/B in DESIGN.md 6)
 #endif
 #ifndef INR_MFMA_ORDER
 #define INR_MFMA_ORDER 1
@@ -820,32 +868,25 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
 
     if (TRAIN) {
         float* __restrict__ slab = a.slabs + ((size_t)img * a.wgs + wg) * a.PS;
-        // ---- dW1ext / layer-0 tiles of this wave ---------------------------------------------------------------------
+        // ---- dW1ext tiles of this wave: one 16-byte store per lane and tile, in accumulator order (Cfg: gradient slab) --------
         if (row_ok) {
 #pragma unroll
             for (int j = 0; j < RPW; ++j) {
-                const int o0 = 16 * (wave * RPW + j) + 4 * g;  // first of this lane's 4 rows
 #pragma unroll
                 for (int b = 0; b < KG; ++b) {
-                    const int pos = 16 * b + l15;
-                    int off = -1, rs = 0;
-                    if (pos < H) {
-                        off = G::P_W1 + pos;
-                        rs = H;
-                    } else if (pos == G::ext_pos(0)) {
-                        off = G::P_B1;
-                        rs = 1;
-                    } else {
+                    bool used = true;   // the last column tile holds the leftover units and the ext inputs only: skip its padding
+                    if (b == KG - 1) {
+                        used = l15 < HR;
 #pragma unroll
-                        for (int c = 0; c < C; ++c)
-                            if (pos == G::ext_pos(1 + c)) {
-                                off = G::P_S1 + c;
-                                rs = C;
-                            }
+                        for (int e = 0; e < NEXT; ++e) used = used || (HM + l15 == G::ext_pos(e));
                     }
-                    if (off >= 0) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) SLAB_ST(&slab[off + (o0 + r) * rs], dW[j][b][r]);
+                    if (used) {
+                        f32x4* dst = (f32x4*)(slab + ((((wave * RPW + j) * KG + b) * 64 + lane) << 2));
+#if INR_SLAB_NT
+                        __builtin_nontemporal_store(dW[j][b], dst);
+#else
+                        *dst = dW[j][b];
+#endif
                     }
                 }
             }
@@ -907,35 +948,35 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
         }
         __syncthreads();
         auto wsum = [&](int i) { return ((stA[i] + stA[WSTR + i]) + stA[2 * WSTR + i]) + stA[3 * WSTR + i]; };
-        for (int i = tid; i < H; i += WG_THREADS) slab[G::P_WO + i] = wsum(SC_DWO + i);
+        for (int i = tid; i < H; i += WG_THREADS) slab[G::SL_WO + i] = wsum(SC_DWO + i);
         for (int i = tid; i < HR * PT; i += WG_THREADS) {
             const int u = i / PT, pos = i - u * PT;
             const float v = wsum(SC_DWL + i);
-            if (pos < H) slab[G::P_W1 + (HM + u) * H + pos] = v;
-            else if (pos == G::ext_pos(0)) slab[G::P_B1 + HM + u] = v;
+            if (pos < H) slab[G::SL_W1L + u * H + pos] = v;
+            else if (pos == G::ext_pos(0)) slab[G::SL_B1L + u] = v;
             else {
 #pragma unroll
                 for (int c = 0; c < C; ++c)
-                    if (pos == G::ext_pos(1 + c)) slab[G::P_S1 + (HM + u) * C + c] = v;
+                    if (pos == G::ext_pos(1 + c)) slab[G::SL_S1L + u * C + c] = v;
             }
         }
         for (int i = tid; i < HM * NEXT; i += WG_THREADS) {
             const int row = i / NEXT, e = i - row * NEXT;
             const float v = wsum(SC_L0 + row * 4 + e);
-            if (e == 0) slab[G::P_BIN + row] = v;
-            else slab[G::P_WIN + row * C + (e - 1)] = v;
+            if (e == 0) slab[G::SL_TILE + G::P_BIN + row] = v;
+            else slab[G::SL_TILE + G::P_WIN + row * C + (e - 1)] = v;
         }
         if (tid < HR * NEXT) {
             const int u = tid / NEXT, e = tid - u * NEXT;
             const float v = wsum(SC_L0L + u * 4 + e);
-            if (e == 0) slab[G::P_BIN + HM + u] = v;
-            else slab[G::P_WIN + (HM + u) * C + (e - 1)] = v;
+            if (e == 0) slab[G::SL_TILE + G::P_BIN + HM + u] = v;
+            else slab[G::SL_TILE + G::P_WIN + (HM + u) * C + (e - 1)] = v;
         }
         if (tid < 2 + C) {
             const float v = wsum(SC_SC + tid);
-            if (tid == 0) slab[G::P] = v;  // loss partial
-            else if (tid == 1) slab[G::P_BO] = v;
-            else slab[G::P_SO + tid - 2] = v;
+            if (tid == 0) slab[G::SL_LOSS] = v;  // loss partial
+            else if (tid == 1) slab[G::slab_col(G::P_BO)] = v;
+            else slab[G::slab_col(G::P_SO) + tid - 2] = v;
         }
     }
 #if INR_STAMPS

@@ -44,7 +44,7 @@ struct UpdArgs {
     float* loss_out;      // mode 1: [n_images]
     int32_t* status;      // [n_images] or null
     InrOptDesc opt;
-    int P, PS, wgs, n_images;
+    int P, PS, wgs, n_images;   // PS: slab stride in floats; the slab's column layout is img.sl_* (icnn_step.h, Cfg: gradient slab)
     int t;                // 1-based optimizer step index
     double bc1;           // 1 - beta1^t
     float bc2_sqrt;       // sqrt(1 - beta2^t)
@@ -56,20 +56,23 @@ struct UpdArgs {
     int input_hi;                    // opt.freeze_input: flat range [0, input_hi) = input.weight | input.bias is never updated
 };
 
+#ifndef INR_UPD_PERM
+#define INR_UPD_PERM 0
+#endif
 constexpr int UPD_MAX_PARAMS = 256;  // most parameters per block
 constexpr int UPD_GROUPS = 16;       // slab groups summed in parallel, then combined in fixed order
 
 // Parameters per block: a CU pulls ~10 B/clock from memory whatever runs on it, so the reduction is as fast as its busiest
 // CU: one block per CU, all equally long (17 814 parameters -> 248 blocks of 72), instead of 279 blocks of 64 with 23 CUs
 // doing double duty.  Multiple of 4 (float4 loads), x n_images blocks when there are many images.
-inline int upd_params_per_block(int P) {
-    int ppb = ((P + 1 + 255) / 256 + 3) / 4 * 4;
+inline int upd_params_per_block(int cols) {   // cols = slab columns in use (P + 1 in the parameter-ordered layout)
+    int ppb = ((cols + 255) / 256 + 3) / 4 * 4;
     if (ppb < 16) ppb = 16;
     if (ppb > UPD_MAX_PARAMS) ppb = UPD_MAX_PARAMS;
     return ppb;
 }
-inline dim3 upd_grid(int P, int n_images) { const int ppb = upd_params_per_block(P); return dim3((P + 1 + ppb - 1) / ppb, n_images); }
-inline dim3 upd_block(int P) { return dim3(upd_params_per_block(P) / 4, UPD_GROUPS); }
+inline dim3 upd_grid(int cols, int n_images) { const int ppb = upd_params_per_block(cols); return dim3((cols + ppb - 1) / ppb, n_images); }
+inline dim3 upd_block(int cols) { return dim3(upd_params_per_block(cols) / 4, UPD_GROUPS); }
 
 // block = (blockDim.x lanes x float4 = ppb parameters) x 16 slab groups
 __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_kernel(const UpdArgs u) {
@@ -78,15 +81,24 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
     const int ppb = 4 * blockDim.x;
     __shared__ float red[UPD_GROUPS][UPD_MAX_PARAMS];
     __shared__ float redl[UPD_GROUPS];     // this step's loss partials (every block sums them: see `frozen` below)
-    const int jl = grp * blockDim.x + tx;  // the first ppb threads finish one parameter each
-    const int j = blockIdx.x * ppb + jl;
+    const int jl = grp * blockDim.x + tx;  // the first ppb threads finish one slab column = one parameter each
+    int lc = jl;                           // its column within the block
+#if INR_UPD_PERM
+    // tile region: 4 consecutive columns are 4 ROWS of one position; walk the positions first so that neighbouring threads touch
+    // neighbouring parameters (params / optimizer state / image are row-major)
+    if (jl < ppb && blockIdx.x * ppb < u.img.sl_tile) {
+        const int q = ppb >> 2, rr = jl / q;
+        lc = (jl - rr * q) * 4 + rr;
+    }
+#endif
+    const int j = jl < ppb ? slab_param_of_col(u.img, blockIdx.x * ppb + lc) : -1;   // flat parameter index, P = loss, -1 = none
     // The kernel is one dependent chain (slabs -> LDS -> optimizer -> stores) and at one image it is latency, not bandwidth,
     // that it pays for: everything the tail needs is requested up front, and all slab rows of a thread are in flight at once.
     float* __restrict__ st = u.opt_state + (size_t)img * (2 * (size_t)u.P + INR_OPT_HEADER_FLOATS);
     float* __restrict__ hdr = st + 2 * (size_t)u.P;
     float p_old = 0.f, m_old = 0.f, v_old = 0.f, lr_now = 0.f;
     bool bad_before = false;
-    if (u.mode == 0 && jl < ppb && j <= u.P) {
+    if (u.mode == 0 && j >= 0) {
         bad_before = hdr[6 + (u.t & 1)] != 0.f;   // written by the PREVIOUS step's launch (double buffer like the lr: no race)
         lr_now = hdr[u.t & 1];
         if (j < u.P) {
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
     {
         const int j4 = blockIdx.x * ppb + 4 * tx;
         f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (j4 < u.PS) {
+        if (j4 < u.PS && slab_param_of_col(u.img, j4) >= 0) {   // (a lane's 4 tile registers are parameters or padding together)
             const float* __restrict__ sl = u.slabs + (size_t)img * u.wgs * u.PS + j4;
             int w = grp;
             for (; w + 15 * UPD_GROUPS < u.wgs; w += 16 * UPD_GROUPS) {   // 256 slabs: one trip, 16 loads in flight
@@ -112,7 +124,7 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
         }
         *(f32x4*)&red[grp][4 * tx] = part;
         if (u.mode == 0 && tx == 0) {   // the loss column (slab entry P), summed in the same order as any parameter column
-            const float* __restrict__ sl = u.slabs + (size_t)img * u.wgs * u.PS + u.P;
+            const float* __restrict__ sl = u.slabs + (size_t)img * u.wgs * u.PS + (u.img.sl_cols - 1);
             float lp = 0.f;
             int w = grp;
             for (; w + 15 * UPD_GROUPS < u.wgs; w += 16 * UPD_GROUPS) {
@@ -127,10 +139,10 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
         }
     }
     __syncthreads();
-    if (jl >= ppb || j > u.P) return;
+    if (j < 0) return;
     float gsum = 0.f;
 #pragma unroll
-    for (int k = 0; k < UPD_GROUPS; ++k) gsum += red[k][jl];  // fixed order: reproducible
+    for (int k = 0; k < UPD_GROUPS; ++k) gsum += red[k][lc];  // fixed order: reproducible
 
     if (u.mode == 1) {
         if (j < u.P) u.grads_out[(size_t)img * u.P + j] = gsum;
@@ -381,6 +393,7 @@ KernelEntry make_entry() {
     for (int e = 0; e < 4; ++e) m.ext[e] = e < G::NEXT ? G::ext_pos(e) : 0;
     m.p_bin = G::P_BIN; m.p_w[0] = G::P_W1; m.p_b[0] = G::P_B1; m.p_s[0] = G::P_S1; m.p_wo = G::P_WO; m.p_bo = G::P_BO;
     m.p_so = G::P_SO; m.P = G::P;
+    m.sl_tile = G::SL_TILE; m.sl_cols = G::SL_COLS; m.KG = G::KG; m.kg_magic = 65536 / G::KG + 1;
     return KernelEntry{H, C, 1, icnn_step_kernel<H, C, true>, icnn_step_kernel<H, C, true, true>,
                        {icnn_step_kernel<H, C, true>, icnn_step_kernel<H, C, true, false, INR_ACT_COS>,
                         icnn_step_kernel<H, C, true, false, INR_ACT_SIN>},
@@ -400,6 +413,7 @@ KernelEntry make_entry2() {
     for (int e = 0; e < 4; ++e) m.ext[e] = e < G::NEXT ? G::ext_pos(e) : 0;
     m.p_bin = G::P_BIN; m.p_w[0] = G::P_W1; m.p_b[0] = G::P_B1; m.p_s[0] = G::P_S1; m.p_w[1] = G::P_W2; m.p_b[1] = G::P_B2;
     m.p_s[1] = G::P_S2; m.p_wo = G::P_WO; m.p_bo = G::P_BO; m.p_so = G::P_SO; m.P = G::P;
+    m.sl_tile = 0; m.sl_cols = G::P + 1; m.KG = 0; m.kg_magic = 0;   // the L = 2 kernels store their slabs in parameter order
     return KernelEntry{H, C, 2, icnn2_step_kernel<H, C, true>, icnn2_step_kernel<H, C, true, true>,
                        {icnn2_step_kernel<H, C, true>, icnn2_step_kernel<H, C, true, false, INR_ACT_COS>,
                         icnn2_step_kernel<H, C, true, false, INR_ACT_SIN>},
@@ -479,7 +493,7 @@ struct Workspace {
 Workspace carve(const KernelEntry* e, long long n_points, int n_images, void* base) {
     Workspace w;
     w.wgs = wgs_per_image(n_points, n_images);
-    w.PS = (e->P + 1 + 3) / 4 * 4;
+    w.PS = (e->img.sl_cols + 31) / 32 * 32;   // slab rows start on 128-byte lines (the tile stores are whole lines then: -0.3 us)
     const long long coef_bytes = ((long long)n_images * 2 * 4 + 255) / 256 * 256;
     const long long img_bytes = ((long long)n_images * e->img.floats * 4 + 255) / 256 * 256;
     const long long slab_bytes = (long long)n_images * w.wgs * w.PS * 4;
@@ -686,6 +700,7 @@ static int prepare(const InrModelDesc* model, const InrGridDesc* grid, int n_ima
 
 static void launch_reduce(const KernelEntry* e, const Workspace& w, int n_images, float* grads, float* loss_out, hipStream_t s) {
     UpdArgs u{};
+    u.img = e->img;
     u.slabs = w.slabs;
     u.grads_out = grads;
     u.loss_out = loss_out;
@@ -694,7 +709,7 @@ static void launch_reduce(const KernelEntry* e, const Workspace& w, int n_images
     u.wgs = w.wgs;
     u.n_images = n_images;
     u.mode = 1;
-    hipLaunchKernelGGL(icnn_update_kernel, upd_grid(e->P, n_images), upd_block(e->P), 0, s, u);
+    hipLaunchKernelGGL(icnn_update_kernel, upd_grid(e->img.sl_cols, n_images), upd_block(e->img.sl_cols), 0, s, u);
 }
 
 int inrfit_forward(const InrModelDesc* model, const float* params, const InrGridDesc* grid, int n_images, float* logits,
@@ -823,7 +838,7 @@ int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const
     }
     if ((rc = launch_pack(e, w, params, n_images, s))) return rc;
     UpdArgs u = make_upd_args(e, w, params, opt_state, loss_hist, status, opt, n_images, steps);
-    const dim3 ugrid = upd_grid(e->P, n_images), ublock = upd_block(e->P);
+    const dim3 ugrid = upd_grid(e->img.sl_cols, n_images), ublock = upd_block(e->img.sl_cols);
     // opt->logits_at_last_forward: final_logits = the output of the LAST training forward (parameters before the last optimizer
     // step) - what the reference's IoU gate looks at (path_connected_net.py:939-972) - written by that step's launch itself
     const bool gate_logits = final_logits && opt->logits_at_last_forward && steps > 0;
@@ -1106,7 +1121,7 @@ int inrfit_cdn_fit(const InrModelDesc* model, const InrFlowDesc* flow, float* ic
     if ((rc = launch_pack(e, w.icnn, icnn_params, n_images, s))) return rc;
     launch_flow_update(w, flow, n_images, 2, flow_params, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0, s);  // effective weights
     UpdArgs u = make_upd_args(e, w.icnn, icnn_params, icnn_opt_state, loss_hist, status, opt, n_images, steps);
-    const dim3 ugrid = upd_grid(e->P, n_images), ublock = upd_block(e->P);
+    const dim3 ugrid = upd_grid(e->img.sl_cols, n_images), ublock = upd_block(e->img.sl_cols);
     const long long hdr_stride = 2 * (long long)e->P + INR_OPT_HEADER_FLOATS;
     const bool gate_logits = final_logits && opt->logits_at_last_forward && steps > 0;   // see inrfit_fit
     for (int it = 0; it < steps; ++it) {
@@ -1568,7 +1583,7 @@ int inrfit_pcn_fit(const InrModelDesc* model, const InrRnvpDesc* rnvp, float* ic
     if (status && hipMemsetAsync(status, 0, sizeof(int32_t) * n_images, s) != hipSuccess) return INR_ELAUNCH;
     if ((rc = launch_pack(e, w.icnn, icnn_params, n_images, s))) return rc;
     UpdArgs u = make_upd_args(e, w.icnn, icnn_params, icnn_opt_state, loss_hist, status, opt, n_images, steps);
-    const dim3 ugrid = upd_grid(e->P, n_images), ublock = upd_block(e->P);
+    const dim3 ugrid = upd_grid(e->img.sl_cols, n_images), ublock = upd_block(e->img.sl_cols);
     const long long hdr_stride = 2 * (long long)e->P + INR_OPT_HEADER_FLOATS;
     const bool gate_logits = final_logits && opt->logits_at_last_forward && steps > 0;   // see inrfit_fit
     for (int it = 0; it < steps; ++it) {
