@@ -56,9 +56,6 @@ struct UpdArgs {
     int input_hi;                    // opt.freeze_input: flat range [0, input_hi) = input.weight | input.bias is never updated
 };
 
-#ifndef INR_UPD_PERM
-#define INR_UPD_PERM 0
-#endif
 constexpr int UPD_MAX_PARAMS = 256;  // most parameters per block
 constexpr int UPD_GROUPS = 16;       // slab groups summed in parallel, then combined in fixed order
 
@@ -82,16 +79,7 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
     __shared__ float red[UPD_GROUPS][UPD_MAX_PARAMS];
     __shared__ float redl[UPD_GROUPS];     // this step's loss partials (every block sums them: see `frozen` below)
     const int jl = grp * blockDim.x + tx;  // the first ppb threads finish one slab column = one parameter each
-    int lc = jl;                           // its column within the block
-#if INR_UPD_PERM
-    // tile region: 4 consecutive columns are 4 ROWS of one position; walk the positions first so that neighbouring threads touch
-    // neighbouring parameters (params / optimizer state / image are row-major)
-    if (jl < ppb && blockIdx.x * ppb < u.img.sl_tile) {
-        const int q = ppb >> 2, rr = jl / q;
-        lc = (jl - rr * q) * 4 + rr;
-    }
-#endif
-    const int j = jl < ppb ? slab_param_of_col(u.img, blockIdx.x * ppb + lc) : -1;   // flat parameter index, P = loss, -1 = none
+    const int j = jl < ppb ? slab_param_of_col(u.img, blockIdx.x * ppb + jl) : -1;   // flat parameter index, P = loss, -1 = none
     // The kernel is one dependent chain (slabs -> LDS -> optimizer -> stores) and at one image it is latency, not bandwidth,
     // that it pays for: everything the tail needs is requested up front, and all slab rows of a thread are in flight at once.
     float* __restrict__ st = u.opt_state + (size_t)img * (2 * (size_t)u.P + INR_OPT_HEADER_FLOATS);
@@ -142,7 +130,7 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
     if (j < 0) return;
     float gsum = 0.f;
 #pragma unroll
-    for (int k = 0; k < UPD_GROUPS; ++k) gsum += red[k][lc];  // fixed order: reproducible
+    for (int k = 0; k < UPD_GROUPS; ++k) gsum += red[k][jl];  // fixed order: reproducible
 
     if (u.mode == 1) {
         if (j < u.P) u.grads_out[(size_t)img * u.P + j] = gsum;
