@@ -149,18 +149,21 @@ struct ImgMap {
     int ext[4];
     int p_bin, p_wo, p_bo, p_so, P;
     int p_w[2], p_b[2], p_s[2]; // flat offsets of skip.k.ln.weight / ln.bias / skp.weight
-    int sl_tile;                // gradient slab: floats of the tile region (Cfg::SL_TILE), 0 = columns are parameters (L = 2 kernels)
+    int sl_tile;                // gradient slab: floats of ONE layer's tile region (Cfg::SL_TILE); L of them lead the slab
     int sl_cols;                // gradient slab: columns in use (Cfg::SL_COLS, or P + 1)
     int KG, kg_magic;           // column tiles per row tile; 65536 / KG + 1 (tile index / KG without a division: exact below 2^13)
 };
 
-// Gradient slab column -> flat parameter index (P = the loss partial, -1 = padding); the inverse of the step kernel's stores.
+// Gradient slab column -> flat parameter index (P = the loss partial, -1 = padding); the inverse of the step kernels' stores:
+//   [layer 0 tiles (sl_tile floats)] ... [layer L-1 tiles] [W_in, b_in] [per layer: leftover rows of W, of b, of S] [w_o, b_o, s_o] [loss]
 // Straight-line selects on fields read with constant indices: it sits in front of the update kernel's first loads.
 __device__ __forceinline__ int slab_param_of_col(const ImgMap& m, int col) {
-    const int H = m.H, HM = m.HM, C = m.C, KG = m.KG, kgm = m.kg_magic, T = m.sl_tile, pw = m.p_w[0], pb = m.p_b[0], ps = m.p_s[0];
+    const int H = m.H, HM = m.HM, C = m.C, KG = m.KG, kgm = m.kg_magic, T = m.sl_tile, two = m.L > 1;
     const int e0 = m.ext[0], e1 = m.ext[1], e2 = m.ext[2], e3 = m.ext[3], pwo = m.p_wo, ncols = m.sl_cols;
-    // tile region
-    const int r = col & 3, lane = (col >> 2) & 63, tb = col >> 8;
+    // tile regions
+    const int tl = (two && col >= T) ? 1 : 0, ct = col - tl * T;
+    const int pw = tl ? m.p_w[1] : m.p_w[0], pb = tl ? m.p_b[1] : m.p_b[0], ps = tl ? m.p_s[1] : m.p_s[0];
+    const int r = ct & 3, lane = (ct >> 2) & 63, tb = ct >> 8;
     const int rt = (tb * kgm) >> 16, b = tb - rt * KG;
     const int o = 16 * rt + 4 * (lane >> 4) + r, pos = 16 * b + (lane & 15);
     int tile = -1;
@@ -169,16 +172,19 @@ __device__ __forceinline__ int slab_param_of_col(const ImgMap& m, int col) {
     tile = pos == e1 ? ps + o * C : tile;
     tile = pos == e0 ? pb + o : tile;
     tile = pos < H ? pw + o * H + pos : tile;
-    // rest region: W_in, b_in | leftover rows of W1 | of b1 | of S1 | w_o, b_o, s_o, loss
-    const int HR = H - HM, c = col - T;
-    const int c1 = c - pw, c2 = c1 - HR * H, c3 = c2 - HR, c4 = c3 - HR * C;
-    int rest = pwo + c4;
-    rest = c4 < 0 ? ps + HM * C + c3 : rest;
-    rest = c3 < 0 ? pb + HM + c2 : rest;
-    rest = c2 < 0 ? pw + HM * H + c1 : rest;
-    rest = c1 < 0 ? c : rest;
-    int res = col < T ? tile : rest;
-    res = T == 0 ? col : res;           // parameter-ordered slabs (L = 2 kernels)
+    // rest region
+    const int HR = H - HM, LS = HR * (H + 1 + C), NT = two ? 2 * T : T;
+    const int c = col - NT, c1 = c - m.p_w[0];
+    const int rl = (two && c1 >= LS) ? 1 : 0, cl = c1 - rl * LS;           // leftover block of layer rl
+    const int qw = rl ? m.p_w[1] : m.p_w[0], qb = rl ? m.p_b[1] : m.p_b[0], qs = rl ? m.p_s[1] : m.p_s[0];
+    const int c2 = cl - HR * H, c3 = c2 - HR;
+    int rest = qs + HM * C + c3;
+    rest = c3 < 0 ? qb + HM + c2 : rest;
+    rest = c2 < 0 ? qw + HM * H + cl : rest;
+    const int ct2 = c1 - (two ? 2 * LS : LS);
+    rest = ct2 >= 0 ? pwo + ct2 : rest;                                   // w_o, b_o, s_o, loss
+    rest = c1 < 0 ? c : rest;                                             // W_in, b_in
+    const int res = col < NT ? tile : rest;
     return col < ncols ? res : -1;
 }
 

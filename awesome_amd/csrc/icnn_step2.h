@@ -54,6 +54,15 @@ struct Cfg2 {
     static constexpr int P_BO = P_WO + H;
     static constexpr int P_SO = P_BO + 1;
     static constexpr int P = P_SO + C;
+    // ---- gradient slab (icnn_step.h, Cfg: gradient slab - here with two layers of tiles) ---------------------------------
+    static constexpr int SL_TILE = TM * KG * 256;                 // per layer
+    static constexpr int SL_IN = 2 * SL_TILE;                     // W_in, b_in at their parameter offsets
+    static constexpr int SL_LS = HR * (H + 1 + C);                // leftover block of one layer: W rows | b | S rows
+    static constexpr int SL_L1 = SL_IN + P_W1;
+    static constexpr int SL_L2 = SL_L1 + SL_LS;
+    static constexpr int SL_WO = SL_L2 + SL_LS;                   // w_o, b_o, s_o, loss
+    static constexpr int SL_LOSS = SL_WO + (P - P_WO);
+    static constexpr int SL_COLS = SL_LOSS + 1;
 };
 
 template <int H, int C, bool TRAIN, bool DX = false, int ACT0 = INR_ACT_RELU>
@@ -627,38 +636,26 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
     if (TRAIN) {
         __syncthreads();
         float* __restrict__ slab = a.slabs + ((size_t)img * a.wgs + wg) * a.PS;
-        auto store_dw = [&](const f32x4 (&dW)[RPW][KG], int p_w, int p_b, int p_s) {
+        // dW tiles of both layers: one 16-byte non-temporal store per lane and tile, in accumulator order (icnn_step.h, gradient slab)
+        auto store_dw = [&](const f32x4 (&dW)[RPW][KG], int base) {
 #pragma unroll
             for (int j = 0; j < RPW; ++j) {
-                const int o0 = 16 * (wave * RPW + j) + 4 * g;
 #pragma unroll
                 for (int b = 0; b < KG; ++b) {
-                    const int pos = 16 * b + l15;
-                    int off = -1, rs = 0;
-                    if (pos < H) {
-                        off = p_w + pos;
-                        rs = H;
-                    } else if (pos == G::ext_pos(0)) {
-                        off = p_b;
-                        rs = 1;
-                    } else {
+                    bool used = true;   // last column tile: leftover units and ext inputs only
+                    if (b == KG - 1) {
+                        used = l15 < HR;
 #pragma unroll
-                        for (int c = 0; c < C; ++c)
-                            if (pos == G::ext_pos(1 + c)) {
-                                off = p_s + c;
-                                rs = C;
-                            }
+                        for (int e = 0; e < NEXT; ++e) used = used || (HM + l15 == G::ext_pos(e));
                     }
-                    if (off >= 0) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) slab[off + (o0 + r) * rs] = dW[j][b][r];
-                    }
+                    if (used)
+                        __builtin_nontemporal_store(dW[j][b], (f32x4*)(slab + base + ((((wave * RPW + j) * KG + b) * 64 + lane) << 2)));
                 }
             }
         };
         if (row_ok) {
-            store_dw(dWa, G::P_W1, G::P_B1, G::P_S1);
-            store_dw(dWb, G::P_W2, G::P_B2, G::P_S2);
+            store_dw(dWa, 0);
+            store_dw(dWb, G::SL_TILE);
         }
         constexpr int SC_DWO = 0;
         constexpr int SC_DWLA = SC_DWO + PT;
@@ -719,37 +716,37 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
         }
         __syncthreads();
         auto wsum = [&](int i) { return ((stA[i] + stA[WSTR + i]) + stA[2 * WSTR + i]) + stA[3 * WSTR + i]; };
-        for (int i = tid; i < H; i += WG_THREADS) slab[G::P_WO + i] = wsum(SC_DWO + i);
+        for (int i = tid; i < H; i += WG_THREADS) slab[G::SL_WO + i] = wsum(SC_DWO + i);
         for (int i = tid; i < 2 * HR * PT; i += WG_THREADS) {
             const int layer = i / (HRA * PT), q = i - layer * (HRA * PT);  // (loop is empty when HR == 0)
             const int u = q / PT, pos = q - u * PT;
             const float v = wsum((layer ? SC_DWLB : SC_DWLA) + q);
-            const int p_w = layer ? G::P_W2 : G::P_W1, p_b = layer ? G::P_B2 : G::P_B1, p_s = layer ? G::P_S2 : G::P_S1;
-            if (pos < H) slab[p_w + (HM + u) * H + pos] = v;
-            else if (pos == G::ext_pos(0)) slab[p_b + HM + u] = v;
+            const int lb = layer ? G::SL_L2 : G::SL_L1;   // leftover block: W rows | b | S rows
+            if (pos < H) slab[lb + u * H + pos] = v;
+            else if (pos == G::ext_pos(0)) slab[lb + HR * H + u] = v;
             else {
 #pragma unroll
                 for (int c = 0; c < C; ++c)
-                    if (pos == G::ext_pos(1 + c)) slab[p_s + (HM + u) * C + c] = v;
+                    if (pos == G::ext_pos(1 + c)) slab[lb + HR * H + HR + u * C + c] = v;
             }
         }
         for (int i = tid; i < HM * NEXT; i += WG_THREADS) {
             const int row = i / NEXT, e = i - row * NEXT;
             const float v = wsum(SC_L0 + row * 4 + e);
-            if (e == 0) slab[G::P_BIN + row] = v;
-            else slab[G::P_WIN + row * C + (e - 1)] = v;
+            if (e == 0) slab[G::SL_IN + G::P_BIN + row] = v;
+            else slab[G::SL_IN + G::P_WIN + row * C + (e - 1)] = v;
         }
         if (tid < HR * NEXT) {
             const int u = tid / NEXT, e = tid - u * NEXT;
             const float v = wsum(SC_L0L + u * 4 + e);
-            if (e == 0) slab[G::P_BIN + HM + u] = v;
-            else slab[G::P_WIN + (HM + u) * C + (e - 1)] = v;
+            if (e == 0) slab[G::SL_IN + G::P_BIN + HM + u] = v;
+            else slab[G::SL_IN + G::P_WIN + (HM + u) * C + (e - 1)] = v;
         }
         if (tid < 2 + C) {
             const float v = wsum(SC_SC + tid);
-            if (tid == 0) slab[G::P] = v;
-            else if (tid == 1) slab[G::P_BO] = v;
-            else slab[G::P_SO + tid - 2] = v;
+            if (tid == 0) slab[G::SL_LOSS] = v;
+            else if (tid == 1) slab[G::SL_WO + (G::P_BO - G::P_WO)] = v;
+            else slab[G::SL_WO + (G::P_SO - G::P_WO) + tid - 2] = v;
         }
     }
 }

@@ -401,7 +401,7 @@ KernelEntry make_entry2() {
     for (int e = 0; e < 4; ++e) m.ext[e] = e < G::NEXT ? G::ext_pos(e) : 0;
     m.p_bin = G::P_BIN; m.p_w[0] = G::P_W1; m.p_b[0] = G::P_B1; m.p_s[0] = G::P_S1; m.p_w[1] = G::P_W2; m.p_b[1] = G::P_B2;
     m.p_s[1] = G::P_S2; m.p_wo = G::P_WO; m.p_bo = G::P_BO; m.p_so = G::P_SO; m.P = G::P;
-    m.sl_tile = 0; m.sl_cols = G::P + 1; m.KG = 0; m.kg_magic = 0;   // the L = 2 kernels store their slabs in parameter order
+    m.sl_tile = G::SL_TILE; m.sl_cols = G::SL_COLS; m.KG = G::KG; m.kg_magic = 65536 / G::KG + 1;
     return KernelEntry{H, C, 2, icnn2_step_kernel<H, C, true>, icnn2_step_kernel<H, C, true, true>,
                        {icnn2_step_kernel<H, C, true>, icnn2_step_kernel<H, C, true, false, INR_ACT_COS>,
                         icnn2_step_kernel<H, C, true, false, INR_ACT_SIN>},
