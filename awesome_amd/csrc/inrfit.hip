@@ -71,6 +71,16 @@ inline int upd_params_per_block(int cols) {   // cols = slab columns in use (P +
 inline dim3 upd_grid(int cols, int n_images) { const int ppb = upd_params_per_block(cols); return dim3((cols + ppb - 1) / ppb, n_images); }
 inline dim3 upd_block(int cols) { return dim3(upd_params_per_block(cols) / 4, UPD_GROUPS); }
 
+#if INR_STAMPS
+__device__ unsigned long long g_updtimes[512][4];   // per block of the LAST update launch, s_memrealtime (100 MHz): entry, slab loads back, reduced, stores done
+#define UPD_STAMP(k)                                                                                          \
+    if (threadIdx.x == 0 && threadIdx.y == 0 && blockIdx.y == 0 && blockIdx.x < 512) {                        \
+        __builtin_amdgcn_s_waitcnt(0);                                                                        \
+        g_updtimes[blockIdx.x][k] = __builtin_amdgcn_s_memrealtime();                                         \
+    }
+#else
+#define UPD_STAMP(k)
+#endif
 // block = (blockDim.x lanes x float4 = ppb parameters) x 16 slab groups
 __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_kernel(const UpdArgs u) {
     const int img = blockIdx.y;
@@ -78,6 +88,7 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
     const int ppb = 4 * blockDim.x;
     __shared__ float red[UPD_GROUPS][UPD_MAX_PARAMS];
     __shared__ float redl[UPD_GROUPS];     // this step's loss partials (every block sums them: see `frozen` below)
+    UPD_STAMP(0);
     const int jl = grp * blockDim.x + tx;  // the first ppb threads finish one slab column = one parameter each
     const int j = jl < ppb ? slab_param_of_col(u.img, blockIdx.x * ppb + jl) : -1;   // flat parameter index, P = loss, -1 = none
     // The kernel is one dependent chain (slabs -> LDS -> optimizer -> stores) and at one image it is latency, not bandwidth,
@@ -126,12 +137,14 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
             redl[grp] = lp;
         }
     }
+    UPD_STAMP(1);
     __syncthreads();
     if (j < 0) return;
     float gsum = 0.f;
 #pragma unroll
     for (int k = 0; k < UPD_GROUPS; ++k) gsum += red[k][jl];  // fixed order: reproducible
 
+    UPD_STAMP(2);
     if (u.mode == 1) {
         if (j < u.P) u.grads_out[(size_t)img * u.P + j] = gsum;
         else u.loss_out[img] = gsum;
@@ -220,6 +233,7 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
     }
     st[j] = m;
     st[u.P + j] = v;
+    UPD_STAMP(3);
 }
 
 // params -> parameter image: constant background (zeros, ext-input constants), then every parameter into its slot(s)
@@ -1646,6 +1660,9 @@ int inrfit_pack_masks(const float* values, int n_images, int64_t n_points, float
 }
 
 #if INR_STAMPS
+int inrfit_debug_updtimes(unsigned long long* host_out) {   // [512][4] of the last update launch
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_updtimes), sizeof(unsigned long long) * 2048) == hipSuccess ? 0 : -4;
+}
 int inrfit_debug_stamps(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -4;
 }
