@@ -462,12 +462,30 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
             float dw1 = 0.f, db1 = 0.f, dw2 = 0.f;
             if (on) {
                 const float* s2 = u.slab2 + (((size_t)img * u.chunks * (K * 2) + nb) * 3) * u.Wp + tid;
+                const size_t cs = (size_t)(K * 2) * 3 * u.Wp;
+                if (u.chunks == 64) {   // the usual count: all partials requested before the first add (a latency chain on 2K + 1 blocks)
+                    float q0[64], q1[64], q2[64];
+#pragma unroll
+                    for (int c = 0; c < 64; ++c) {
+                        const float* q = s2 + c * cs;
+                        q0[c] = q[0];
+                        q1[c] = q[u.Wp];
+                        q2[c] = q[2 * u.Wp];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 64; ++c) {
+                        dw1 += q0[c];
+                        db1 += q1[c];
+                        dw2 += q2[c];
+                    }
+                } else {
 #pragma unroll 16
-                for (int c = 0; c < u.chunks; ++c) {
-                    const float* q = s2 + (size_t)c * (K * 2) * 3 * u.Wp;
-                    dw1 += q[0];
-                    db1 += q[u.Wp];
-                    dw2 += q[2 * u.Wp];
+                    for (int c = 0; c < u.chunks; ++c) {
+                        const float* q = s2 + c * cs;
+                        dw1 += q[0];
+                        db1 += q[u.Wp];
+                        dw2 += q[2 * u.Wp];
+                    }
                 }
             }
             float db2 = 0.f;

@@ -851,8 +851,17 @@ __global__ __launch_bounds__(256) void rnvp_update_kernel(const RnvpUpdArgs u) {
             } else {
                 g = 0.f;
                 const float* s2 = u.slab2 + ((((size_t)img * u.chunks) * (F * 2) + f * 2 + net) * (2 * C + 1) + row) * m.HIDp + j;
+                const size_t cs = (size_t)(F * 2) * (2 * C + 1) * m.HIDp;
+                if (u.chunks == 64) {   // the usual count: every chunk's partial requested before the first add (this kernel is a
+                    float q[64];        // latency chain on F + 1 blocks; `#pragma unroll 64` on the runtime bound falls back to a scalar loop)
+#pragma unroll
+                    for (int c = 0; c < 64; ++c) q[c] = s2[c * cs];
+#pragma unroll
+                    for (int c = 0; c < 64; ++c) g += q[c];
+                } else {
 #pragma unroll 8
-                for (int c = 0; c < u.chunks; ++c) g += s2[(size_t)c * (F * 2) * (2 * C + 1) * m.HIDp];
+                    for (int c = 0; c < u.chunks; ++c) g += s2[c * cs];
+                }
             }
         }
         if (u.mode == 1) {
