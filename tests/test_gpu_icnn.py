@@ -314,6 +314,43 @@ def test_gradient_accuracy_against_float64(amd, layers, C):
     assert max(e_hip) <= 3.0 * max(e_ref) + 1e-6, (max(e_hip), max(e_ref))
 
 
+@pytest.mark.parametrize("h,C,layers", [(130, 2, 1), (130, 3, 1), (64, 2, 1), (64, 3, 1), (32, 2, 1), (32, 3, 1),
+                                         (130, 2, 2), (130, 3, 2), (64, 2, 2), (64, 3, 2)])
+def test_every_compiled_shape_every_parameter_gradient(amd, h, C, layers):
+    """All ten kernel entries of the library on a ragged grid: the loss and the gradient of EVERY parameter against the oracle - in
+    particular every gradient-slab column reaches its parameter (the slabs are stored in accumulator-tile order and mapped back by
+    the update kernel, icnn_step.h `slab_param_of_col`), for widths with and without leftover units - and one clamped Adam step."""
+    A = amd
+    from awesome_amd.model import ConvexNextNet
+    torch.manual_seed(17 + h + C + layers)
+    m = ConvexNextNet(n_hidden=h, n_hidden_layers=layers, in_features=C)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    H_, W_ = 19, 23     # N = 437: 6 full chunks + a ragged one
+    grid = O.positional_grid(W_, H_) if C == 2 else O.positional_grid(W_, H_, 0.4, 1.0)
+    un = torch.from_numpy(np.random.RandomState(h + C).rand(1, 1, H_, W_).astype(np.float32))
+    lo, go = O.loss_and_grads(sd, grid[None], un, "se")
+    spec = A.IcnnSpec(h, C, layers)
+    params = A.pack_state_dict(spec, sd, "cuda:0")[None].contiguous()
+    g_ = A.Grid.from_image_grid(grid.to("cuda:0"))
+    loss, g = A.loss_grad(spec, params, g_, un.reshape(1, -1).to("cuda:0"), loss="se")
+    assert float(loss[0]) == pytest.approx(float(lo), rel=2e-5)
+    got = A.unpack_params(spec, g[0].cpu())
+    assert set(got) == set(go)
+    for k, ref in go.items():
+        ref = ref.numpy()
+        np.testing.assert_allclose(got[k].numpy(), ref, rtol=2e-4, atol=2e-4 * float(np.abs(ref).max()) + 1e-10, err_msg=k)
+    # one Adam step with the convexity clamp through the fused fit: every parameter moves like the oracle's
+    res = A.fit(spec, params.clone(), g_, un.reshape(1, -1).to("cuda:0"), 1, lr=1e-2, loss="se", optimizer="adam")
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.Adam(list(p.values()), lr=1e-2)
+    O.weighted_loss(torch.sigmoid(O.icnn_forward_image(p, grid[None])), un, "se").backward()
+    opt.step()
+    O.icnn_enforce_convexity(p)
+    new = A.unpack_params(spec, res.params[0].cpu())
+    for k, v in p.items():
+        np.testing.assert_allclose(new[k].numpy(), v.detach().numpy(), rtol=1e-4, atol=2e-5, err_msg=k)
+
+
 def test_baseline_config_full_fit_matches_reference(amd, golden_dir):
     """BASELINE configs[1] end to end at full size: 2000 full-batch Adam steps of ConvexNextNet(h=130, L=1) on the 256x256 blob,
     HIP vs the REAL reference classes' fit of the same seeded problem (tools/gen_golden.py gen_fit_blob256: final mask, loss
