@@ -79,6 +79,8 @@ def get_config():
     ap.add_argument("--dataset-args", type=str, default=None, help="JSON dict merged into the config's dataset_args")
     ap.add_argument("--prior-model-args", type=str, default=None, help="JSON dict merged into the config's prior_model_args")
     ap.add_argument("--override", type=str, default=None, help="JSON dict deep-merged into the whole config (e.g. agent_args)")
+    ap.add_argument("--save-masks", action="store_true", help="export every fitted prior's mask as <output>/masks/<index>.png "
+                    "(1 bit per pixel; thresholded and bit-packed on the device, awesome_amd.run.evaluate_dataset)")
     args = ap.parse_args()
     with open(args.config_path) as f:
         cfg = yaml.safe_load(f)
@@ -100,6 +102,8 @@ def get_config():
                 dst[k] = v
     if args.override:
         deep_merge(cfg, json.loads(args.override))
+    if args.save_masks:
+        cfg["save_masks"] = True
     return cfg
 
 
@@ -226,6 +230,12 @@ def main(cfg):
             vals.append(float(A.miou(p, gt)[0]))
             nvals.append(float(A.miou(ds.unaries(k).reshape(1, -1).to(device), gt)[0]))
         gt_iou, noisy_iou = f32(vals), f32(nvals)
+    masks_saved = 0
+    if cfg.get("save_masks") and mine:
+        # evaluation + export on the device (reference: get_result / split_model_result / save_result_mask per image on the host,
+        # run/functions.py:2111-2151, 2315-2361, 2432-2487): every rank writes the masks of its own images into the shared folder
+        from awesome_amd.run import evaluate_dataset
+        masks_saved = len(evaluate_dataset(wrapper, ds, indices=mine, out_dir=os.path.join(out_dir, "masks"))["indices"])
     iou_all = parallel.gather_per_image(iou, len(ds), rank, world)
     retries_all = parallel.gather_per_image(retries, len(ds), rank, world)
     if gt_iou is not None:
@@ -254,6 +264,8 @@ def main(cfg):
         summary = {"images": len(ds), "ranks": world, "epochs": num_epochs, "seconds": round(dt, 4),
                    "fits_per_s": round(len(ds) / dt, 4), "ForegroundBinaryMIOU_vs_unaries": round(float(iou_all.mean()), 5),
                    "retries": [int(v) for v in retries_all.tolist()], "priors_saved": len(merged["cache"]), "output": out_dir}
+        if cfg.get("save_masks"):
+            summary["masks_saved"] = len([f for f in os.listdir(os.path.join(out_dir, "masks")) if f.endswith(".png")])
         if gt_iou is not None:
             summary["ForegroundBinaryMIOU_vs_ground_truth"] = round(float(gt_all.mean()), 5)
             summary["input_labels_MIOU_vs_ground_truth"] = round(float(noisy_all.mean()), 5)

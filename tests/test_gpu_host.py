@@ -92,13 +92,20 @@ def test_fitter_warm_start_chain(dev):
 
 def test_run_py_config_entrypoint(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run.py"), "--config-path",
-                          os.path.join(ROOT, "config", "c1_disc64.yaml"), "--output-folder", str(tmp_path)],
+                          os.path.join(ROOT, "config", "c1_disc64.yaml"), "--output-folder", str(tmp_path), "--save-masks"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     summary = json.loads(out.stdout.strip().splitlines()[-1])
     assert summary["images"] == 1 and summary["ForegroundBinaryMIOU_vs_unaries"] > 0.98
     cache = torch.load(os.path.join(summary["output"], "prior_cache_epoch_0.pth"))
     assert "0" in cache["cache"] and "skip.0.ln.weight" in cache["cache"]["0"]
+    # --save-masks: the fitted prior's mask, thresholded and bit-packed on the device, as a 1-bit PNG (white = object)
+    assert summary["masks_saved"] == 1
+    PIL = pytest.importorskip("PIL.Image")
+    im = np.asarray(PIL.open(os.path.join(summary["output"], "masks", "0.png"))).astype(bool)
+    from awesome_amd.dataset import disc_unaries
+    disc = disc_unaries(64, 64, 32, 32, 15.0).numpy() < 0.5
+    assert im.shape == (64, 64) and (im & disc).sum() / (im | disc).sum() > 0.97
 
 
 def test_run_py_two_ranks_save_every_prior(tmp_path):

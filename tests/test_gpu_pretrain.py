@@ -332,3 +332,38 @@ def test_pretrain_spatio_temporal_dispatch(dev):
     for k, v in twin.state_dict().items():
         if v.is_floating_point() and not k.endswith("data_dep_init_done"):
             assert torch.equal(v, state[k]), k
+
+
+def test_evaluation_and_export_after_pretrain(dev, tmp_path):
+    """SURVEY §8 f2 on the HIP path: after `wrapper.pretrain(...)` the reference-style `get_result` / `split_model_result` /
+    `save_result_mask` chain per image, and `evaluate_dataset` for the whole set at once on the device (threshold + integer-count
+    IoU + bit-packed masks, one kernel each): same IoU as the per-image chain with the oracle's IoU, PNGs that decode to the
+    thresholded prior masks."""
+    PIL = pytest.importorskip("PIL.Image")
+    from awesome_amd.model import ConvexNextNet
+    from awesome_amd.run import evaluate_dataset, get_result, save_result_mask, split_model_result
+    args = dict(n_hidden=130, in_features=2, n_hidden_layers=1)
+    torch.manual_seed(11)
+    ds, wrapper, agent = _setup(dev, ConvexNextNet, args, n=3, size=40)
+    wrapper.pretrain(train_set=ds, test_set=None, device=dev, agent=agent, use_progress_bar=False, num_epochs=300, lr=2e-3,
+                     optimizer="adam", reuse_state=False)
+    ev = evaluate_dataset(wrapper, ds, out_dir=str(tmp_path / "masks"))
+    assert ev["shape"] == (40, 40) and ev["bits"].shape == (3, 25) and ev["indices"] == [0, 1, 2]
+    for k in range(3):
+        res, gt, image, _, _ = get_result(wrapper, ds, k, model_gets_targets=False)
+        assert res.device.type == "cpu" and res.shape == (1, 2, 40, 40)
+        ret = split_model_result(res, wrapper, ds, image)
+        prior = ret["prior"]                                     # (1, H, W), after the wrapper's sigmoid (use_prior_sigmoid)
+        assert prior.shape == (1, 40, 40) and ret["segmentation"].shape == (1, 40, 40)
+        p = prior if getattr(wrapper, "use_prior_sigmoid", False) else torch.sigmoid(prior)
+        obj = (p[0] <= 0.5)                                      # foreground -> 0 convention
+        gt_obj = gt[0] <= 0.5                                    # the data set's masks use the same convention
+        inter, union = float((obj & gt_obj).sum()), float((obj | gt_obj).sum())
+        assert float(ev["iou"][k]) == pytest.approx(inter / union, abs=1e-6)
+        assert float(ev["iou"][k]) == pytest.approx(O.miou_binary((p > 0.5).float(), gt, invert=True), abs=1e-6)   # MIOU (awesome/measures/miou.py:29-48)
+        im = np.asarray(PIL.open(str(tmp_path / "masks" / f"{k}.png"))).astype(bool)
+        np.testing.assert_array_equal(im, obj.numpy())
+        # the reference's own export: binary channel mask (object = 0) -> colour-index PNG
+        save_result_mask((p > 0.5).float(), str(tmp_path / f"ref_{k}.png"))
+        np.testing.assert_array_equal(np.asarray(PIL.open(str(tmp_path / f"ref_{k}.png"))), obj.numpy().astype(np.uint8))
+    assert ev["miou"] == pytest.approx(float(ev["iou"].mean())) and ev["miou"] > 0.8
