@@ -13,7 +13,7 @@ from __future__ import annotations
 import os
 import struct
 import zlib
-from typing import Any, Dict, List, Optional, Sequence, Tuple
+from typing import Any, Dict, Optional, Sequence
 
 import numpy as np
 import torch
