@@ -198,7 +198,15 @@ def main(cfg):
         params = [p for p in seg.parameters()] + bank_params(prior)
         opt = torch.optim.Adam(params, lr=float(opt_args.get("lr", 1e-3)))
         trainer = JointTrainer(jw, bank, criterion, opt)
-        for _ in range(joint_epochs):
+        for epoch in range(joint_epochs):
+            # the runner's extra-penalty hook (awesome/run/awesome_runner.py:351-371; config fields awesome_config.py:164-173): from
+            # epoch N on the loss adds its penalty term, optionally with the learning rate scaled once
+            if (cfg.get("use_extra_penalty_hook") and epoch >= int(cfg.get("extra_penalty_after_n_epochs", 200))
+                    and hasattr(criterion, "extra_penalty") and not criterion.extra_penalty):
+                criterion.extra_penalty = True
+                if cfg.get("use_reduce_lr_in_extra_penalty_hook"):
+                    for group in opt.param_groups:
+                        group["lr"] = group["lr"] * float(cfg.get("reduce_lr_in_extra_penalty_hook_factor", 0.05))
             acc = torch.zeros((), device=device)
             for k in mine:
                 (_, _), ((image, feat, xy), target) = ds[k]
@@ -272,6 +280,8 @@ def main(cfg):
         if joint_losses:
             summary["joint_epochs"] = joint_epochs
             summary["joint_loss_first_last"] = [round(joint_losses[0], 6), round(joint_losses[-1], 6)]
+            if cfg.get("use_extra_penalty_hook"):
+                summary["extra_penalty"] = bool(getattr(criterion, "extra_penalty", False))
         with open(os.path.join(out_dir, "summary.json"), "w") as f:
             json.dump(summary, f, indent=1)
         print(json.dumps(summary))

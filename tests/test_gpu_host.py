@@ -143,6 +143,12 @@ def test_run_py_two_ranks_save_every_prior(tmp_path):
 @pytest.mark.parametrize("config,override,checks", [
     ("c5_refine_noisy256.yaml", {"dataset_args": {"n_images": 2, "size": 64}, "agent_args": {"joint_epochs": 3, "pretrain_args": {"num_epochs": 80}}},
      dict(images=2, joint_epochs=3)),
+    # the runner's extra-penalty hook in the joint epochs (awesome_runner.py:351-371): AwesomeImageLoss switches its penalty on at epoch 1
+    ("c5_refine_noisy256.yaml", {"dataset_args": {"n_images": 2, "size": 64}, "agent_args": {"joint_epochs": 3, "pretrain_args": {"num_epochs": 80}},
+                                 "loss_type": "awesome_amd.measures.AwesomeImageLoss", "loss_args": {"alpha": 1.0},
+                                 "use_extra_penalty_hook": True, "extra_penalty_after_n_epochs": 1,
+                                 "use_reduce_lr_in_extra_penalty_hook": True},
+     dict(images=2, joint_epochs=3, extra_penalty=True)),
     ("c2_blob256_path_connected.yaml", {"dataset_args": {"size": 64}, "agent_args": {"pretrain_args": {"num_epochs": 80}}}, dict(images=1)),
     ("c4_sequence128x16.yaml", {"dataset_args": {"size": 32, "frames": 4}, "num_epochs": 60}, dict(images=1)),
     ("c1_disc64_siren.yaml", {}, dict(images=1)),
@@ -162,7 +168,9 @@ def test_run_py_configs_of_the_flow_priors(tmp_path, config, override, checks):
     assert all(torch.isfinite(v).all() for sd in cache["cache"].values() for v in sd.values() if v.is_floating_point())
     if "joint_epochs" in checks:
         first, last = summary["joint_loss_first_last"]
-        assert np.isfinite(first) and np.isfinite(last) and last <= first * 1.05
+        assert np.isfinite(first) and np.isfinite(last)
+        if not checks.get("extra_penalty"):      # (the hook changes the loss's definition between the first and the last epoch)
+            assert last <= first * 1.05
         assert "ForegroundBinaryMIOU_vs_ground_truth" in summary
 
 
