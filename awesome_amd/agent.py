@@ -15,6 +15,7 @@ unless the caller reads a value.  Everything else the reference agent does (trac
 control plane and out of scope."""
 from __future__ import annotations
 
+import inspect
 import logging
 import os
 from typing import Any, Callable, Dict, Iterable, List, Optional, Sequence, Tuple
@@ -88,6 +89,21 @@ class PretrainAgent:
         return state
 
 
+def _loss_takes_input(loss: Callable) -> bool:
+    """TorchAgent.forward_additional_loss_args (torch_agent.py:150-164): a loss whose `__call__` (for an nn.Module: whose `forward`)
+    names `_input` or `kwargs` also receives `_input=device_inputs`."""
+    try:
+        spec = inspect.signature(loss.__call__).parameters
+    except (TypeError, ValueError):
+        return False
+    if "_input" in spec or "kwargs" in spec:
+        if isinstance(loss, torch.nn.Module):
+            spec = inspect.signature(loss.forward).parameters
+            return "_input" in spec or "kwargs" in spec
+        return True
+    return False
+
+
 class JointTrainer:
     """One optimisation step of the joint segmentation + prior training (TorchAgent._perform_step, :428-551) on device-resident
     priors.  `wrapper` is a WrapperModule(segmentation_module, prior_module); `bank` holds one parameter row per image of the
@@ -98,13 +114,14 @@ class JointTrainer:
 
     def __init__(self, wrapper: torch.nn.Module, bank: PriorBank, criterion: Callable, optimizer: torch.optim.Optimizer):
         self.wrapper, self.bank, self.criterion, self.optimizer = wrapper, bank, criterion, optimizer
+        self.forward_additional_loss_args = _loss_takes_input(criterion)
 
     def perform_step(self, key: Any, inputs: Sequence[torch.Tensor], labels: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """-> (loss, output) as device tensors (no host sync)."""
         self.optimizer.zero_grad()
         with self.bank.manager(self.wrapper.prior_module, key):
             out = self.wrapper(*inputs)
-            loss = self.criterion(out, labels)
+            loss = self.criterion(out, labels, _input=list(inputs)) if self.forward_additional_loss_args else self.criterion(out, labels)
             loss.backward()
             self.optimizer.step()
             self.wrapper.enforce_convexity()   # batch_processed hook (awesome_runner.py:294-297)

@@ -278,3 +278,23 @@ def test_zoo_cache_round_trip(tmp_path):
     mem = Zoo(None)                                                                                   # memory only
     mem.save_model_state("n", a, config=cfg)
     assert mem.load_model_state("n", make(), config=cfg)[0] is True
+
+
+def test_loss_contract_additional_arguments_rule():
+    """TorchAgent.forward_additional_loss_args (awesome/agent/torch_agent.py:150-164): `_input=device_inputs` goes to losses whose
+    call signature names `_input` or `kwargs` - for an nn.Module it is the signature of `forward` that counts."""
+    import torch
+    from awesome_amd.agent import _loss_takes_input
+    from awesome_amd.measures import SE, AwesomeImageLoss, FBMSJointLoss
+
+    class WithInput(torch.nn.Module):
+        def forward(self, output, target, _input=None):
+            return output.sum()
+
+    class Plain:
+        def __call__(self, output, target):
+            return output.sum()
+
+    assert _loss_takes_input(AwesomeImageLoss()) and _loss_takes_input(FBMSJointLoss()) and _loss_takes_input(SE())
+    assert _loss_takes_input(WithInput())
+    assert not _loss_takes_input(torch.nn.BCELoss()) and not _loss_takes_input(Plain())
