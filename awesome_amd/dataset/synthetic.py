@@ -119,6 +119,21 @@ class SyntheticPriorDataset(PriorDataset):
     def ground_truth_batch(self, indices) -> torch.Tensor:
         return self._inner.ground_truth_batch(indices)
 
+    # ---- the rest of the reference's dataset contract -----------------------------------------------------------
+    def decode_encoding(self, output: torch.Tensor) -> torch.Tensor:
+        """AwesomeDataset.decode_encoding (awesome/dataset/awesome_dataset.py:393-412), binary, 2-D: `>= 0.5`."""
+        return (output >= 0.5).to(dtype=torch.float32)
+
+    def split_indices(self):
+        """(train, validation) indices (awesome_dataset.py:169-171): every synthetic image is a training image - the per-image
+        fits have nothing to validate on."""
+        return np.arange(len(self)), np.zeros((0,), dtype=np.int64)
+
+    def get_config(self):
+        """base_dataset.py:51-60: the constructor arguments."""
+        return dict(n_images=len(self), size=self.size, kind=self.kind, returns_index=self.returns_index,
+                    training_batch_size=self.training_batch_size)
+
     @prior()
     def __getitem__(self, i: int):
         un = self._inner.unaries(int(i)).clamp(1e-6, 1 - 1e-6)

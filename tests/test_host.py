@@ -298,3 +298,30 @@ def test_loss_contract_additional_arguments_rule():
     assert _loss_takes_input(AwesomeImageLoss()) and _loss_takes_input(FBMSJointLoss()) and _loss_takes_input(SE())
     assert _loss_takes_input(WithInput())
     assert not _loss_takes_input(torch.nn.BCELoss()) and not _loss_takes_input(Plain())
+
+
+def test_synthetic_prior_dataset_follows_the_dataset_contract():
+    """SURVEY §8(b) dataset contract: items `((key, state), ((image, features, xy), target))` under `@prior()`, `split_indices`,
+    `get_config`, `training_batch_size`, `returns_index`, `decode_encoding` (>= 0.5, awesome_dataset.py:393-412), `__prior_cache__`."""
+    import numpy as np
+    import torch
+    from awesome_amd.dataset import SyntheticPriorDataset
+
+    class Tiny(torch.nn.Module):
+        def __init__(self, n=3):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(n))
+
+    ds = SyntheticPriorDataset(n_images=3, size=16, kind="blob", prior_model_type=Tiny, prior_model_args=dict(n=3))
+    (key, state), ((image, feat, xy), target) = ds[1]
+    assert key == 1 and set(state) == {"w"} and image.shape == (1, 16, 16) and xy.shape == (2, 16, 16) and target.shape == (1, 16, 16)
+    train, val = ds.split_indices()
+    assert list(train) == [0, 1, 2] and len(val) == 0
+    cfg = ds.get_config()
+    assert cfg["n_images"] == 3 and cfg["size"] == 16 and cfg["kind"] == "blob"
+    assert ds.training_batch_size == 1 and ds.returns_index is False and ds.has_prior and 1 in ds.__prior_cache__.__cache__
+    out = torch.tensor([[0.49999, 0.5], [0.7, 0.1]])
+    np.testing.assert_array_equal(ds.decode_encoding(out).numpy(), np.array([[0.0, 1.0], [1.0, 0.0]], np.float32))
+    ds.return_prior = False
+    (image2, _, _), _ = ds[1]
+    assert torch.equal(image2, image)
