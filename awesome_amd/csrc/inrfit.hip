@@ -482,12 +482,20 @@ int set_lds(const KernelEntry* e) {
     return INR_OK;
 }
 
+// Gradient slab buffers an optimisation loop rotates through (step it uses buffer it % INR_SLAB_BUFFERS).  A step kernel that writes
+// its slabs over the very lines the update kernel of the previous step has just read - lines that then sit, clean, in the L2s of all
+// eight XCDs - runs 3.6 us longer than one that writes lines nobody has touched for a few launches (measured: DESIGN.md 6).
+constexpr int INR_SLAB_BUFFERS = 4;
+
 struct Workspace {
     float* coef;
     float* wimg;
-    float* slabs;
+    float* slabs;            // the buffer of the current step (set_step rotates it)
+    float* slabs0;           // buffer 0
+    long long slab_floats;   // floats per buffer
     int wgs, PS;
     long long bytes;
+    void set_step(int it) { slabs = slabs0 + (size_t)(it % INR_SLAB_BUFFERS) * slab_floats; }
     int act0 = INR_ACT_RELU;     // layer-0 activation of the model this workspace was prepared for
     float act_omega = 0.f;
 };
@@ -498,10 +506,11 @@ Workspace carve(const KernelEntry* e, long long n_points, int n_images, void* ba
     w.PS = (e->img.sl_cols + 31) / 32 * 32;   // slab rows start on 128-byte lines (the tile stores are whole lines then: -0.3 us)
     const long long coef_bytes = ((long long)n_images * 2 * 4 + 255) / 256 * 256;
     const long long img_bytes = ((long long)n_images * e->img.floats * 4 + 255) / 256 * 256;
-    const long long slab_bytes = (long long)n_images * w.wgs * w.PS * 4;
+    w.slab_floats = ((long long)n_images * w.wgs * w.PS + 63) / 64 * 64;
+    const long long slab_bytes = w.slab_floats * 4 * INR_SLAB_BUFFERS;
     w.coef = (float*)base;
     w.wimg = (float*)((char*)base + coef_bytes);
-    w.slabs = (float*)((char*)base + coef_bytes + img_bytes);
+    w.slabs0 = w.slabs = (float*)((char*)base + coef_bytes + img_bytes);
     w.bytes = coef_bytes + img_bytes + slab_bytes;
     return w;
 }
@@ -845,6 +854,8 @@ int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const
     // step) - what the reference's IoU gate looks at (path_connected_net.py:939-972) - written by that step's launch itself
     const bool gate_logits = final_logits && opt->logits_at_last_forward && steps > 0;
     for (int it = 0; it < steps; ++it) {
+        w.set_step(step0 + it);
+        u.slabs = w.slabs;
         if ((rc = launch_step_timed(e, w, grid, targets, loss->kind, n_images, s, gate_logits && it == steps - 1 ? final_logits : nullptr)))
             return rc;
         u.t = step0 + it + 1;
@@ -1127,6 +1138,8 @@ int inrfit_cdn_fit(const InrModelDesc* model, const InrFlowDesc* flow, float* ic
     const long long hdr_stride = 2 * (long long)e->P + INR_OPT_HEADER_FLOATS;
     const bool gate_logits = final_logits && opt->logits_at_last_forward && steps > 0;   // see inrfit_fit
     for (int it = 0; it < steps; ++it) {
+        w.icnn.set_step(step0 + it);
+        u.slabs = w.icnn.slabs;
         launch_flow_fwd(w, grid, n_images, w.xd, s);
         if ((rc = launch_step(e, w.icnn, true, &w.dgrid, targets, loss->kind, n_images,
                               gate_logits && it == steps - 1 ? final_logits : nullptr, s, w.dxd))) return rc;
@@ -1589,6 +1602,8 @@ int inrfit_pcn_fit(const InrModelDesc* model, const InrRnvpDesc* rnvp, float* ic
     const long long hdr_stride = 2 * (long long)e->P + INR_OPT_HEADER_FLOATS;
     const bool gate_logits = final_logits && opt->logits_at_last_forward && steps > 0;   // see inrfit_fit
     for (int it = 0; it < steps; ++it) {
+        w.icnn.set_step(step0 + it);
+        u.slabs = w.icnn.slabs;
         launch_rnvp_fwd(w, flow_params, grid, n_images, w.xd, true, s, false, it > 0);
         if ((rc = launch_step(e, w.icnn, true, &w.dgrid, targets, loss->kind, n_images,
                               gate_logits && it == steps - 1 ? final_logits : nullptr, s, w.dxd))) return rc;
