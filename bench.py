@@ -262,9 +262,9 @@ def main():
     flop_per_launch = STEP_FLOP_PER_POINT * N * B
     achieved = flop_per_launch / (kernel_ms * 1e-3) / 1e12
     # HBM bytes per launch of this kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes of
-    # this same command; profiles/r02_d_pmc_step_kernel.json) - only quoted for the configuration it was measured on
+    # this same command; profiles/r02_e_pmc_step_kernel.json) - only quoted for the configuration it was measured on
     traffic = None
-    tf = os.path.join(ROOT, "profiles", "r02_d_pmc_step_kernel.json")
+    tf = os.path.join(ROOT, "profiles", "r02_e_pmc_step_kernel.json")
     if B == 1 and S == 256 and os.path.exists(tf):
         with open(tf) as f:
             traffic = json.load(f).get("traffic_bytes_per_launch")
