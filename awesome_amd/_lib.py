@@ -15,7 +15,7 @@ INR_LOSS_SE, INR_LOSS_BCE = 0, 1
 INR_WEIGHT_NONE, INR_WEIGHT_EQUAL, INR_WEIGHT_RATIO, INR_WEIGHT_SSSDMS, INR_WEIGHT_EXPLICIT = 0, 1, 2, 3, 4
 INR_OPT_ADAM, INR_OPT_ADAMAX = 0, 1
 INR_OPT_HEADER_FLOATS = 8
-INRFIT_ABI_VERSION = 4
+INRFIT_ABI_VERSION = 5
 INR_ACT_RELU, INR_ACT_COS, INR_ACT_SIN = 0, 1, 2
 ACT_KINDS = {"relu": INR_ACT_RELU, "cos": INR_ACT_COS, "sin": INR_ACT_SIN}
 INR_FLOW_NORMAL_BLOCK, INR_FLOW_SIMPLE = 0, 1
@@ -58,7 +58,11 @@ class InrLossDesc(C.Structure):
 
 class InrJointLossDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("weight_mode", C.c_int32), ("ratio", C.c_float), ("alpha", C.c_float), ("beta", C.c_float),
-                ("clip_penalty", C.c_int32)]
+                ("clip_penalty", C.c_int32), ("form", C.c_int32), ("prior_kind", C.c_int32), ("prior_weight_mode", C.c_int32),
+                ("prior_ratio", C.c_float), ("gamma", C.c_float), ("extra_penalty", C.c_int32), ("n_scribble", C.c_int64)]
+
+
+JOINT_FBMS, JOINT_AWESOME_IMAGE, JOINT_AWESOME_PIXEL = 0, 1, 2
 
 
 class InrOptDesc(C.Structure):
@@ -131,6 +135,19 @@ EXPORTS = {
     "inrfit_joint_loss_workspace_bytes": (C.c_int64, [C.c_int64]),
     "inrfit_joint_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.POINTER(InrJointLossDesc), C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_joint_step_workspace_bytes": (C.c_int64, [C.POINTER(InrModelDesc), C.POINTER(InrGridDesc)]),
+    "inrfit_joint_step": (C.c_int, [C.POINTER(InrModelDesc), C.c_void_p, C.c_void_p, C.POINTER(InrGridDesc), C.c_void_p, C.c_void_p,
+                                    C.POINTER(InrJointLossDesc), C.POINTER(InrOptDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_pcn_joint_step": (C.c_int, [C.POINTER(InrModelDesc), C.POINTER(InrRnvpDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(InrGridDesc), C.c_void_p, C.c_void_p, C.POINTER(InrJointLossDesc),
+                                        C.POINTER(InrOptDesc), C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_cdn_joint_step": (C.c_int, [C.POINTER(InrModelDesc), C.POINTER(InrFlowDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(InrGridDesc), C.c_void_p, C.c_void_p, C.POINTER(InrJointLossDesc),
+                                        C.POINTER(InrOptDesc), C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_debug_tanh_exp": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "inrfit_miou": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_void_p,
                               C.c_void_p]),
     "inrfit_timing_begin": (C.c_int, [C.c_int]),

@@ -107,17 +107,140 @@ def _loss_takes_input(loss: Callable) -> bool:
 class JointTrainer:
     """One optimisation step of the joint segmentation + prior training (TorchAgent._perform_step, :428-551) on device-resident
     priors.  `wrapper` is a WrapperModule(segmentation_module, prior_module); `bank` holds one parameter row per image of the
-    prior module; `criterion(output, labels)` e.g. FBMSJointLoss.  One optimizer covers the segmentation module's parameters
-    and the prior module's Parameter objects (whose storage the bank re-points per image); per-image Adam moments of the prior
-    live in `prior_opt_state[key]`, swapped with the rows - the reference shares ONE optimizer state over all images' priors
-    (torch_agent.py:812-839 builds it once over model.parameters()), which is what `shared_prior_moments=True` reproduces."""
+    prior module; `criterion(output, labels)` e.g. FBMSJointLoss.  `optimizer`: ONE torch optimizer over the segmentation module's
+    parameters and the prior module's Parameter objects, as the reference builds it (torch_agent.py:812-839).
 
-    def __init__(self, wrapper: torch.nn.Module, bank: PriorBank, criterion: Callable, optimizer: torch.optim.Optimizer):
+    Two implementations of the same step:
+
+    * **fused** (default whenever it applies): the segmentation module runs in torch; everything behind its output - prior forward on
+      the image's bank row, sigmoid, the composite loss, d loss / d seg, the prior's backward from the activations of that same pass,
+      Adam / Adamax and enforce_convexity on the row in place - is ONE C-ABI call (`inrfit_joint_step` and its path-connected
+      variants, awesome_amd.joint).  The torch optimizer then steps the segmentation parameters only (the prior's Parameters never
+      receive a .grad, which torch.optim skips); the prior's hyper-parameters are read from their param group every step, so host
+      LR schedulers keep working.  Applies to: batch size 1 (what a PriorManager swap implies), FBMSJointLoss / AwesomeImageLoss
+      (before its extra penalty) with fusable criteria, Adam or Adamax without amsgrad, a prior with a device form (ICNN,
+      PathConnectedNet, ConvexDiffeomorphismNet; these two only without weight decay, which torch would also apply to their 1x1 /
+      linear layer).
+    * **autograd**: WrapperModule forward -> criterion -> loss.backward() through the HIP autograd bridges -> optimizer.step() ->
+      enforce_convexity(); any criterion, any optimizer.
+
+    The reference shares ONE optimizer state over all images' priors (it has one prior model whose VALUES are swapped): that is
+    `shared_prior_moments=True`, the default; False keeps Adam moments and step counts per image (fused path only)."""
+
+    def __init__(self, wrapper: torch.nn.Module, bank: PriorBank, criterion: Callable, optimizer: torch.optim.Optimizer,
+                 fused: Optional[bool] = None, shared_prior_moments: bool = True):
         self.wrapper, self.bank, self.criterion, self.optimizer = wrapper, bank, criterion, optimizer
         self.forward_additional_loss_args = _loss_takes_input(criterion)
+        self.shared_prior_moments = bool(shared_prior_moments)
+        self._fused_plan = self._plan_fused()
+        if fused and self._fused_plan is None:
+            raise ValueError("this combination of prior module / criterion / optimizer has no fused joint step")
+        self.fused = (self._fused_plan is not None) if fused is None else bool(fused)
+        self._t: Dict[Any, int] = {}
+        self._opt_state: Dict[Any, Tuple[torch.Tensor, Optional[torch.Tensor]]] = {}
+        self.last_status: Optional[torch.Tensor] = None
 
+    # -- fused path ----------------------------------------------------------------------------------------------------------
+    def _plan_fused(self) -> Optional[Dict[str, Any]]:
+        prior = getattr(self.wrapper, "prior_module", None)
+        if prior is None or self.bank.device.type != "cuda":
+            return None
+        if not getattr(self.wrapper, "use_prior_sigmoid", True) or not getattr(self.wrapper, "evaluate_prior", True):
+            return None
+        opt = self.optimizer
+        if isinstance(opt, torch.optim.Adam) and not isinstance(opt, torch.optim.AdamW):
+            kind = "adam"
+        elif isinstance(opt, torch.optim.Adamax):
+            kind = "adamax"
+        else:
+            return None
+        from .prior_bank import _ordered_parameters
+        pids = {id(p) for p in _ordered_parameters(prior)}
+        groups = [g for g in opt.param_groups if any(id(p) in pids for p in g["params"])]
+        if len(groups) != 1 or groups[0].get("amsgrad", False) or groups[0].get("maximize", False):
+            return None
+        if not pids <= {id(p) for p in groups[0]["params"]}:
+            return None
+        if hasattr(prior, "_specs"):
+            ispec, dspec = prior._specs()
+            family = "pcn" if type(dspec).__name__ == "RnvpSpec" else "cdn"
+            if kind != "adam" and family == "cdn":
+                return None
+        elif hasattr(prior, "spec"):
+            ispec, dspec, family = prior.spec, None, "icnn"
+            if getattr(prior, "fit_options", None):   # FCNet / encode nets: frozen ranges, no clamp - not part of the joint configs
+                return None
+        else:
+            return None
+        if not hasattr(self.criterion, "joint_desc") or self.criterion.joint_desc() is None:
+            return None
+        return dict(kind=kind, group=groups[0], family=family, ispec=ispec, dspec=dspec)
+
+    def _state_for(self, key: Any, plan) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        k = None if self.shared_prior_moments else key
+        st = self._opt_state.get(k)
+        if st is None:
+            from . import _lib as L
+            P = plan["ispec"].n_params
+            dev = self.bank.device
+            iopt = torch.zeros(2 * P + L.INR_OPT_HEADER_FLOATS, dtype=torch.float32, device=dev)
+            fopt = None if plan["dspec"] is None else torch.zeros(2 * plan["dspec"].n_params, dtype=torch.float32, device=dev)
+            st = self._opt_state[k] = (iopt, fopt)
+        return st
+
+    def _perform_step_fused(self, key: Any, inputs: Sequence[torch.Tensor], labels: torch.Tensor):
+        from . import icnn as K
+        from . import joint as J
+        plan, w = self._fused_plan, self.wrapper
+        desc = self.criterion.joint_desc()
+        g = plan["group"]
+        if desc is None or (plan["family"] != "icnn" and float(g.get("weight_decay", 0.0)) != 0.0):
+            return None
+        if desc.form != 0 and (desc.form != 1 or desc.extra_penalty):
+            return None   # AwesomeImageLoss with its extra penalty on: two data terms on the prior (inrfit_joint_step: INR_EUNSUPPORTED)
+        xi = inputs[0] if inputs[0].dim() == 4 else inputs[0][None]
+        if xi.shape[0] != 1:
+            return None
+        if plan["family"] == "pcn" and not all(float(b) > 0 for n, b in w.prior_module.named_buffers() if n.endswith("data_dep_init_done")):
+            return None   # ActNorm's data-dependent initialisation happens in the module's first forward: take the autograd step once
+        ai = tuple(a if not isinstance(a, torch.Tensor) or a.dim() == 4 else a[None] for a in inputs[1:])
+        self.optimizer.zero_grad()
+        seg = w.segmentation_output(xi, ai)                                   # (1, H, W), autograd attached
+        pa, _ = w.get_prior_args(xi, *ai, segm=seg)
+        coords = pa[0]
+        coords = coords[0] if coords.dim() == 4 else coords
+        grid = K.Grid.explicit(coords.reshape(coords.shape[0], -1).to(torch.float32).contiguous())
+        row = self.bank.row(key)
+        P = plan["ispec"].n_params
+        kc = None if self.shared_prior_moments else key
+        t = self._t[kc] = self._t.get(kc, 0) + 1
+        iopt, fopt = self._state_for(key, plan)
+        segd = seg.detach().reshape(-1).to(torch.float32).contiguous()
+        tgt = labels.detach().reshape(-1).to(torch.float32).contiguous()
+        hp = dict(step=t, lr=float(g["lr"]), betas=tuple(g.get("betas", (0.9, 0.999))), eps=float(g.get("eps", 1e-8)))
+        if plan["family"] == "icnn":
+            res = J.joint_step(plan["ispec"], row, iopt, grid, segd, tgt, desc, optimizer=plan["kind"],
+                               weight_decay=float(g.get("weight_decay", 0.0)), clamp=True, **hp)
+        elif plan["family"] == "pcn":
+            res = J.pcn_joint_step(plan["ispec"], plan["dspec"], row[:P], row[P:], iopt, fopt, grid, segd, tgt, desc,
+                                   optimizer=plan["kind"], flow_weight_decay=0.0, **hp)
+        else:
+            res = J.cdn_joint_step(plan["ispec"], plan["dspec"], row[:P], row[P:], iopt, fopt, grid, segd, tgt, desc,
+                                   weight_decay_on_weight_g=0.0, **hp)
+        self.last_status = res.status
+        if seg.requires_grad:
+            seg.backward(res.dseg.view_as(seg))
+        self.optimizer.step()                                                  # segmentation parameters only
+        out = torch.cat([seg.detach(), torch.sigmoid(res.prior_logits).view_as(seg)], dim=0)[None]
+        return res.loss[0], out
+
+    # -- the step ------------------------------------------------------------------------------------------------------------
     def perform_step(self, key: Any, inputs: Sequence[torch.Tensor], labels: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """-> (loss, output) as device tensors (no host sync)."""
+        if self.fused and self._fused_plan is not None:
+            done = self._perform_step_fused(key, inputs, labels)
+            if done is not None:
+                return done
         self.optimizer.zero_grad()
         with self.bank.manager(self.wrapper.prior_module, key):
             out = self.wrapper(*inputs)

@@ -413,6 +413,7 @@ struct FlowUpdArgs {
     float bc2_sqrt, one_minus_b1, one_minus_b2, wd_g;
     int mode;             // 0 = Adam step + effective weights, 1 = gradients only, 2 = effective weights only (prep)
     const int32_t* status;   // per image (mode 0): frozen by a non-finite loss -> no step, like the ICNN and RealNVP updates
+    const float* gscale;     // [n_images] factor on every reduced gradient (the joint step's detached clip factor), or null
 };
 
 __device__ __forceinline__ float block_sum256(float v, float* sm) {  // fixed-order sum over a 256-thread block
@@ -423,7 +424,8 @@ __device__ __forceinline__ float block_sum256(float v, float* sm) {  // fixed-or
     return ((sm[0] + sm[1]) + sm[2]) + sm[3];
 }
 
-__device__ __forceinline__ float adam_apply(const FlowUpdArgs& u, float p, float g, float lr, float wd, float* m_, float* v_) {
+__device__ __forceinline__ float adam_apply(const FlowUpdArgs& u, float gmul, float p, float g, float lr, float wd, float* m_, float* v_) {
+    g = g * gmul;   // the joint step's detached clip factor (x 1.0 is exact: the plain fits are bit-identical)
     if (wd != 0.f) g = __fadd_rn(g, __fmul_rn(wd, p));
     float m = *m_, v = *v_;
     m = __fadd_rn(m, __fmul_rn(u.one_minus_b1, __fsub_rn(g, m)));
@@ -439,10 +441,14 @@ __device__ __forceinline__ float adam_apply(const FlowUpdArgs& u, float p, float
 __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
     __shared__ float sm[4];
     const int img = blockIdx.y, nb = blockIdx.x, tid = threadIdx.x;
+    const float gmul = u.gscale != nullptr ? u.gscale[img] : 1.f;
     const FlowMap& m = u.m;
-    // an image the ICNN update of this step has frozen (non-finite loss: status set one launch earlier) takes no optimizer step:
-    // its effective weights are rebuilt from the unchanged parameters
-    const int mode = (u.mode == 0 && u.status != nullptr && u.status[img] != INR_STATUS_OK) ? 2 : u.mode;
+    // an image the ICNN update of this step has frozen (non-finite loss) takes no optimizer step: its effective weights are rebuilt
+    // from the unchanged parameters.  ONE source of truth with the ICNN update: the "frozen" flag it has just written for step t
+    // into the header's double buffer (hdr[6 + ((t + 1) & 1)], one launch earlier on this stream) - `status` may be NULL.
+    const bool frozen = (u.lr_hdr != nullptr && u.lr_hdr[(size_t)img * u.hdr_stride + 6 + ((u.t + 1) & 1)] != 0.f) ||
+                        (u.status != nullptr && u.status[img] != INR_STATUS_OK);
+    const int mode = (u.mode == 0 && frozen) ? 2 : u.mode;
     const int W = m.W, K = m.K;
     float* __restrict__ fp = u.FP + (size_t)img * m.FP;
     float* __restrict__ fe = u.FE + (size_t)img * m.FE;
@@ -513,9 +519,9 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
                 return;
             }
             if (on) {
-                v1 = adam_apply(u, v1, dv1, lr, 0.f, &om[pb + tid], &ov[pb + tid]);
-                b1 = adam_apply(u, b1, db1, lr, 0.f, &om[pb + W + 1 + tid], &ov[pb + W + 1 + tid]);
-                v2 = adam_apply(u, v2, dv2, lr, 0.f, &om[pb + 2 * W + 1 + tid], &ov[pb + 2 * W + 1 + tid]);
+                v1 = adam_apply(u, gmul, v1, dv1, lr, 0.f, &om[pb + tid], &ov[pb + tid]);
+                b1 = adam_apply(u, gmul, b1, db1, lr, 0.f, &om[pb + W + 1 + tid], &ov[pb + W + 1 + tid]);
+                v2 = adam_apply(u, gmul, v2, dv2, lr, 0.f, &om[pb + 2 * W + 1 + tid], &ov[pb + 2 * W + 1 + tid]);
                 fp[pb + tid] = v1;
                 fp[pb + W + 1 + tid] = b1;
                 fp[pb + 2 * W + 1 + tid] = v2;
@@ -524,9 +530,9 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
             {
                 float m1 = om[pb + W], q1 = ov[pb + W], m2 = om[pb + 3 * W + 1], q2 = ov[pb + 3 * W + 1];
                 float m3 = om[pb + 3 * W + 2], q3 = ov[pb + 3 * W + 2];
-                g1 = adam_apply(u, g1, dg1, lr, u.wd_g, &m1, &q1);
-                g2 = adam_apply(u, g2, dg2, lr, u.wd_g, &m2, &q2);
-                b2 = adam_apply(u, b2, db2, lr, 0.f, &m3, &q3);
+                g1 = adam_apply(u, gmul, g1, dg1, lr, u.wd_g, &m1, &q1);
+                g2 = adam_apply(u, gmul, g2, dg2, lr, u.wd_g, &m2, &q2);
+                b2 = adam_apply(u, gmul, b2, db2, lr, 0.f, &m3, &q3);
                 __syncthreads();  // everyone has read the old state
                 if (tid == 0) {
                     om[pb + W] = m1; ov[pb + W] = q1; om[pb + 3 * W + 1] = m2; ov[pb + 3 * W + 1] = q2;
@@ -574,10 +580,10 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
             if (mode == 1) {
                 go[pb] = dw; go[pb + 1] = dsb; go[pb + 2] = dsg; go[pb + 3] = dsv;
             } else {
-                w = adam_apply(u, w, dw, lr, 0.f, &om[pb], &ov[pb]);
-                sb = adam_apply(u, sb, dsb, lr, 0.f, &om[pb + 1], &ov[pb + 1]);
-                sg = adam_apply(u, sg, dsg, lr, u.wd_g, &om[pb + 2], &ov[pb + 2]);
-                sv = adam_apply(u, sv, dsv, lr, 0.f, &om[pb + 3], &ov[pb + 3]);
+                w = adam_apply(u, gmul, w, dw, lr, 0.f, &om[pb], &ov[pb]);
+                sb = adam_apply(u, gmul, sb, dsb, lr, 0.f, &om[pb + 1], &ov[pb + 1]);
+                sg = adam_apply(u, gmul, sg, dsg, lr, u.wd_g, &om[pb + 2], &ov[pb + 2]);
+                sv = adam_apply(u, gmul, sv, dsv, lr, 0.f, &om[pb + 3], &ov[pb + 3]);
                 fp[pb] = w; fp[pb + 1] = sb; fp[pb + 2] = sg; fp[pb + 3] = sv;
             }
         }
@@ -589,7 +595,7 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
             const float d = tot[3 * K + k];
             if (mode == 1) go[k] = d;
             else {
-                p = adam_apply(u, p, d, lr, 0.f, &om[k], &ov[k]);
+                p = adam_apply(u, gmul, p, d, lr, 0.f, &om[k], &ov[k]);
                 fp[k] = p;
             }
         }

@@ -54,6 +54,7 @@ struct UpdArgs {
     int clamp_lo[3], clamp_hi[3];  // flat ranges projected onto >= 0 (ln.weight of every hidden layer, out.ln.weight)
     int freeze_lo[3], freeze_hi[3];  // flat ranges that are never updated (the skip weights when opt.freeze_skips)
     int input_hi;                    // opt.freeze_input: flat range [0, input_hi) = input.weight | input.bias is never updated
+    const float* gscale;             // [n_images] factor on the reduced gradient (device; the joint step's detached clip factor), or null
 };
 
 constexpr int UPD_MAX_PARAMS = 256;  // most parameters per block
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
     float gsum = 0.f;
 #pragma unroll
     for (int k = 0; k < UPD_GROUPS; ++k) gsum += red[k][jl];  // fixed order: reproducible
+    if (u.gscale != nullptr && j < u.P) gsum *= u.gscale[img];   // joint step: the prior's gradient is linear in the penalty coefficient
 
     UPD_STAMP(2);
     if (u.mode == 1) {
@@ -561,7 +563,7 @@ int inrfit_query(int* abi_version, int* max_hidden, int* lds_bytes) {
 #define INRFIT_BUILD_FLAGS "unknown (not built by awesome_amd/build.py)"
 #endif
 const char* inrfit_build_info(void) {
-    return "libinrfit abi " "4" "; gfx950; slab_base 256; " __VERSION__ "; flags: " INRFIT_BUILD_FLAGS;
+    return "libinrfit abi " "5" "; gfx950; slab_base 256; " __VERSION__ "; flags: " INRFIT_BUILD_FLAGS;
 }
 
 int inrfit_debug_set_slab_base(int slab_base) {
@@ -932,9 +934,10 @@ CdnWs carve_cdn(const KernelEntry* e, const InrFlowDesc* f, const InrGridDesc* g
 
 void launch_flow_update(const CdnWs& w, const InrFlowDesc* f, int n_images, int mode, float* FP, float* opt, float* grads_out,
                         const InrOptDesc* od, float wd_g, int t, const float* lr_hdr, long long hdr_stride, hipStream_t s,
-                        const int32_t* status = nullptr) {
+                        const int32_t* status = nullptr, const float* gscale = nullptr) {
     FlowUpdArgs u{};
     u.status = status;
+    u.gscale = gscale;
     u.FP = FP;
     u.FE = w.FE;
     u.opt = opt;
@@ -1218,8 +1221,8 @@ PcnWs carve_pcn(const KernelEntry* e, const InrRnvpDesc* r, const InrGridDesc* g
     const long long N = grid->n_points;
     w.rm = make_rnvp_map(r);
     const int C = w.rm.C, F = w.rm.F;
-    w.Q = 1;   // two points per lane (half the record reads per point) measured slower even at 262144 points: 73 vs 70 us
-               // forward, 155 vs 137 us backward - the loops are VALU-bound, not LDS-bound
+    w.Q = 1;   // one point per lane: two (half the record reads per point) measured slower even at 262144 points - 73 vs 70 us
+               // forward, 155 vs 137 us backward; the loops are VALU-bound, not LDS-bound - and are no longer instantiated
     w.blocks1 = (int)((N + 256 * w.Q - 1) / (256 * w.Q));
     w.chunks = 64;   // x F flows x 4 waves: enough waves for the 1024 SIMDs
     while (w.chunks > 1 && N / w.chunks < 1024) w.chunks /= 2;
@@ -1256,12 +1259,8 @@ int rnvp_set_lds() {
     bool ok = true;
     ok &= hipFuncSetAttribute((const void*)rnvp_fwd_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
     ok &= hipFuncSetAttribute((const void*)rnvp_fwd_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
-    ok &= hipFuncSetAttribute((const void*)rnvp_fwd_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
-    ok &= hipFuncSetAttribute((const void*)rnvp_fwd_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
     ok &= hipFuncSetAttribute((const void*)rnvp_bwd_points_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
     ok &= hipFuncSetAttribute((const void*)rnvp_bwd_points_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
-    ok &= hipFuncSetAttribute((const void*)rnvp_bwd_points_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
-    ok &= hipFuncSetAttribute((const void*)rnvp_bwd_points_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
     ok &= hipFuncSetAttribute((const void*)rnvp_inverse_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
     ok &= hipFuncSetAttribute((const void*)rnvp_inverse_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
     rc = ok ? INR_OK : INR_ENODEVICE;
@@ -1288,6 +1287,7 @@ int check_pcn(const InrModelDesc* model, const InrRnvpDesc* r, const InrGridDesc
     }
     *w_out = carve_pcn(e, r, grid, n_images, workspace);
     if (workspace_bytes < w_out->bytes) return INR_EWORKSPACE;
+    if (const int rc = rnvp_set_lds()) return rc;   // flow records of wide MLPs exceed the default 64 KB of dynamic LDS
     if (e) {
         const int rc = set_lds(e);
         if (rc) return rc;
@@ -1321,11 +1321,9 @@ void launch_rnvp_fwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, i
     const dim3 g(w.blocks1, n_images);
     const size_t lds = (size_t)w.rm.LDSF * sizeof(float);
     if (w.rm.C == 2) {
-        if (w.Q == 1) hipLaunchKernelGGL((rnvp_fwd_kernel<2, 1>), g, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((rnvp_fwd_kernel<2, 2>), g, dim3(256), lds, s, a);
+        hipLaunchKernelGGL((rnvp_fwd_kernel<2, 1>), g, dim3(256), lds, s, a);
     } else {
-        if (w.Q == 1) hipLaunchKernelGGL((rnvp_fwd_kernel<3, 1>), g, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((rnvp_fwd_kernel<3, 2>), g, dim3(256), lds, s, a);
+        hipLaunchKernelGGL((rnvp_fwd_kernel<3, 1>), g, dim3(256), lds, s, a);
     }
 }
 
@@ -1343,11 +1341,9 @@ void launch_rnvp_bwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, i
     const dim3 g1(w.blocks1, n_images);
     const size_t lds = (size_t)(w.rm.LDSF + 4 * w.S1) * sizeof(float);
     if (w.rm.C == 2) {
-        if (w.Q == 1) hipLaunchKernelGGL((rnvp_bwd_points_kernel<2, 1>), g1, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((rnvp_bwd_points_kernel<2, 2>), g1, dim3(256), lds, s, a);
+        hipLaunchKernelGGL((rnvp_bwd_points_kernel<2, 1>), g1, dim3(256), lds, s, a);
     } else {
-        if (w.Q == 1) hipLaunchKernelGGL((rnvp_bwd_points_kernel<3, 1>), g1, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((rnvp_bwd_points_kernel<3, 2>), g1, dim3(256), lds, s, a);
+        hipLaunchKernelGGL((rnvp_bwd_points_kernel<3, 1>), g1, dim3(256), lds, s, a);
     }
     RnvpUnitsArgs ua{};
     ua.RP = rp;
@@ -1629,31 +1625,332 @@ int inrfit_pcn_fit(const InrModelDesc* model, const InrRnvpDesc* rnvp, float* ic
 
 int64_t inrfit_joint_loss_workspace_bytes(int64_t n_elems) {
     if (n_elems <= 0) return INR_EINVAL;
-    return (int64_t)(JL_MAX_BLOCKS * 4 + 8) * 4;
+    return (int64_t)(JL_MAX_BLOCKS * JL_PART + JL_RES + 8) * 4;
 }
 
-int inrfit_joint_loss(const float* output, const float* target, int batch, int64_t hw, const InrJointLossDesc* desc,
-                      float* loss_out, float* doutput, void* workspace, int64_t workspace_bytes, void* stream) {
-    if (!output || !target || !desc || !loss_out || !workspace || batch <= 0 || hw <= 0) return INR_EINVAL;
-    if (desc->kind != INR_LOSS_SE && desc->kind != INR_LOSS_BCE) return INR_EINVAL;
-    if (desc->weight_mode < INR_WEIGHT_NONE || desc->weight_mode > INR_WEIGHT_SSSDMS) return INR_EINVAL;
-    if (workspace_bytes < inrfit_joint_loss_workspace_bytes((int64_t)batch * hw)) return INR_EWORKSPACE;
+namespace {
+
+int check_joint_desc(const InrJointLossDesc* d) {
+    if (!d) return INR_EINVAL;
+    if (d->kind != INR_LOSS_SE && d->kind != INR_LOSS_BCE) return INR_EINVAL;
+    if (d->weight_mode < INR_WEIGHT_NONE || d->weight_mode > INR_WEIGHT_SSSDMS) return INR_EINVAL;
+    if (d->form < INR_JOINT_FBMS || d->form > INR_JOINT_AWESOME_PIXEL) return INR_EINVAL;
+    if (d->form == INR_JOINT_AWESOME_IMAGE) {
+        if (d->prior_kind != INR_LOSS_SE && d->prior_kind != INR_LOSS_BCE) return INR_EINVAL;
+        if (d->prior_weight_mode < INR_WEIGHT_NONE || d->prior_weight_mode > INR_WEIGHT_SSSDMS) return INR_EINVAL;
+    }
+    return INR_OK;
+}
+
+// kernel arguments of the composite loss for `batch` items of `n` pixels (see joint_loss.h for the three layouts)
+int make_joint_args(const float* output, const float* target, int batch, long long n, const InrJointLossDesc* desc, float* doutput,
+                    void* workspace, JointLossArgs* out) {
     JointLossArgs a{};
     a.output = output;
     a.target = target;
     a.doutput = doutput;
     a.part = (float*)workspace;
-    a.res = a.part + JL_MAX_BLOCKS * 4;
-    a.hw = hw;
-    a.n = (long long)batch * hw;
-    const long long want = (a.n + 1023) / 1024;   // >= 4 pixels per thread
-    a.blocks = (int)(want < 1 ? 1 : (want > JL_MAX_BLOCKS ? JL_MAX_BLOCKS : want));
+    a.res = a.part + JL_MAX_BLOCKS * JL_PART;
+    a.n = n;
+    a.batch = batch;
+    a.total = (long long)batch * n;
     a.d = *desc;
+    if (desc->form == INR_JOINT_AWESOME_PIXEL) {
+        a.es = 2; a.cs = 1; a.bs = 2 * n;
+        a.n_data = desc->n_scribble > 0 ? desc->n_scribble : n;
+        if (a.n_data > n) return INR_EINVAL;
+        a.pen_lo = n - a.n_data;                       // awesome_loss.py:58-59 slices [random:], random = n - n_scribble
+        a.pen_on = desc->extra_penalty && a.n_data < n;
+        a.d.prior_kind = desc->kind;                   // one criterion for both terms
+        a.d.prior_weight_mode = desc->weight_mode;
+        a.d.prior_ratio = desc->ratio;
+    } else {
+        a.es = 1; a.cs = n; a.bs = 2 * n;
+        a.n_data = n;
+        a.pen_lo = 0;
+        a.pen_on = desc->form == INR_JOINT_FBMS ? 1 : (desc->extra_penalty ? 1 : 0);
+    }
+    const long long want = (a.total + 1023) / 1024;   // >= 4 pixels per thread
+    a.blocks = (int)(want < 1 ? 1 : (want > JL_MAX_BLOCKS ? JL_MAX_BLOCKS : want));
+    *out = a;
+    return INR_OK;
+}
+
+}  // namespace
+
+int inrfit_joint_loss(const float* output, const float* target, int batch, int64_t hw, const InrJointLossDesc* desc,
+                      float* loss_out, float* doutput, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!output || !target || !loss_out || !workspace || batch <= 0 || hw <= 0) return INR_EINVAL;
+    int rc = check_joint_desc(desc);
+    if (rc) return rc;
+    if (workspace_bytes < inrfit_joint_loss_workspace_bytes((int64_t)batch * hw)) return INR_EWORKSPACE;
+    JointLossArgs a;
+    if ((rc = make_joint_args(output, target, batch, hw, desc, doutput, workspace, &a))) return rc;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(joint_loss_partial_kernel, dim3(a.blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(joint_loss_partial_kernel<true>, dim3(a.blocks), dim3(256), 0, s, a);
     hipLaunchKernelGGL(joint_loss_finish_kernel, dim3(1), dim3(256), 0, s, a);
-    if (doutput) hipLaunchKernelGGL(joint_loss_grad_kernel, dim3(a.blocks), dim3(256), 0, s, a);
+    if (doutput) hipLaunchKernelGGL(joint_loss_grad_kernel<false>, dim3(a.blocks), dim3(256), 0, s, a, (const float*)nullptr, (float*)nullptr);
     if (hipMemcpyAsync(loss_out, a.res, 4 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return INR_ELAUNCH;
+    return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fused joint step (one image): composite loss + prior forward/backward + optimizer, no host round trip
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// one thread: this step's learning rate into the ICNN header's double buffer (the update kernels read hdr[t & 1]), the
+// "frozen" flags cleared (every joint step stands alone), and the data-term coefficients of the prior's step kernel:
+// FBMS: the penalty beta mean((prior - seg)^2) as the SE term against the soft target `seg` with the UNCLIPPED, unscaled
+// coefficient 1/n (joint_step_finish_kernel turns the kernel's own loss column into the clip factor);
+// AWESOME_IMAGE: left to loss_coef_kernel (class weights of the prior criterion from the targets).
+__global__ void joint_prep_kernel(float* hdr, float lr, int t, float* coef, float c, int write_coef) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        hdr[t & 1] = lr;
+        hdr[2] = lr;
+        hdr[6] = hdr[7] = 0.f;
+        if (write_coef) coef[0] = coef[1] = c;
+    }
+}
+
+struct JointFinArgs {
+    JointLossArgs jl;       // part = the segmentation-side partial sums (joint_loss_partial_kernel<false>)
+    const float* slabs;     // the step kernel's gradient slabs of this step [wgs][PS]
+    int wgs, PS, loss_col;
+    float* gscale;          // [1] -> the update kernels
+    float* loss_out;        // [4] or null
+};
+
+__global__ __launch_bounds__(256) void joint_step_finish_kernel(const JointFinArgs f) {
+    __shared__ float sm[4];
+    const JointLossArgs& a = f.jl;
+    float v[3] = {0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < a.blocks; b += 256)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] += a.part[JL_PART * b + k];
+    float tot[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tot[k] = jl_block_sum(v[k], sm);
+    float lc = 0.f;   // the prior's share, as the step kernel summed it: FBMS mean((prior - seg)^2); AWESOME_IMAGE mean(w' pcrit)
+    for (int w = threadIdx.x; w < f.wgs; w += 256) lc += f.slabs[(size_t)w * f.PS + f.loss_col];
+    const float prior_term = jl_block_sum(lc, sm);
+    if (threadIdx.x != 0) return;
+    float gs;
+    if (a.d.form == INR_JOINT_FBMS) {
+        jl_finish(a, tot, prior_term * (float)a.total);     // jl_finish divides the penalty sum by n again
+        gs = a.res[3] * a.d.beta;                           // d penalty / d theta = clip * beta * d mean((p - s)^2) / d theta
+    } else {
+        const float nd = (float)a.total, nfg = tot[2];
+        const float w = jl_class_weight(a.d.weight_mode, a.d.ratio, nfg, nd - nfg);
+        const float seg_raw = (w * tot[0] + tot[1]) / nd;
+        a.res[0] = seg_raw + a.d.alpha * prior_term;
+        a.res[1] = seg_raw;
+        a.res[2] = 0.f;
+        a.res[3] = 1.f;
+        a.res[4] = w / nd;
+        a.res[5] = 1.f / nd;
+        a.res[6] = 0.f;
+        a.res[7] = nfg;
+        gs = a.d.alpha;
+    }
+    f.gscale[0] = gs;
+    if (f.loss_out) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f.loss_out[k] = a.res[k];
+    }
+}
+
+// what the three joint-step entry points share, before and after the prior's own kernels
+struct JointCtx {
+    JointLossArgs jl;
+    float* gscale;
+    float* logits;
+    InrLossDesc prior_loss;   // the data term the prior's step kernel evaluates
+    const float* prior_targets;
+};
+
+int joint_begin(const InrJointLossDesc* desc, const InrOptDesc* opt, const float* seg, const float* target, long long N, int step,
+                float* prior_logits, float* jws, float* icnn_hdr, float* coef, hipStream_t s, JointCtx* c) {
+    int rc = check_joint_desc(desc);
+    if (rc) return rc;
+    if (!opt || (opt->kind != INR_OPT_ADAM && opt->kind != INR_OPT_ADAMAX) || step < 1) return INR_EINVAL;
+    if (desc->form == INR_JOINT_AWESOME_PIXEL) return INR_EUNSUPPORTED;            // pixel mode has no dense-grid prior pass
+    if (desc->form == INR_JOINT_AWESOME_IMAGE && desc->extra_penalty) return INR_EUNSUPPORTED;   // two data terms on the prior
+    // seg-side sums over the single image: output = seg (channel stride unused), PRIOR = false
+    if ((rc = make_joint_args(seg, target, 1, N, desc, nullptr, jws, &c->jl))) return rc;
+    c->gscale = c->jl.res + JL_RES;
+    c->logits = prior_logits;
+    hipLaunchKernelGGL(joint_loss_partial_kernel<false>, dim3(c->jl.blocks), dim3(256), 0, s, c->jl);
+    const bool fbms = desc->form == INR_JOINT_FBMS;
+    hipLaunchKernelGGL(joint_prep_kernel, dim3(1), dim3(64), 0, s, icnn_hdr, opt->lr, step, coef, 1.f / (float)N, fbms ? 1 : 0);
+    if (fbms) {
+        c->prior_loss = InrLossDesc{INR_LOSS_SE, INR_WEIGHT_EXPLICIT, 1.f, 1.f / (float)N, 1.f / (float)N};
+        c->prior_targets = seg;
+    } else {
+        c->prior_loss = InrLossDesc{desc->prior_kind, desc->prior_weight_mode, desc->prior_ratio, 0.f, 0.f};
+        c->prior_targets = target;
+        hipLaunchKernelGGL(loss_coef_kernel, dim3(1), dim3(256), 0, s, target, N, c->prior_loss, coef);
+    }
+    return INR_OK;
+}
+
+void joint_finish(const JointCtx& c, const KernelEntry* e, const Workspace& w, float* loss_out, hipStream_t s) {
+    JointFinArgs f{};
+    f.jl = c.jl;
+    f.slabs = w.slabs;
+    f.wgs = w.wgs;
+    f.PS = w.PS;
+    f.loss_col = e->img.sl_cols - 1;
+    f.gscale = c.gscale;
+    f.loss_out = loss_out;
+    hipLaunchKernelGGL(joint_step_finish_kernel, dim3(1), dim3(256), 0, s, f);
+}
+
+void joint_dseg(const JointCtx& c, float* dseg, hipStream_t s) {
+    hipLaunchKernelGGL(joint_loss_grad_kernel<true>, dim3(c.jl.blocks), dim3(256), 0, s, c.jl, (const float*)c.logits, dseg);
+}
+
+void set_step_consts(UpdArgs& u, const InrOptDesc* opt, int t) {
+    u.t = t;
+    u.bc1 = 1.0 - pow((double)opt->beta1, (double)t);
+    u.bc2_sqrt = (float)sqrt(1.0 - pow((double)opt->beta2, (double)t));
+    u.hist_idx = 0;
+}
+
+long long joint_ws_bytes(long long N) { return align256(inrfit_joint_loss_workspace_bytes(N)) + align256(N * 4); }
+
+}  // namespace
+
+int64_t inrfit_joint_step_workspace_bytes(const InrModelDesc* model, const InrGridDesc* grid) {
+    const int64_t b = inrfit_workspace_bytes(model, grid, 1);
+    if (b < 0) return b;
+    return align256(b) + joint_ws_bytes(grid->n_points);
+}
+
+int inrfit_joint_step(const InrModelDesc* model, float* params, float* opt_state, const InrGridDesc* grid, const float* seg,
+                      const float* target, const InrJointLossDesc* desc, const InrOptDesc* opt, int step, float* loss_out,
+                      float* dseg, float* prior_logits, int32_t* status, void* workspace, int64_t workspace_bytes, void* stream) {
+    const KernelEntry* e;
+    Workspace w;
+    if (!params || !opt_state || !seg || !target || !dseg) return INR_EINVAL;
+    int rc = prepare(model, grid, 1, workspace, workspace_bytes, &e, &w);
+    if (rc) return rc;
+    const long long N = grid->n_points;
+    if (workspace_bytes < inrfit_joint_step_workspace_bytes(model, grid)) return INR_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* jws = (float*)((char*)workspace + align256(w.bytes));
+    float* logits = prior_logits ? prior_logits : (float*)((char*)jws + align256(inrfit_joint_loss_workspace_bytes(N)));
+    JointCtx c;
+    if ((rc = joint_begin(desc, opt, seg, target, N, step, logits, jws, opt_state + 2 * (size_t)e->P, w.coef, s, &c))) return rc;
+    if (status && hipMemsetAsync(status, 0, sizeof(int32_t), s) != hipSuccess) return INR_ELAUNCH;
+    if ((rc = launch_pack(e, w, params, 1, s))) return rc;
+    w.set_step(step);
+    if ((rc = launch_step(e, w, true, grid, c.prior_targets, c.prior_loss.kind, 1, logits, s))) return rc;
+    joint_finish(c, e, w, loss_out, s);
+    InrOptDesc o = *opt;
+    o.plateau = 0;
+    UpdArgs u = make_upd_args(e, w, params, opt_state, nullptr, status, &o, 1, 1);
+    u.slabs = w.slabs;
+    u.gscale = c.gscale;
+    set_step_consts(u, &o, step);
+    hipLaunchKernelGGL(icnn_update_kernel, upd_grid(e->img.sl_cols, 1), upd_block(e->img.sl_cols), 0, s, u);
+    joint_dseg(c, dseg, s);
+    return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
+}
+
+int inrfit_pcn_joint_step(const InrModelDesc* model, const InrRnvpDesc* rnvp, float* icnn_params, float* flow_params,
+                          float* icnn_opt_state, float* flow_opt_state, const InrGridDesc* grid, const float* seg,
+                          const float* target, const InrJointLossDesc* desc, const InrOptDesc* opt, float flow_weight_decay,
+                          int step, float* loss_out, float* dseg, float* prior_logits, int32_t* status, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
+    const KernelEntry* e;
+    PcnWs w;
+    if (!icnn_params || !flow_params || !icnn_opt_state || !flow_opt_state || !seg || !target || !dseg) return INR_EINVAL;
+    int rc = check_pcn(model, rnvp, grid, 1, workspace, workspace_bytes, true, &e, &w);
+    if (rc) return rc;
+    const long long N = grid->n_points;
+    if (workspace_bytes < align256(w.bytes) + joint_ws_bytes(N)) return INR_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* jws = (float*)((char*)workspace + align256(w.bytes));
+    float* logits = prior_logits ? prior_logits : (float*)((char*)jws + align256(inrfit_joint_loss_workspace_bytes(N)));
+    JointCtx c;
+    float* hdr = icnn_opt_state + 2 * (size_t)e->P;
+    if ((rc = joint_begin(desc, opt, seg, target, N, step, logits, jws, hdr, w.icnn.coef, s, &c))) return rc;
+    if (status && hipMemsetAsync(status, 0, sizeof(int32_t), s) != hipSuccess) return INR_ELAUNCH;
+    if ((rc = launch_pack(e, w.icnn, icnn_params, 1, s))) return rc;
+    w.icnn.set_step(step);
+    launch_rnvp_fwd(w, flow_params, grid, 1, w.xd, true, s);
+    if ((rc = launch_step(e, w.icnn, true, &w.dgrid, c.prior_targets, c.prior_loss.kind, 1, logits, s, w.dxd))) return rc;
+    joint_finish(c, e, w.icnn, loss_out, s);
+    InrOptDesc o = *opt;
+    o.plateau = 0;
+    UpdArgs u = make_upd_args(e, w.icnn, icnn_params, icnn_opt_state, nullptr, status, &o, 1, 1);
+    u.slabs = w.icnn.slabs;
+    u.gscale = c.gscale;
+    set_step_consts(u, &o, step);
+    hipLaunchKernelGGL(icnn_update_kernel, upd_grid(e->img.sl_cols, 1), upd_block(e->img.sl_cols), 0, s, u);
+    launch_rnvp_bwd(w, flow_params, grid, 1, s);
+    RnvpUpdArgs ru = make_rnvp_upd_args(w, 1, 0, flow_params, flow_opt_state, nullptr, &o, flow_weight_decay, step, hdr,
+                                        2 * (long long)e->P + INR_OPT_HEADER_FLOATS, status);
+    ru.gscale = c.gscale;
+    launch_rnvp_update_args(w, 1, ru, s);
+    joint_dseg(c, dseg, s);
+    return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
+}
+
+int inrfit_cdn_joint_step(const InrModelDesc* model, const InrFlowDesc* flow, float* icnn_params, float* flow_params,
+                          float* icnn_opt_state, float* flow_opt_state, const InrGridDesc* grid, const float* seg,
+                          const float* target, const InrJointLossDesc* desc, const InrOptDesc* opt, float wd_on_weight_g,
+                          int step, float* loss_out, float* dseg, float* prior_logits, int32_t* status, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
+    const KernelEntry* e;
+    CdnWs w;
+    if (!icnn_params || !flow_params || !icnn_opt_state || !flow_opt_state || !seg || !target || !dseg) return INR_EINVAL;
+    if (!opt || opt->kind != INR_OPT_ADAM) return INR_EINVAL;
+    int rc = check_cdn(model, flow, grid, 1, workspace, workspace_bytes, true, &e, &w);
+    if (rc) return rc;
+    const long long N = grid->n_points;
+    if (workspace_bytes < align256(w.bytes) + joint_ws_bytes(N)) return INR_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* jws = (float*)((char*)workspace + align256(w.bytes));
+    float* logits = prior_logits ? prior_logits : (float*)((char*)jws + align256(inrfit_joint_loss_workspace_bytes(N)));
+    JointCtx c;
+    float* hdr = icnn_opt_state + 2 * (size_t)e->P;
+    if ((rc = joint_begin(desc, opt, seg, target, N, step, logits, jws, hdr, w.icnn.coef, s, &c))) return rc;
+    if (status && hipMemsetAsync(status, 0, sizeof(int32_t), s) != hipSuccess) return INR_ELAUNCH;
+    if ((rc = launch_pack(e, w.icnn, icnn_params, 1, s))) return rc;
+    w.icnn.set_step(step);
+    launch_flow_update(w, flow, 1, 2, flow_params, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0, s);  // effective weights
+    launch_flow_fwd(w, grid, 1, w.xd, s);
+    if ((rc = launch_step(e, w.icnn, true, &w.dgrid, c.prior_targets, c.prior_loss.kind, 1, logits, s, w.dxd))) return rc;
+    joint_finish(c, e, w.icnn, loss_out, s);
+    InrOptDesc o = *opt;
+    o.plateau = 0;
+    UpdArgs u = make_upd_args(e, w.icnn, icnn_params, icnn_opt_state, nullptr, status, &o, 1, 1);
+    u.slabs = w.icnn.slabs;
+    u.gscale = c.gscale;
+    set_step_consts(u, &o, step);
+    hipLaunchKernelGGL(icnn_update_kernel, upd_grid(e->img.sl_cols, 1), upd_block(e->img.sl_cols), 0, s, u);
+    launch_flow_bwd(w, flow, grid, 1, s);
+    launch_flow_update(w, flow, 1, 0, flow_params, flow_opt_state, nullptr, &o, wd_on_weight_g, step, hdr,
+                       2 * (long long)e->P + INR_OPT_HEADER_FLOATS, s, status, c.gscale);
+    joint_dseg(c, dseg, s);
+    return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
+}
+
+__global__ __launch_bounds__(256) void debug_tanh_exp_kernel(const float* __restrict__ x, long long n, float* __restrict__ th,
+                                                              float* __restrict__ ex) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        th[i] = fast_tanh(x[i]);
+        ex[i] = fast_exp(x[i]);
+    }
+}
+
+int inrfit_debug_tanh_exp(const float* x, int64_t n, float* tanh_out, float* exp_out, void* stream) {
+    if (!x || !tanh_out || !exp_out || n <= 0) return INR_EINVAL;
+    hipLaunchKernelGGL(debug_tanh_exp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)n,
+                       tanh_out, exp_out);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 

@@ -1,15 +1,23 @@
-// joint_loss.h - FBMSJointLoss fused on the device (awesome/measures/fbms_joint_loss.py:35-59).
+// joint_loss.h - the composite training losses of the joint segmentation + prior step, fused on the device (SURVEY.md §8(f).1,
+// row a12).  One set of three kernels serves the three reference classes (InrJointLossDesc.form):
 //
-//   output (B, 2, H, W) = [seg, prior] (both after their sigmoids, awesome/model/wrapper_module.py:230-273), target (B, 1, H, W)
-//   seg_loss = alpha * mean(w (.) crit(seg, target))        crit = BCELoss | SE, w = UnariesWeightedLoss._compute_weight
-//                                                           (awesome/measures/unaries_weighted_loss.py:35-69; counts over the batch)
-//   penalty  = beta * mean((seg - prior)^2)                 SE('mean')(output_convx, output_seg): BOTH arguments carry gradient
-//   if clip_penalty and penalty > seg_loss: penalty *= (seg_loss / penalty).detach()
-//   loss = seg_loss + penalty
+//   INR_JOINT_FBMS           awesome/measures/fbms_joint_loss.py:35-59        output (B, 2, H, W) = [seg, prior], target (B, 1, H, W)
+//       seg_loss = alpha * mean(w (.) crit(seg, target));  penalty = beta * mean((prior - seg)^2)   (BOTH arguments carry gradient)
+//       if clip_penalty and penalty > seg_loss: penalty *= (seg_loss / penalty).detach();   loss = seg_loss + penalty
+//   INR_JOINT_AWESOME_IMAGE  awesome/measures/awesome_image_loss.py:34-53     same layout
+//       loss = mean(w crit(seg, t)) + alpha * mean(w' pcrit(prior, t));
+//       extra_penalty:  loss = gamma * loss + beta * mean((prior - (seg > 0.5))^2)                   (the indicator has no gradient)
+//   INR_JOINT_AWESOME_PIXEL  awesome/measures/awesome_loss.py:45-65           output (B, n, 2): (seg, prior) per pixel, interleaved;
+//       the first n_scribble pixels carry targets (B, n_scribble, 1), the rest are random pixels for the align term
+//       loss = mean(w crit(seg_s, t)) + alpha * mean(w crit(prior_s, t));
+//       extra_penalty and n > n_scribble:  loss = gamma * loss + beta * mean((prior_r - (seg_r > 0.5))^2) over pixels [n - n_scribble, n)
+//       (the reference slices [random:] with random = n - n_scribble, awesome_loss.py:58-59; gamma = 0.1, beta = 100 are its constants)
+//   crit / pcrit = BCELoss | SE, w = UnariesWeightedLoss._compute_weight (awesome/measures/unaries_weighted_loss.py:35-69; fg/bg counts
+//   over the whole batch of targets).
 //
-// The reference decides the clip on the host (one device -> host sync per training step) and runs ~15 elementwise torch kernels
+// The reference decides FBMS's clip on the host (one device -> host sync per training step) and runs ~15 elementwise torch kernels
 // for value + autograd.  Here: three launches, no sync - partial sums per block, one block that combines them in fixed order and
-// turns them into the loss and the per-class coefficients, one pass that writes d loss / d output.  HBM-bound: reads 3 floats and
+// turns them into the loss and the gradient coefficients, one pass that writes d loss / d output.  HBM-bound: reads 3 floats and
 // writes 2 per pixel (12 + 8 B), 1.3 MB at 256x256.
 #pragma once
 #include "icnn_step.h"
@@ -17,15 +25,22 @@
 namespace {
 
 constexpr int JL_MAX_BLOCKS = 512;
+constexpr int JL_PART = 8;    // partial sums per block
+constexpr int JL_RES = 16;    // result / coefficient slots
 
 struct JointLossArgs {
-    const float* output;   // [B][2][HW]
-    const float* target;   // [B][HW]
-    float* doutput;        // [B][2][HW] or null
-    float* part;           // [blocks][4] partial sums: loss over fg pixels, over bg pixels, fg count, penalty
-    float* res;            // [8]: loss, seg_loss_raw, penalty_raw, clip scale | c_fg, c_bg, c_pen, (unused)
-    long long hw, n;       // n = B * HW
-    int blocks;
+    const float* output;   // image forms: [B][2][n]; pixel form: [B][n][2]
+    const float* target;   // [B][n_data]
+    float* doutput;        // like output, or null
+    float* part;           // [blocks][JL_PART]: seg loss over fg, over bg, fg count, penalty, prior loss over fg, over bg
+    float* res;            // [JL_RES], see joint_loss_finish_kernel
+    long long n;           // pixels per batch item
+    long long n_data;      // leading pixels of a batch item that carry the data terms (n for the image forms)
+    long long pen_lo;      // first pixel of a batch item inside the penalty / align term
+    long long total;       // B * n
+    long long es, cs, bs;  // strides of output: element, channel, batch item
+    int blocks, batch;
+    int pen_on;            // the penalty / align term is part of the loss
     InrJointLossDesc d;
 };
 
@@ -40,6 +55,13 @@ __device__ __forceinline__ float jl_dcrit(int kind, float x, float t) {
     if (kind == INR_LOSS_SE) return 2.f * (x - t);
     return (x - t) / fmaxf((1.f - x) * x, 1e-12f);                                       // binary_cross_entropy_backward
 }
+__device__ __forceinline__ float jl_class_weight(int mode, float ratio, float nfg, float nbg) {
+    if (mode == INR_WEIGHT_NONE || !(nfg > 0.f)) return 1.f;
+    const float cc = nbg / nfg;
+    if (mode == INR_WEIGHT_EQUAL) return cc;
+    if (mode == INR_WEIGHT_RATIO) return (cc - 1.f) * ratio + 1.f;
+    return rintf(cc / 10.f) + 1.f;   // sssdms (torch.round: half to even)
+}
 
 __device__ __forceinline__ float jl_block_sum(float v, float* sm) {   // 256 threads, fixed order
     v = sum_over_groups(sum_over_points(v));
@@ -49,72 +71,132 @@ __device__ __forceinline__ float jl_block_sum(float v, float* sm) {   // 256 thr
     return ((sm[0] + sm[1]) + sm[2]) + sm[3];
 }
 
+// PRIOR = false: the segmentation-side sums only (the fused joint step: the prior's share of the loss comes out of the ICNN step
+// kernel's own loss column, joint_step_finish_kernel)
+template <bool PRIOR>
 __global__ __launch_bounds__(256) void joint_loss_partial_kernel(const JointLossArgs a) {
     __shared__ float sm[4];
-    float lfg = 0.f, lbg = 0.f, nfg = 0.f, pen = 0.f;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < a.n; e += (long long)a.blocks * 256) {
-        const long long b = e / a.hw, i = e - b * a.hw;
-        const float s = a.output[(2 * b) * a.hw + i], p = a.output[(2 * b + 1) * a.hw + i], t = a.target[e];
-        const float l = jl_crit(a.d.kind, s, t);
-        if (t < 0.5f) {
-            lfg += l;
-            nfg += 1.f;
-        } else {
-            lbg += l;
+    float lfg = 0.f, lbg = 0.f, nfg = 0.f, pen = 0.f, pfg = 0.f, pbg = 0.f;
+    const bool fbms = a.d.form == INR_JOINT_FBMS;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < a.total; e += (long long)a.blocks * 256) {
+        const long long b = e / a.n, i = e - b * a.n;
+        const float s = a.output[b * a.bs + i * a.es];
+        const float p = PRIOR ? a.output[b * a.bs + i * a.es + a.cs] : 0.f;
+        if (i < a.n_data) {
+            const float t = a.target[b * a.n_data + i];
+            const float l = jl_crit(a.d.kind, s, t);
+            const float lp = (PRIOR && !fbms) ? jl_crit(a.d.prior_kind, p, t) : 0.f;
+            if (t < 0.5f) {
+                lfg += l;
+                pfg += lp;
+                nfg += 1.f;
+            } else {
+                lbg += l;
+                pbg += lp;
+            }
         }
-        const float d = s - p;
-        pen = fmaf(d, d, pen);
+        if (PRIOR && a.pen_on && i >= a.pen_lo) {
+            const float d = fbms ? s - p : p - (s > 0.5f ? 1.f : 0.f);
+            pen = fmaf(d, d, pen);
+        }
     }
     const float r0 = jl_block_sum(lfg, sm), r1 = jl_block_sum(lbg, sm), r2 = jl_block_sum(nfg, sm), r3 = jl_block_sum(pen, sm);
+    const float r4 = jl_block_sum(pfg, sm), r5 = jl_block_sum(pbg, sm);
     if (threadIdx.x == 0) {
-        float* o = a.part + 4 * blockIdx.x;
-        o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3;
+        float* o = a.part + JL_PART * blockIdx.x;
+        o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3; o[4] = r4; o[5] = r5;
     }
+}
+
+// res: [0] loss, [1] mean weighted crit(seg) (before alpha / gamma), [2] mean penalty (before beta), [3] FBMS clip factor,
+//      [4] [5] d loss / d crit(seg_i) for a foreground / background pixel, [6] coefficient of the penalty gradient,
+//      [7] fg count, [8] [9] d loss / d pcrit(prior_i) fg / bg, [10] mean weighted pcrit(prior) (before alpha)
+__device__ __forceinline__ void jl_finish(const JointLossArgs& a, const float (&tot)[6], float pen_sum) {
+    const float nd = (float)((long long)a.batch * a.n_data), npen = (float)((long long)a.batch * (a.n - a.pen_lo));
+    const float nfg = tot[2], nbg = nd - nfg;
+    const float w = jl_class_weight(a.d.weight_mode, a.d.ratio, nfg, nbg);
+    const float seg_raw = (w * tot[0] + tot[1]) / nd;
+    const float pen_raw = a.pen_on ? pen_sum / npen : 0.f;
+    float loss, scale = 1.f, cfg, cbg, cpen, pfg = 0.f, pbg = 0.f, pri_raw = 0.f;
+    if (a.d.form == INR_JOINT_FBMS) {
+        const float seg_loss = a.d.alpha * seg_raw;
+        float pen = a.d.beta * pen_raw;
+        if (a.d.clip_penalty && pen > seg_loss) {
+            scale = seg_loss / pen;
+            pen = pen * scale;
+        }
+        loss = seg_loss + pen;
+        cfg = a.d.alpha * w / nd;
+        cbg = a.d.alpha / nd;
+        cpen = scale * a.d.beta * 2.f / npen;      // d penalty / d (seg_i - prior_i) = cpen (seg_i - prior_i)
+    } else {
+        const float wp = jl_class_weight(a.d.prior_weight_mode, a.d.prior_ratio, nfg, nbg);
+        pri_raw = (wp * tot[4] + tot[5]) / nd;
+        const float g = a.pen_on ? a.d.gamma : 1.f;
+        loss = g * (seg_raw + a.d.alpha * pri_raw) + (a.pen_on ? a.d.beta * pen_raw : 0.f);
+        cfg = g * w / nd;
+        cbg = g / nd;
+        pfg = g * a.d.alpha * wp / nd;
+        pbg = g * a.d.alpha / nd;
+        cpen = a.pen_on ? a.d.beta * 2.f / npen : 0.f;   // d align / d prior_i = cpen (prior_i - [seg_i > 0.5])
+    }
+    a.res[0] = loss;
+    a.res[1] = seg_raw;
+    a.res[2] = pen_raw;
+    a.res[3] = scale;
+    a.res[4] = cfg;
+    a.res[5] = cbg;
+    a.res[6] = cpen;
+    a.res[7] = nfg;
+    a.res[8] = pfg;
+    a.res[9] = pbg;
+    a.res[10] = pri_raw;
 }
 
 __global__ __launch_bounds__(256) void joint_loss_finish_kernel(const JointLossArgs a) {
     __shared__ float sm[4];
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int b = threadIdx.x; b < a.blocks; b += 256)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] += a.part[4 * b + k];
-    float tot[4];
+        for (int k = 0; k < 6; ++k) v[k] += a.part[JL_PART * b + k];
+    float tot[6];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) tot[k] = jl_block_sum(v[k], sm);
+    for (int k = 0; k < 6; ++k) tot[k] = jl_block_sum(v[k], sm);
     if (threadIdx.x != 0) return;
-    const float n = (float)a.n, nfg = tot[2], nbg = n - nfg;
-    float w = 1.f;
-    if (a.d.weight_mode != INR_WEIGHT_NONE && nfg > 0.f) {
-        const float cc = nbg / nfg;
-        if (a.d.weight_mode == INR_WEIGHT_EQUAL) w = cc;
-        else if (a.d.weight_mode == INR_WEIGHT_RATIO) w = (cc - 1.f) * a.d.ratio + 1.f;
-        else w = rintf(cc / 10.f) + 1.f;   // sssdms (torch.round: half to even)
-    }
-    const float seg_raw = (w * tot[0] + tot[1]) / n, pen_raw = tot[3] / n;
-    const float seg_loss = a.d.alpha * seg_raw;
-    float pen = a.d.beta * pen_raw, scale = 1.f;
-    if (a.d.clip_penalty && pen > seg_loss) {
-        scale = seg_loss / pen;
-        pen = pen * scale;
-    }
-    a.res[0] = seg_loss + pen;
-    a.res[1] = seg_raw;
-    a.res[2] = pen_raw;
-    a.res[3] = scale;
-    a.res[4] = a.d.alpha * w / n;              // d seg_loss / d l_i for a foreground pixel
-    a.res[5] = a.d.alpha / n;                  // ... background pixel
-    a.res[6] = scale * a.d.beta * 2.f / n;     // d penalty / d (seg_i - prior_i) = c_pen * (seg_i - prior_i)
-    a.res[7] = nfg;
+    jl_finish(a, tot, tot[3]);
 }
 
-__global__ __launch_bounds__(256) void joint_loss_grad_kernel(const JointLossArgs a) {
-    const float cfg = a.res[4], cbg = a.res[5], cpen = a.res[6];
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < a.n; e += (long long)gridDim.x * 256) {
-        const long long b = e / a.hw, i = e - b * a.hw;
-        const float s = a.output[(2 * b) * a.hw + i], p = a.output[(2 * b + 1) * a.hw + i], t = a.target[e];
-        const float g = cpen * (s - p);
-        a.doutput[(2 * b) * a.hw + i] = fmaf(t < 0.5f ? cfg : cbg, jl_dcrit(a.d.kind, s, t), g);
-        a.doutput[(2 * b + 1) * a.hw + i] = -g;
+// SEG_ONLY: d loss / d seg into a compact [B][n] array (the fused joint step: the prior's gradient never leaves the prior kernels);
+// `prior` then comes from `logits` (the prior's pre-sigmoid output written by the step kernel)
+template <bool SEG_ONLY>
+__global__ __launch_bounds__(256) void joint_loss_grad_kernel(const JointLossArgs a, const float* __restrict__ logits, float* __restrict__ dseg) {
+    const float cfg = a.res[4], cbg = a.res[5], cpen = a.res[6], pfg = a.res[8], pbg = a.res[9];
+    const bool fbms = a.d.form == INR_JOINT_FBMS;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < a.total; e += (long long)gridDim.x * 256) {
+        const long long b = e / a.n, i = e - b * a.n;
+        const float s = a.output[b * a.bs + i * a.es];
+        const float p = SEG_ONLY ? 1.f / (1.f + expf(-logits[e])) : a.output[b * a.bs + i * a.es + a.cs];
+        float gs = 0.f, gp = 0.f;
+        if (i < a.n_data) {
+            const float t = a.target[b * a.n_data + i];
+            gs = (t < 0.5f ? cfg : cbg) * jl_dcrit(a.d.kind, s, t);
+            if (!fbms && !SEG_ONLY) gp = (t < 0.5f ? pfg : pbg) * jl_dcrit(a.d.prior_kind, p, t);
+        }
+        if (a.pen_on && i >= a.pen_lo) {
+            if (fbms) {
+                const float g = cpen * (s - p);
+                gs += g;
+                gp -= g;
+            } else {
+                gp = fmaf(cpen, p - (s > 0.5f ? 1.f : 0.f), gp);
+            }
+        }
+        if (SEG_ONLY) {
+            dseg[e] = gs;
+        } else {
+            a.doutput[b * a.bs + i * a.es] = gs;
+            a.doutput[b * a.bs + i * a.es + a.cs] = gp;
+        }
     }
 }
 

@@ -68,19 +68,76 @@ __host__ __device__ inline FlowIdx flow_idx(unsigned mask) {
     return x;
 }
 
-template <int C>
-__device__ __forceinline__ float sel(const float (&z)[C], int idx) {   // uniform idx: no dynamic register indexing
-    float v = z[0];
-    if (idx == 1) v = z[1];
-    if (C > 2 && idx == 2) v = z[C > 2 ? 2 : 0];
-    return v;
+// ---- tanh / exp of the coupling outputs ---------------------------------------------------------------------------------------
+// libm's tanhf / expf cost ~35 / ~12 VALU instructions each (denormal / overflow handling, an IEEE division); the coupling needs
+// 2 tanh + 1 exp per point, flow and output channel, a third of the forward's instructions.  The forms below keep
+// libm's accuracy class - RELATIVE error, so tiny outputs of the zero-initialised nets stay exact to rounding - at ~19 / 5:
+//   exp:  e^x = 2^hi (1 + lo ln 2) with x log2(e) = hi + lo split exactly by one fma (v_exp_f32: 1 ulp), |x| <~ 80;
+//         measured max rel. error 1.3e-7 on [-10, 10] (tests/test_gpu_rnvp.py::test_fast_tanh_exp_error_bounds asserts 2.5e-7)
+//   tanh: |x| < 0.625: odd minimax polynomial x + x^3 P(x^2) (the Cephes tanhf coefficients); else 1 - 2 / (e^{2|x|} + 1) with the exp
+//         above and v_rcp_f32 (1 ulp); measured max rel. error 2.4e-7 (asserted: 5e-7; libm: 1.2e-7).
+// A first attempt in round 1 (tanh x = 1 - 2/(1 + e^2x) for ALL x, plain v_exp_f32 of x log2e) had ABSOLUTE error 2e-7, i.e. large
+// relative error near 0 where the couplings start: "3x noisier" gradients.  The relative-error forms do not have that problem
+// (test_accuracy_against_float64 holds with the same x4 bar as libm).
+__device__ __forceinline__ float fast_exp(float x) {
+    constexpr float L2E = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-8f, LN2 = 0.693147182464599609375f;
+    const float hi = x * L2E;
+    const float lo = fmaf(x, L2E_LO, fmaf(x, L2E, -hi));   // x log2(e) - hi
+    const float e = __builtin_amdgcn_exp2f(hi);
+    return fmaf(e * LN2, lo, e);
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float ax = fabsf(x);
+    const float z = x * x;
+    float p = fmaf(-5.70498872745e-3f, z, 2.06390887954e-2f);
+    p = fmaf(p, z, -5.37397155531e-2f);
+    p = fmaf(p, z, 1.33314422036e-1f);
+    p = fmaf(p, z, -3.33332819422e-1f);
+    const float small = fmaf(p * z, x, x);
+    const float e = fast_exp(fminf(2.f * ax, 40.f));        // tanh saturates to 1 long before; keeps 2^hi finite
+    const float big = fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
+    return ax < 0.625f ? small : copysignf(big, x);
+}
+// coupling log-scale: tanh-bounded -> fast_exp; unbounded (output_fn none) -> libm
+template <bool BOUNDED>
+__device__ __forceinline__ float coupling_exp(float s) {
+    if constexpr (BOUNDED) return fast_exp(s);
+    else return expf(s);
 }
 
-// tanh / exp of the coupling outputs: libm.  (v_exp_f32 / v_rcp_f32 forms - tanh x = 1 - 2/(1 + e^2x), abs. error 2e-7 - made
-// the point kernels 3 % faster but the deformation ~10x noisier than fp32 libm, which then switches relus near 0 differently
-// from the reference arithmetic: single gradient entries off by 1e-3 of the tensor maximum.  Not worth it.)
-__device__ __forceinline__ float fast_exp(float x) { return expf(x); }
-__device__ __forceinline__ float fast_tanh(float x) { return tanhf(x); }
+// Channel roles of a flow as COMPILE-TIME constants of its mask (bit c set = channel c passes through and feeds the MLPs).  The
+// point kernels dispatch once per flow on the (wave-uniform) mask value - 2 masks at C = 2, 6 at C = 3 - into code in which the
+// state z[C], the inputs and the outputs are plain registers: no select chains, no run-time indexed per-lane arrays (which hipcc
+// had placed in scratch memory: private_segment 28 bytes, scratch_store_dwordx3 / SGPR-indexed scratch_load in round 2's C = 3
+// kernels; now private_segment_fixed_size == 0, checked by tests/test_abi.py on the code object).
+template <int C, unsigned MASK>
+struct MaskT {
+    static constexpr bool b0 = (MASK & 1u) != 0, b1 = ((MASK >> 1) & 1u) != 0, b2 = C > 2 && ((MASK >> 2) & 1u) != 0;
+    static constexpr int NIN = (int)b0 + (int)b1 + (int)b2, NOUT = C - NIN;
+    static_assert(NIN >= 1 && NOUT >= 1, "a flow needs at least one input and one output channel");
+    static constexpr int in0 = b0 ? 0 : (b1 ? 1 : 2), in1 = (b0 && b1) ? 1 : 2;
+    static constexpr int out0 = !b0 ? 0 : (!b1 ? 1 : 2), out1 = (!b0 && !b1) ? 1 : 2;
+    static constexpr int in(int q) { return q == 0 ? in0 : in1; }
+    static constexpr int out(int q) { return q == 0 ? out0 : out1; }
+};
+
+template <unsigned V> using MaskC = std::integral_constant<unsigned, V>;
+template <int C, class Fn>
+__device__ __forceinline__ void with_mask(unsigned mask, Fn&& fn) {   // mask is wave-uniform (a kernel argument indexed by the flow)
+    if constexpr (C == 2) {
+        if (mask == 1u) fn(MaskC<1>{});
+        else fn(MaskC<2>{});
+    } else {
+        switch (mask) {
+            case 1u: fn(MaskC<1>{}); break;
+            case 2u: fn(MaskC<2>{}); break;
+            case 3u: fn(MaskC<3>{}); break;
+            case 4u: fn(MaskC<4>{}); break;
+            case 5u: fn(MaskC<5>{}); break;
+            default: fn(MaskC<6>{}); break;
+        }
+    }
+}
 
 __device__ __forceinline__ float minmax_fwd(float v, float lo, float hi, float nlo, float nhi) {   // transforms/min_max.py:8-19
     return (v - lo) / (hi - lo) * (nhi - nlo) + nlo;
@@ -195,78 +252,49 @@ __device__ __forceinline__ void rnvp_nets(const float* rec, int HID, const float
     }
 }
 
-// dispatch on the flow's mask shape; results in fixed [2]-arrays (unused slots untouched)
-template <int C, bool DU, int Q>
-__device__ __forceinline__ void rnvp_nets_any(const float* rec, int HID, const FlowIdx& x, const float (&z)[Q][C], f32x2 (&o)[Q][2],
-                                              f32x2 (&J)[Q][2][2]) {
-    if (C == 2 || x.nin == 1) {
-        float zin[Q][1];
+// one flow on z (MaskedAffineFlow, then ActNorm unless !ACTNORM), channel roles fixed at compile time
+template <int C, unsigned MASK, bool ACTNORM, bool TANH, int Q>
+__device__ __forceinline__ void rnvp_flow_forward_m(const float* rec, const RnvpMap& m, float (&z)[Q][C]) {
+    using M = MaskT<C, MASK>;
+    constexpr int NIN = M::NIN, NOUT = M::NOUT;
+    float zin[Q][NIN];
+    f32x2 o[Q][NOUT], J[Q][NOUT][NIN];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) zin[q][0] = sel<C>(z[q], x.in(0));
-        if (C == 2) {
-            f32x2 o1[Q][1], J1[Q][1][1];
-            rnvp_nets<1, 1, DU, Q>(rec, HID, zin, o1, J1);
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                o[q][0] = o1[q][0];
-                J[q][0][0] = J1[q][0][0];
-            }
-        } else {
-            f32x2 o2[Q][2], J2[Q][2][1];
-            rnvp_nets<1, 2, DU, Q>(rec, HID, zin, o2, J2);
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                o[q][0] = o2[q][0];
-                o[q][1] = o2[q][1];
-                J[q][0][0] = J2[q][0][0];
-                J[q][1][0] = J2[q][1][0];
-            }
-        }
-    } else {
-        float zin[Q][2];
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            zin[q][0] = sel<C>(z[q], x.in(0));
-            zin[q][1] = sel<C>(z[q], x.in(1));
-        }
-        f32x2 o1[Q][1], J1[Q][1][2];
-        rnvp_nets<2, 1, DU, Q>(rec, HID, zin, o1, J1);
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            o[q][0] = o1[q][0];
-            J[q][0][0] = J1[q][0][0];
-            J[q][0][1] = J1[q][0][1];
-        }
+    for (int q = 0; q < Q; ++q) {
+        zin[q][0] = z[q][M::in0];
+        if constexpr (NIN > 1) zin[q][NIN - 1] = z[q][M::in1];
     }
-}
-
-// one flow on z (MaskedAffineFlow, then ActNorm unless !ACTNORM)
-template <int C, bool ACTNORM, int Q>
-__device__ __forceinline__ void rnvp_flow_forward(const float* rec, const RnvpMap& m, const FlowIdx& x, float (&z)[Q][C]) {
-    f32x2 o[Q][2], J[Q][2][2];
-    rnvp_nets_any<C, false, Q>(rec, m.HID, x, z, o, J);
+    rnvp_nets<NIN, NOUT, false, Q>(rec, m.HID, zin, o, J);
     const float* tl = rec + m.HID * RNVP_REC;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
 #pragma unroll
-        for (int k = 0; k < C - 1; ++k) {   // fixed bounds + guards: no dynamically indexed registers
-            if (k < x.nout) {
-                float s = o[q][k][0], t = o[q][k][1];
-                if (m.out_fn) {
-                    s = fast_tanh(s) * m.out_scale;
-                    t = fast_tanh(t) * m.out_scale;
-                }
-                const float es = fast_exp(s);
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-                    if (c == x.out(k)) z[q][c] = fmaf(z[q][c], es, t);
+        for (int k = 0; k < NOUT; ++k) {
+            constexpr int c0 = M::out0, c1 = M::out1;
+            float s = o[q][k][0], t = o[q][k][1];
+            if constexpr (TANH) {
+                s = fast_tanh(s) * m.out_scale;
+                t = fast_tanh(t) * m.out_scale;
             }
+            const float es = coupling_exp<TANH>(s);
+            if (k == 0) z[q][c0] = fmaf(z[q][c0], es, t);
+            else z[q][c1 < C ? c1 : 0] = fmaf(z[q][c1 < C ? c1 : 0], es, t);
         }
         if (ACTNORM) {
 #pragma unroll
             for (int c = 0; c < C; ++c) z[q][c] = fmaf(z[q][c], tl[4 + c], tl[7 + c]);
         }
     }
+}
+
+// run-time mask (wave-uniform) and output function -> the specialised body
+template <int C, bool ACTNORM, int Q>
+__device__ __forceinline__ void rnvp_flow_forward(const float* rec, const RnvpMap& m, unsigned mask, float (&z)[Q][C]) {
+    with_mask<C>(mask, [&](auto mk) {
+        constexpr unsigned MASK = decltype(mk)::value;
+        if (m.out_fn) rnvp_flow_forward_m<C, MASK, ACTNORM, true, Q>(rec, m, z);
+        else rnvp_flow_forward_m<C, MASK, ACTNORM, false, Q>(rec, m, z);
+    });
 }
 
 template <int C>
@@ -319,7 +347,7 @@ __global__ __launch_bounds__(256) void rnvp_fwd_kernel(const RnvpFwdArgs a) {
                     for (int c = 0; c < C; ++c) a.zs[(((size_t)img * a.m.F + f) * C + c) * N + p[q]] = z[q][c];
                 }
         }
-        rnvp_flow_forward<C, true, Q>(rsm + RNVP_HDR + f * a.m.fl, a.m, flow_idx<C>(a.m.masks[f]), z);
+        rnvp_flow_forward<C, true, Q>(rsm + RNVP_HDR + f * a.m.fl, a.m, a.m.masks[f], z);
     }
 #pragma unroll
     for (int q = 0; q < Q; ++q)
@@ -357,25 +385,29 @@ __global__ __launch_bounds__(256) void rnvp_inverse_kernel(const RnvpInvArgs a) 
     for (int f = a.m.F - 1; f >= 0; --f) {
         const float* rec = rsm + RNVP_HDR + f * a.m.fl;
         const float* tl = rec + a.m.HID * RNVP_REC;
-        const FlowIdx x = flow_idx<C>(a.m.masks[f]);
 #pragma unroll
         for (int c = 0; c < C; ++c) z[0][c] = (z[0][c] - tl[7 + c]) / tl[4 + c];   // ActNorm^-1
-        f32x2 o[1][2], J[1][2][2];
-        rnvp_nets_any<C, false, 1>(rec, a.m.HID, x, z, o, J);   // the masked channels are unchanged by the coupling
+        with_mask<C>(a.m.masks[f], [&](auto mk) {
+            using M = MaskT<C, decltype(mk)::value>;
+            constexpr int NIN = M::NIN, NOUT = M::NOUT;
+            float zin[1][NIN];
+            zin[0][0] = z[0][M::in0];
+            if constexpr (NIN > 1) zin[0][NIN - 1] = z[0][M::in1];
+            f32x2 o[1][NOUT], J[1][NOUT][NIN];
+            rnvp_nets<NIN, NOUT, false, 1>(rec, a.m.HID, zin, o, J);   // the masked channels are unchanged by the coupling
 #pragma unroll
-        for (int k = 0; k < C - 1; ++k) {
-            if (k < x.nout) {
+            for (int k = 0; k < NOUT; ++k) {
                 float s = o[0][k][0], t = o[0][k][1];
-                if (a.m.out_fn) {
+                if (a.m.out_fn) {   // (libm here: the inverse is not on the fit path)
                     s = tanhf(s) * a.m.out_scale;
                     t = tanhf(t) * a.m.out_scale;
                 }
                 const float e = expf(-s);
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-                    if (c == x.out(k)) z[0][c] = (z[0][c] - t) * e;
+                constexpr int c0 = M::out0, c1 = M::out1 < C ? M::out1 : 0;
+                if (k == 0) z[0][c0] = (z[0][c0] - t) * e;
+                else z[0][c1] = (z[0][c1] - t) * e;
             }
-        }
+        });
     }
     if (p < N) {
 #pragma unroll
@@ -398,6 +430,85 @@ struct RnvpBwdArgs {
     RnvpMap m;
     int S1;
 };
+
+// One flow of the backward walk for Q points per lane, channel roles fixed at compile time.  In: g = d loss / d (state behind this
+// flow's ActNorm); out: g = d loss / d (state in front of the flow), per-lane partial sums of the per-point-scalar gradients in
+// acc (db2s [C] | db2t [C] | das [C] | dat [C]), and per point the gradients at the MLP outputs in ps (do_s [NOUT] | do_t [NOUT]).
+template <int C, unsigned MASK, bool TANH, int Q>
+__device__ __forceinline__ void rnvp_flow_backward_m(const RnvpBwdArgs& a, const float* rec, const float* tl, int img, int f, int N,
+                                                     const int (&p)[Q], const int (&pc)[Q], const bool (&valid)[Q], float (&g)[Q][C],
+                                                     float (&acc)[4 * C]) {
+    using M = MaskT<C, MASK>;
+    constexpr int NIN = M::NIN, NOUT = M::NOUT;
+    const int F = a.m.F;
+    float z[Q][C], zin[Q][NIN];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) z[q][c] = a.zs[(((size_t)img * F + f) * C + c) * N + pc[q]];
+        zin[q][0] = z[q][M::in0];
+        if constexpr (NIN > 1) zin[q][NIN - 1] = z[q][M::in1 < C ? M::in1 : 0];
+    }
+    f32x2 o[Q][NOUT], J[Q][NOUT][NIN];
+    rnvp_nets<NIN, NOUT, true, Q>(rec, a.m.HID, zin, o, J);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        // post-coupling state and the outputs of the nets
+        float zc[C], es[NOUT], dfs[NOUT], dft[NOUT];
+#pragma unroll
+        for (int c = 0; c < C; ++c) zc[c] = z[q][c];
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) {
+            float s = o[q][k][0], t = o[q][k][1];
+            dfs[k] = dft[k] = 1.f;
+            if constexpr (TANH) {
+                const float ths = fast_tanh(s), tht = fast_tanh(t);
+                s = ths * a.m.out_scale;
+                t = tht * a.m.out_scale;
+                dfs[k] = fmaf(-ths, ths, 1.f) * a.m.out_scale;
+                dft[k] = fmaf(-tht, tht, 1.f) * a.m.out_scale;
+            }
+            es[k] = coupling_exp<TANH>(s);
+            zc[M::out(k)] = fmaf(z[q][M::out(k)], es[k], t);
+        }
+        // ActNorm: y = zc * exp(as) + at
+        float gz[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float ea = tl[4 + c];
+            acc[2 * C + c] += g[q][c] * zc[c] * ea;
+            acc[3 * C + c] += g[q][c];
+            gz[c] = g[q][c] * ea;
+        }
+        // coupling
+        float dos[NOUT], dot[NOUT], gin[NIN];
+#pragma unroll
+        for (int mm = 0; mm < NIN; ++mm) gin[mm] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) {
+            const float gk = gz[M::out(k)], zk = z[q][M::out(k)];
+            dos[k] = gk * zk * es[k] * dfs[k];
+            dot[k] = gk * dft[k];
+            gz[M::out(k)] = gk * es[k];
+            acc[M::out(k)] += dos[k];
+            acc[C + M::out(k)] += dot[k];
+#pragma unroll
+            for (int mm = 0; mm < NIN; ++mm) gin[mm] = fmaf(dos[k], J[q][k][mm][0], fmaf(dot[k], J[q][k][mm][1], gin[mm]));
+        }
+#pragma unroll
+        for (int mm = 0; mm < NIN; ++mm) gz[M::in(mm)] += gin[mm];
+        if (valid[q]) {   // (the MLP inputs are not stored again: the unit kernel reads them from zs)
+            float* pp = a.ps + (((size_t)img * F + f) * a.m.A) * N + p[q];
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) {
+                pp[(size_t)k * N] = dos[k];
+                pp[(size_t)(NOUT + k) * N] = dot[k];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) g[q][c] = gz[c];
+    }
+}
 
 template <int C, int Q>
 __global__ __launch_bounds__(256) void rnvp_bwd_points_kernel(const RnvpBwdArgs a) {
@@ -425,92 +536,13 @@ __global__ __launch_bounds__(256) void rnvp_bwd_points_kernel(const RnvpBwdArgs 
     for (int f = F - 1; f >= 0; --f) {
         const float* rec = rsm + RNVP_HDR + f * a.m.fl;
         const float* tl = rec + a.m.HID * RNVP_REC;
-        const FlowIdx x = flow_idx<C>(a.m.masks[f]);
-        float z[Q][C];
-#pragma unroll
-        for (int q = 0; q < Q; ++q)
-#pragma unroll
-            for (int c = 0; c < C; ++c) z[q][c] = a.zs[(((size_t)img * F + f) * C + c) * N + pc[q]];
-        f32x2 o[Q][2], J[Q][2][2];
-        rnvp_nets_any<C, true, Q>(rec, a.m.HID, x, z, o, J);
         float acc[4 * C];   // db2s[C] | db2t[C] | das[C] | dat[C]
 #pragma unroll
         for (int k = 0; k < 4 * C; ++k) acc[k] = 0.f;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            // post-coupling state and the outputs of the nets
-            float zc[C], es[2], dfs[2], dft[2];
-#pragma unroll
-            for (int c = 0; c < C; ++c) zc[c] = z[q][c];
-#pragma unroll
-            for (int k = 0; k < C - 1; ++k) {
-                es[k] = dfs[k] = dft[k] = 0.f;
-                if (k < x.nout) {
-                    float s = o[q][k][0], t = o[q][k][1];
-                    dfs[k] = dft[k] = 1.f;
-                    if (a.m.out_fn) {
-                        const float ths = fast_tanh(s), tht = fast_tanh(t);
-                        s = ths * a.m.out_scale;
-                        t = tht * a.m.out_scale;
-                        dfs[k] = (1.f - ths * ths) * a.m.out_scale;
-                        dft[k] = (1.f - tht * tht) * a.m.out_scale;
-                    }
-                    es[k] = fast_exp(s);
-#pragma unroll
-                    for (int c = 0; c < C; ++c)
-                        if (c == x.out(k)) zc[c] = fmaf(z[q][c], es[k], t);
-                }
-            }
-            // ActNorm: y = zc * exp(as) + at
-            float gz[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const float ea = tl[4 + c];
-                acc[2 * C + c] += g[q][c] * zc[c] * ea;
-                acc[3 * C + c] += g[q][c];
-                gz[c] = g[q][c] * ea;
-            }
-            // coupling
-            float dos[2] = {0.f, 0.f}, dot[2] = {0.f, 0.f}, gin[2] = {0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < C - 1; ++k) {
-                if (k < x.nout) {
-                    const float gk = sel<C>(gz, x.out(k)), zk = sel<C>(z[q], x.out(k));
-                    dos[k] = gk * zk * es[k] * dfs[k];
-                    dot[k] = gk * dft[k];
-#pragma unroll
-                    for (int c = 0; c < C; ++c)
-                        if (c == x.out(k)) {
-                            gz[c] = gk * es[k];
-                            acc[c] += dos[k];
-                            acc[C + c] += dot[k];
-                        }
-#pragma unroll
-                    for (int mm = 0; mm < C - 1; ++mm)
-                        if (mm < x.nin) gin[mm] = fmaf(dos[k], J[q][k][mm][0], fmaf(dot[k], J[q][k][mm][1], gin[mm]));
-                }
-            }
-#pragma unroll
-            for (int mm = 0; mm < C - 1; ++mm) {
-                if (mm < x.nin) {
-#pragma unroll
-                    for (int c = 0; c < C; ++c)
-                        if (c == x.in(mm)) gz[c] += gin[mm];
-                }
-            }
-            if (valid[q]) {
-                float* pp = a.ps + (((size_t)img * F + f) * a.m.A) * N + p[q];
-                int r = 0;   // (the MLP inputs are not stored again: the unit kernel reads them from zs)
-#pragma unroll
-                for (int k = 0; k < C - 1; ++k)
-                    if (k < x.nout) pp[(size_t)(r++) * N] = dos[k];
-#pragma unroll
-                for (int k = 0; k < C - 1; ++k)
-                    if (k < x.nout) pp[(size_t)(r++) * N] = dot[k];
-            }
-#pragma unroll
-            for (int c = 0; c < C; ++c) g[q][c] = gz[c];
-        }
+        with_mask<C>(a.m.masks[f], [&](auto mk) {
+            if (a.m.out_fn) rnvp_flow_backward_m<C, decltype(mk)::value, true, Q>(a, rec, tl, img, f, N, p, pc, valid, g, acc);
+            else rnvp_flow_backward_m<C, decltype(mk)::value, false, Q>(a, rec, tl, img, f, N, p, pc, valid, g, acc);
+        });
 #pragma unroll
         for (int k = 0; k < 4 * C; ++k) {
             const float v = sum_over_groups(sum_over_points(acc[k]));
@@ -760,9 +792,11 @@ struct RnvpUpdArgs {
     int hist_idx, hist_stride;
     float* RE;            // [n_images][LDSF] packed image to refresh after the step (mode 0), or null
     int unit_linear;      // header of RE with a = 1, b = 0 (learn_flow_identity)
+    const float* gscale;  // [n_images] factor on every reduced gradient (the joint step's detached clip factor), or null
 };
 
-__device__ __forceinline__ float opt_apply(const RnvpUpdArgs& u, float p, float g, float lr, float wd, float* m_, float* v_) {
+__device__ __forceinline__ float opt_apply(const RnvpUpdArgs& u, float gmul, float p, float g, float lr, float wd, float* m_, float* v_) {
+    g = g * gmul;   // the joint step's detached clip factor (x 1.0 is exact: the plain fits are bit-identical)
     if (wd != 0.f) g = __fadd_rn(g, __fmul_rn(wd, p));
     float m = *m_, v = *v_;
     m = __fadd_rn(m, __fmul_rn(u.one_minus_b1, __fsub_rn(g, m)));
@@ -786,9 +820,12 @@ __global__ __launch_bounds__(256) void rnvp_update_kernel(const RnvpUpdArgs u) {
     __shared__ float sm[4];
     __shared__ float tot[4 * 3 + 2 * 3];
     const int img = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
+    const float gmul = u.gscale != nullptr ? u.gscale[img] : 1.f;
     const RnvpMap& m = u.m;
     const int F = m.F, HID = m.HID;
-    const bool frozen = u.status != nullptr && u.status[img] != INR_STATUS_OK;
+    // one source of truth with the ICNN update: the flag it has just written for step t (hdr[6 + ((t + 1) & 1)]); `status` may be NULL
+    const bool frozen = (u.lr_hdr != nullptr && u.lr_hdr[(size_t)img * u.hdr_stride + 6 + ((u.t + 1) & 1)] != 0.f) ||
+                        (u.status != nullptr && u.status[img] != INR_STATUS_OK);
     float* __restrict__ rp = u.RP + (size_t)img * m.RP;
     float* __restrict__ om = u.opt ? u.opt + (size_t)img * 2 * m.RP : nullptr;
     float* __restrict__ ov = om ? om + m.RP : nullptr;
@@ -867,7 +904,7 @@ __global__ __launch_bounds__(256) void rnvp_update_kernel(const RnvpUpdArgs u) {
         if (u.mode == 1) {
             go[base + i] = g;
         } else if (!frozen && isfinite(g)) {
-            rp[base + i] = opt_apply(u, rp[base + i], g, lr, f < F ? u.wd_flow : 0.f, &om[base + i], &ov[base + i]);
+            rp[base + i] = opt_apply(u, gmul, rp[base + i], g, lr, f < F ? u.wd_flow : 0.f, &om[base + i], &ov[base + i]);
         }
     }
     if (u.mode == 0 && u.RE != nullptr) {
@@ -922,7 +959,7 @@ __global__ __launch_bounds__(1024) void rnvp_actnorm_init_kernel(const RnvpInitA
     for (int f = 0; f < a.m.F; ++f) {
         __syncthreads();
         rnvp_params_to_lds<C>(rp, rsm, a.m, f, f + 1);
-        const FlowIdx x = flow_idx<C>(a.m.masks[f]);
+        const unsigned mask = a.m.masks[f];
         double s[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) s[c] = 0.0;
@@ -930,7 +967,7 @@ __global__ __launch_bounds__(1024) void rnvp_actnorm_init_kernel(const RnvpInitA
             float z[1][C];
 #pragma unroll
             for (int c = 0; c < C; ++c) z[0][c] = zb[(size_t)c * N + p];
-            rnvp_flow_forward<C, false, 1>(rsm + RNVP_HDR, a.m, x, z);
+            rnvp_flow_forward<C, false, 1>(rsm + RNVP_HDR, a.m, mask, z);
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 zb[(size_t)c * N + p] = z[0][c];
@@ -1042,7 +1079,7 @@ __global__ __launch_bounds__(256) void rnvp_init_couple_kernel(const RnvpInitPar
     }
     if (f >= a.b.m.F) return;   // finishing launch
     rnvp_params_to_lds<C>(rp, rsm, a.b.m, f, f + 1);
-    const FlowIdx x = flow_idx<C>(a.b.m.masks[f]);
+    const unsigned mask = a.b.m.masks[f];
     double s[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) s[c] = 0.0;
@@ -1058,7 +1095,7 @@ __global__ __launch_bounds__(256) void rnvp_init_couple_kernel(const RnvpInitPar
 #pragma unroll
             for (int c = 0; c < C; ++c) z[0][c] = fmaf(zb[(size_t)c * N + p], sc[c], sh[c]);
         }
-        rnvp_flow_forward<C, false, 1>(rsm + RNVP_HDR, a.b.m, x, z);
+        rnvp_flow_forward<C, false, 1>(rsm + RNVP_HDR, a.b.m, mask, z);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             zb[(size_t)c * N + p] = z[0][c];

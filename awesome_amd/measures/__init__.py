@@ -1,1 +1,1 @@
-from .losses import SE, UnariesWeightedLoss, MIOU, AwesomeImageLoss, AwesomeLoss, FBMSJointLoss, criterion_to_desc  # noqa: F401
+from .losses import SE, UnariesWeightedLoss, UnariesConversionLoss, criterion_targets, MIOU, AwesomeImageLoss, AwesomeLoss, FBMSJointLoss, criterion_to_desc  # noqa: F401

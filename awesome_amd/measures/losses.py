@@ -63,6 +63,25 @@ class UnariesWeightedLoss:
         return self.name or type(self).__name__
 
 
+class UnariesConversionLoss:
+    """awesome/measures/unaries_conversion_loss.py:8-31: the criterion on BINARISED unaries, `target = (target >= 0.5).float()`
+    (the pretrain criterion of every ConvexDiffeomorphismNet config: UnariesConversionLoss(SE('mean')))."""
+
+    def __init__(self, criterion=None, name: Optional[str] = None, **kwargs):
+        self.criterion, self.name = criterion, name
+
+    def __call__(self, output: torch.Tensor, target: torch.Tensor, **kwargs) -> torch.Tensor:
+        return self.criterion(output, (target >= 0.5).float(), **kwargs)
+
+    def get_name(self) -> str:
+        return self.name or ("UC" + self.criterion.get_name())
+
+
+def criterion_targets(criterion, unaries: torch.Tensor) -> torch.Tensor:
+    """The targets the fused fit kernels must see for `criterion`: binarised under UnariesConversionLoss, unchanged otherwise."""
+    return (unaries >= 0.5).to(unaries.dtype) if isinstance(criterion, UnariesConversionLoss) else unaries
+
+
 class MIOU:
     """awesome/measures/miou.py:29-48 with average='binary'."""
 
@@ -87,7 +106,11 @@ class MIOU:
 
 
 class AwesomeImageLoss:
-    """awesome/measures/awesome_image_loss.py:34-53: crit(seg,t) + alpha*crit(prior,t) [+ penalty]."""
+    """awesome/measures/awesome_image_loss.py:34-53: crit(seg,t) + alpha*crit(prior,t) [+ penalty].
+
+    On CUDA tensors (B, 2, H, W) with criteria the kernels know (BCELoss / SE, optionally inside UnariesWeightedLoss) it runs as the
+    fused HIP loss `inrfit_joint_loss` (form INR_JOINT_AWESOME_IMAGE: value and both gradient channels in three launches); any other
+    criterion is composed from torch ops."""
 
     def __init__(self, criterion=None, prior_criterion=None, alpha=1.0, beta=100.0, gamma=0.1, name=None, **kwargs):
         self.criterion = criterion or torch.nn.BCELoss()
@@ -95,7 +118,28 @@ class AwesomeImageLoss:
         self.alpha, self.beta, self.gamma, self.name = alpha, beta, gamma, name
         self.extra_penalty = False  # toggled by the runner (awesome/run/awesome_runner.py:351-371)
 
+    def joint_desc(self):
+        """InrJointLossDesc of this loss, or None if a criterion has no kernel form."""
+        from .. import _lib as L
+        try:
+            kind, mode, ratio = criterion_to_desc(self.criterion)
+            pkind, pmode, pratio = criterion_to_desc(self.prior_criterion)
+        except TypeError:
+            return None
+        for c in (self.criterion, self.prior_criterion):
+            if getattr(c, "reduction", "mean") not in ("mean", "none") or (isinstance(c, UnariesWeightedLoss) and c.reduction != "mean"):
+                return None
+            if isinstance(c, torch.nn.BCELoss) and c.reduction != "mean":
+                return None
+        return L.InrJointLossDesc(L.LOSS_KINDS[kind], L.WEIGHT_MODES[mode], float(ratio), float(self.alpha), float(self.beta), 0,
+                                  L.JOINT_AWESOME_IMAGE, L.LOSS_KINDS[pkind], L.WEIGHT_MODES[pmode], float(pratio),
+                                  float(self.gamma), int(bool(self.extra_penalty)), 0)
+
     def __call__(self, output: torch.Tensor, target: torch.Tensor, **kwargs) -> torch.Tensor:
+        if output.is_cuda and output.dim() == 4 and output.shape[1] == 2:
+            desc = self.joint_desc()
+            if desc is not None:
+                return _FusedJointLoss.apply(output, target, desc)
         c = output.shape[1] // 2
         seg, prior = output[:, :c], output[:, c:]
         loss = self.criterion(seg, target) + self.alpha * self.prior_criterion(prior, target)
@@ -110,17 +154,35 @@ class AwesomeImageLoss:
 class AwesomeLoss:
     """awesome/measures/awesome_loss.py:45-65 (pixel mode): output (..., n_pixels, 2) = (segmentation, prior) per pixel, the
     first floor(n * scribble_percentage) pixels are scribbles with targets, the rest random pixels for the align term:
-    crit(seg, t) + alpha*crit(prior, t)  [ -> 0.1*loss + 100*mean((prior_rand - (seg_rand > .5))^2) with extra_penalty ]."""
+    crit(seg, t) + alpha*crit(prior, t)  [ -> 0.1*loss + 100*mean((prior_rand - (seg_rand > .5))^2) with extra_penalty ].
+    On CUDA tensors with a criterion the kernels know: the fused HIP loss (form INR_JOINT_AWESOME_PIXEL)."""
 
     def __init__(self, criterion=None, alpha: float = 1.0, name=None, scribble_percentage: float = 1.0, **kwargs):
         self.criterion = criterion or torch.nn.BCELoss()
         self.alpha, self.name, self.scribble_percentage = alpha, name, scribble_percentage
         self.extra_penalty = False
 
+    def joint_desc(self, total: int = 0):
+        from .. import _lib as L
+        try:
+            kind, mode, ratio = criterion_to_desc(self.criterion)
+        except TypeError:
+            return None
+        if isinstance(self.criterion, (torch.nn.BCELoss, UnariesWeightedLoss)) and self.criterion.reduction != "mean":
+            return None
+        n_scr = int(total * self.scribble_percentage // 1)
+        return L.InrJointLossDesc(L.LOSS_KINDS[kind], L.WEIGHT_MODES[mode], float(ratio), float(self.alpha), 100.0, 0,
+                                  L.JOINT_AWESOME_PIXEL, L.LOSS_KINDS[kind], L.WEIGHT_MODES[mode], float(ratio), 0.1,
+                                  int(bool(self.extra_penalty)), n_scr)
+
     def __call__(self, output: torch.Tensor, target: torch.Tensor, **kwargs) -> torch.Tensor:
         total = output.shape[-2]
         n_scr = int(total * self.scribble_percentage // 1)
         n_rand = total - n_scr
+        if output.is_cuda and output.shape[-1] == 2 and n_scr > 0:
+            desc = self.joint_desc(total)
+            if desc is not None:
+                return _FusedJointLoss.apply(output, target, desc)
         seg, prior = output[..., :n_scr, 0:1], output[..., :n_scr, 1:2]
         loss = self.criterion(seg, target) + self.alpha * self.criterion(prior, target)
         if self.extra_penalty and n_rand > 0:
@@ -134,15 +196,20 @@ class AwesomeLoss:
 
 
 class _FusedJointLoss(torch.autograd.Function):
-    """FBMSJointLoss value + gradient in three HIP launches (inrfit_joint_loss), no host sync."""
+    """A composite joint loss (InrJointLossDesc.form) value + gradient in three HIP launches (inrfit_joint_loss), no host sync.
+    Image forms: output (B, 2, H, W); pixel form: output (..., n, 2)."""
 
     @staticmethod
     def forward(ctx, output: torch.Tensor, target: torch.Tensor, desc):
         import ctypes as C
         from .. import _lib as L
         out = output.detach().contiguous().to(torch.float32)
-        b, c2 = out.shape[0], out.shape[1]
-        hw = out.numel() // (b * c2)
+        if desc.form == L.JOINT_AWESOME_PIXEL:
+            hw = out.shape[-2]
+            b = out.numel() // (2 * hw)
+        else:
+            b, c2 = out.shape[0], out.shape[1]
+            hw = out.numel() // (b * c2)
         tgt = target.detach().contiguous().to(torch.float32)
         lib = L.load()
         nbytes = int(lib.inrfit_joint_loss_workspace_bytes(b * hw))
@@ -178,6 +245,11 @@ class FBMSJointLoss:
         from .. import _lib as L
         if not output.is_cuda or output.dim() != 4 or output.shape[1] != 2:
             return None
+        return self.joint_desc()
+
+    def joint_desc(self):
+        """InrJointLossDesc of this loss for the fused joint step (awesome_amd.agent.JointTrainer), or None."""
+        from .. import _lib as L
         if not (isinstance(self.penalty_criterion, SE) and self.penalty_criterion.reduction == "mean"):
             return None
         if isinstance(self.criterion, UnariesWeightedLoss) and self.criterion.reduction != "mean":
@@ -210,6 +282,8 @@ class FBMSJointLoss:
 def criterion_to_desc(criterion) -> Tuple[str, str, float]:
     """(loss kind, weight mode, ratio) for the fused kernel, or raise if the criterion has no fused form."""
     mode, ratio, inner = "none", 1.0, criterion
+    if isinstance(criterion, UnariesConversionLoss):   # only changes the targets: see criterion_targets
+        criterion = inner = criterion.criterion
     if isinstance(criterion, UnariesWeightedLoss):
         mode, ratio, inner = criterion.mode, criterion.ratio, criterion.criterion
     if isinstance(inner, SE):

@@ -15,6 +15,7 @@ backward, get_deformation, the ActNorm data-dependent init and the fused fit - r
 from __future__ import annotations
 
 import math
+import re
 import copy
 from typing import Any, Dict, Optional, Tuple
 
@@ -200,14 +201,25 @@ class PathConnectedNet(nn.Module, PriorFitMixin):
             if k.endswith("data_dep_init_done"):
                 sd[k] = torch.ones_like(sd[k])      # ActNorm's data-dependent init has happened on this image
 
+    def _engine_retry_state(self, fresh, failed):
+        # TensorUtil.reset_parameters (awesome/util/torch.py:160-194) re-draws modules that have reset_parameters(): the Linear
+        # layers and the ICNN.  nf.flows.ActNorm has none: its s, t and data_dep_init_done survive the reset (:975-978).
+        out = dict(fresh)
+        for k, v in failed.items():
+            if k.endswith("data_dep_init_done") or (k.startswith("flow_net.") and re.search(r"flows\.\d+\.(s|t)$", k)):
+                out[k] = v.detach().clone().to(fresh[k].device if k in fresh else v.device)
+        return out
+
     def _engine_fit(self, grid, unaries, flat, epochs, cold, opts, states=None):
         from ..measures import criterion_to_desc
         ispec, rspec = self._specs()
         P = ispec.n_params
         ip, fp = flat[:, :P].contiguous(), flat[:, P:].contiguous()
         n = ip.shape[0]
-        # ActNorm initialises itself on the first batch it sees (nf.flows.ActNorm): per image, unless its state says it has
-        need = list(range(n))
+        # ActNorm initialises itself on the first batch it sees (nf.flows.ActNorm): per image, unless its state says it has.
+        # A warm start (`states is None`: the previous frame's fitted state, :867-870 load_state_dict incl. data_dep_init_done = 1)
+        # never re-initialises: the 200-epoch refit continues from the previous deformation.
+        need = []
         if states is not None:
             need = [j for j in range(n) if not all(float(v) > 0 for k, v in states[j].items() if k.endswith("data_dep_init_done"))]
         if need:
@@ -215,7 +227,8 @@ class PathConnectedNet(nn.Module, PriorFitMixin):
             g = grid if grid.coords is None or grid.coords.dim() == 2 else K.Grid.explicit(grid.coords[need].contiguous())
             R.actnorm_init(rspec, sub, g)
             fp[need] = sub
-        if cold and opts.get("prefit_flow_net_identity", False):
+        prefit = cold and opts.get("_prefit", True)   # once per cold image, not again on a retry (:871-894 sit before the retry loop)
+        if prefit and opts.get("prefit_flow_net_identity", False):
             zoo = opts.get("zoo")
             kw = dict(lr=float(opts.get("prefit_flow_net_identity_lr", 1e-2)),
                       weight_decay=float(opts.get("prefit_flow_net_identity_weight_decay", 1e-5)))
@@ -237,7 +250,7 @@ class PathConnectedNet(nn.Module, PriorFitMixin):
                 lin = 2 * rspec.channels
                 fp[:, lin:] = shared[lin:]
                 self.load_state_dict(keep)
-        if cold and opts.get("prefit_convex_net", False):
+        if prefit and opts.get("prefit_convex_net", False):
             xd = R.rnvp_forward(rspec, fp, grid)
             K.fit(ispec, ip, K.Grid.explicit(xd), unaries, int(opts.get("prefit_convex_net_num_epochs", 200)),
                   lr=float(opts.get("prefit_convex_net_lr", 1e-3)), loss="se", optimizer="adam",

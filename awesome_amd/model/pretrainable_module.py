@@ -108,6 +108,10 @@ class PriorFitMixin(PretrainableModule):
                                                           (`states`: the images' starting state_dicts on a cold start - buffers)
         _engine_after_fit(state_dict)                     buffers a fit changes (e.g. ActNorm's data_dep_init_done)
         _engine_warm_start(flat, ctx, image, opts) -> (flat, ctx)     adjust the previous frame's fit before the short refit
+        _engine_retry_state(fresh, failed) -> state_dict               what reset_parameters leaves untouched, for a retry
+
+    `states is None` in _engine_fit = a warm start (the previous frame's fitted state, loaded with load_state_dict in the
+    reference: every buffer, e.g. ActNorm's data_dep_init_done = 1, comes along); `opts["_prefit"]`: run the pre-fit stages.
     """
 
     # -- hooks with defaults ----------------------------------------------------------------------------------------------
@@ -119,6 +123,11 @@ class PriorFitMixin(PretrainableModule):
 
     def _engine_warm_start(self, flat: torch.Tensor, ctx: Any, image: "_Image", opts: Dict[str, Any]):
         return flat, ctx
+
+    def _engine_retry_state(self, fresh: Dict[str, torch.Tensor], failed: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """The state a retry starts from: `fresh` (reset_parameters) with whatever reset_parameters does NOT touch in the reference
+        taken over from the failed fit (modules without a reset_parameters method keep their fitted values and buffers)."""
+        return fresh
 
     def _engine_fresh_state(self, key: int = 0, attempt: int = 0) -> Dict[str, torch.Tensor]:
         """reset_parameters() (the retry of path_connected_net.py:975-985) as a new state_dict; this module's own parameters are
@@ -143,11 +152,15 @@ class PriorFitMixin(PretrainableModule):
         if wrapper_module is None:
             raise ValueError("Wrapper model must be provided for pretraining.")
         ds = getattr(agent, "training_dataset", None)
-        if ds is None or not hasattr(ds, "__prior_cache__"):
-            raise ValueError("Agent must be trained on a prior dataset.")
-        if not getattr(ds, "has_prior", False):
+        # path_connected_net.py:485-509: `isinstance(ds, PriorDataset) and ds.has_prior` -> per-image fits, anything else -> the
+        # spatio-temporal fit (a module without one raises the reference's "Agent must be trained on a prior dataset.")
+        if ds is None or not hasattr(ds, "__prior_cache__") or not getattr(ds, "has_prior", False):
             return self._non_prior_based_pretrain(train_set=train_set, test_set=test_set, device=device, agent=agent,
                                                   use_progress_bar=use_progress_bar, wrapper_module=wrapper_module, **kwargs)
+        if not kwargs.get("use_prior_sigmoid", True):
+            # the fused fits evaluate criterion(sigmoid(logits), unaries) (wrapper_module.py:265-273 with use_sigmoid=True, every
+            # reference config); raw-logit criteria have no device form - refuse instead of silently applying the sigmoid
+            raise NotImplementedError("use_prior_sigmoid=False has no fused form (no reference config sets it)")
         if (do_pretrain_checkpoints or use_pretrain_checkpoints) and pretrain_checkpoint_dir is None:
             raise ValueError("Pretrain checkpoint dir must be provided.")
         if do_pretrain_checkpoints:
@@ -236,8 +249,12 @@ class PriorFitMixin(PretrainableModule):
         """proper_prior_fit_metric = MIOU(average='binary', invert=True) on (prior > 0.5) vs (unaries > 0.5) (:964-972)."""
         return K.miou((torch.sigmoid(logits) > 0.5).float(), (unaries > 0.5).float(), 0.5, 0.5, invert=True)
 
-    def _fit_group(self, group: List["_Image"], flats: torch.Tensor, epochs: int, cold: bool, device, opts, states=None):
-        """One device call for images that share a grid shape.  Returns (flat [n, Ptot], iou [n], status [n])."""
+    def _fit_group(self, group: List["_Image"], flats: torch.Tensor, epochs: int, cold: bool, device, opts, states=None,
+                   prefit: bool = False):
+        """One device call for images that share a grid shape.  Returns (flat [n, Ptot], iou [n], status [n]).  `prefit`: the
+        pre-fit stages (learn_flow_identity / learn_convex_net) run - in the reference once per cold image BEFORE the retry loop
+        (path_connected_net.py:871-894), never again after reset_parameters()."""
+        opts = dict(opts, _prefit=bool(prefit))
         g0 = group[0].grid
         same = all(im.grid.shape == g0.shape and (im.grid is g0 or torch.equal(im.grid, g0)) for im in group[1:])
         c, h, w = g0.shape[1], g0.shape[2], g0.shape[3]
@@ -246,7 +263,9 @@ class PriorFitMixin(PretrainableModule):
         else:
             grid = K.Grid.explicit(torch.stack([im.grid[0].reshape(c, h * w) for im in group]))
         un = torch.stack([im.unaries.reshape(-1) for im in group]).contiguous()
-        flat, logits, status = self._engine_fit(grid, un, flats.to(device).contiguous(), int(epochs), cold, opts, states)
+        from ..measures import criterion_targets   # UnariesConversionLoss (every ConvexDiffeomorphismNet config) binarises the targets
+        un_fit = criterion_targets(opts.get("criterion"), un).contiguous()
+        flat, logits, status = self._engine_fit(grid, un_fit, flats.to(device).contiguous(), int(epochs), cold, opts, states)
         return flat, self._gate(logits, un), status
 
     def _fit_independent(self, images: List["_Image"], device, opts) -> None:
@@ -262,7 +281,8 @@ class PriorFitMixin(PretrainableModule):
                 pending, states = group, [im.state for im in group]
                 for attempt in range(retrys + 1):
                     flats = torch.stack([self._engine_pack(sd) for sd in states])
-                    flat, iou, status = self._fit_group(pending, flats, int(opts.get("num_epochs", 2000)), True, device, opts, states)
+                    flat, iou, status = self._fit_group(pending, flats, int(opts.get("num_epochs", 2000)), True, device, opts, states,
+                                                        prefit=attempt == 0)
                     ok = (iou >= thr).cpu().tolist()
                     failed, failed_states = [], []
                     for j, im in enumerate(pending):
@@ -274,7 +294,7 @@ class PriorFitMixin(PretrainableModule):
                             logging.info(f"Prior fit not proper on image index: {im.pos}. Retrying. Metric: {im.iou} Threshold: {thr}")
                             im.retries += 1
                             failed.append(im)
-                            failed_states.append(self._engine_fresh_state(im.key, attempt))
+                            failed_states.append(self._engine_retry_state(self._engine_fresh_state(im.key, attempt), im.fitted))
                         else:
                             logging.info(f"Prior fit not proper on image index: {im.pos}. Retries exceeded. Metric: {im.iou} Threshold: {thr}")
                     pending, states = failed, failed_states
@@ -302,14 +322,15 @@ class PriorFitMixin(PretrainableModule):
                 epochs, cold = int(opts.get("num_epochs", 2000)), True
             proper = False
             for attempt in range(retrys + 1):
-                flat, iou, status = self._fit_group([im], start[None], epochs, cold, device, opts, [base_state] if cold else None)
+                flat, iou, status = self._fit_group([im], start[None], epochs, cold, device, opts, [base_state] if cold else None,
+                                                    prefit=cold and attempt == 0)
                 im.fitted, im.iou, im.status = self._merge(base_state, flat[0]), float(iou[0]), int(status[0])
                 if im.iou >= thr:
                     proper = True
                     break
                 if attempt < retrys and im.status == 0:
                     im.retries += 1
-                    base_state = self._engine_fresh_state(im.key, attempt)
+                    base_state = self._engine_retry_state(self._engine_fresh_state(im.key, attempt), im.fitted)
                     start, epochs, cold = self._engine_pack(base_state), int(opts.get("num_epochs", 2000)), True
                 else:
                     break

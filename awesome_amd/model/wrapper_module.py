@@ -82,6 +82,12 @@ class WrapperModule(nn.Module, PretrainableModule):
             prior = torch.sigmoid(prior)
         return prior
 
+    def segmentation_output(self, xi: torch.Tensor, ai: Tuple[Any, ...], kwargs: Optional[Dict[str, Any]] = None) -> torch.Tensor:
+        """The segmentation half of `forward` for ONE batch item (xi (1, C, H, W)): (1, H, W) probabilities, autograd attached.
+        The fused joint step (awesome_amd.agent.JointTrainer) takes it from here; everything behind it runs in one C-ABI call."""
+        seg_in, seg_args, seg_kwargs = self.get_segmentation_module_args(xi, ai, kwargs or {})
+        return self.process_segmentation_output(self.segmentation_module(seg_in, *seg_args, **seg_kwargs))
+
     def forward(self, _input: torch.Tensor, *args, **kwargs) -> torch.Tensor:
         if _input.dim() == 3:
             _input = _input[None]
@@ -90,8 +96,7 @@ class WrapperModule(nn.Module, PretrainableModule):
         for i in range(_input.shape[0]):
             one = lambda t: t[i][None] if isinstance(t, torch.Tensor) else t  # noqa: E731
             xi, ai = one(_input), tuple(one(a) for a in args)
-            seg_in, seg_args, seg_kwargs = self.get_segmentation_module_args(xi, ai, kwargs)
-            seg = self.process_segmentation_output(self.segmentation_module(seg_in, *seg_args, **seg_kwargs))
+            seg = self.segmentation_output(xi, ai, kwargs)
             if self.prior_module is not None and self.evaluate_prior:
                 pa, pk = self.get_prior_args(xi, *ai, segm=seg)
                 prior = self.process_prior_output(self.prior_module(*pa, **pk))

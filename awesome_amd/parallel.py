@@ -62,6 +62,22 @@ def barrier() -> None:
         dist.barrier()
 
 
+def any_rank_failed(failed: bool, device=None) -> bool:
+    """True on EVERY rank if any rank reports a failure (one MAX all-reduce).  Called by a rank BEFORE it joins the data
+    collectives, so that a rank whose work raised does not leave the others waiting in max_over_ranks / gather_per_image / barrier
+    until the launcher times out: everybody learns of the failure and exits non-zero together."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return bool(failed)
+    t = torch.tensor([1 if failed else 0], dtype=torch.int32, device=_coll_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
+
+
+def shutdown() -> None:
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def max_over_ranks(value: float, device=None) -> float:
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)

@@ -50,7 +50,10 @@ def get_result(model: torch.nn.Module, dataloader: Any, index: int, model_gets_t
     with torch.no_grad():
         model.train(False)
         _input_d = _apply_deep(inputs, lambda x: x[None, ...].to(device=device))
-        with PriorManager(model, prior_state, getattr(dataloader, "__prior_cache__", None), training=False):
+        # store_device = cpu: an evaluation-only swap must not turn the cache's entries into device tensors (a manager built
+        # without store_device clears the cache's one, as in the reference; a cache saved afterwards would carry CUDA tensors)
+        with PriorManager(model, prior_state, getattr(dataloader, "__prior_cache__", None), store_device=torch.device("cpu"),
+                          training=False):
             kw = {}
             if model_gets_targets:
                 kw["targets"] = _apply_deep(labels, lambda x: x[None, ...].to(device=device))
@@ -168,7 +171,8 @@ def evaluate_dataset(model: torch.nn.Module, dataloader: Any, indices: Optional[
         for i in indices:
             inputs, labels, _, prior_state = decompose_training_item(dataloader[i], dataloader)
             _input_d = _apply_deep(inputs, lambda x: x[None, ...].to(device=device))
-            with PriorManager(model, prior_state, getattr(dataloader, "__prior_cache__", None), training=False):
+            with PriorManager(model, prior_state, getattr(dataloader, "__prior_cache__", None), store_device=torch.device("cpu"),
+                              training=False):
                 res = model(*_input_d) if isinstance(_input_d, (tuple, list)) else model(_input_d)
             _, prior = model.split_model_output(res)[0]
             prior = prior if prior is not None else model.split_model_output(res)[0][0]

@@ -43,7 +43,9 @@ def parse_args():
     ap.add_argument("--images-per-gpu", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra 'variants' timings (other priors of the same path)")
-    ap.add_argument("--cpu-sample-steps", type=int, default=60)
+    ap.add_argument("--cpu-sample-steps", type=int, default=200, help="timed optimizer steps of the CPU baseline with all host threads")
+    ap.add_argument("--cpu-sample-steps-8", type=int, default=100, help="... of its 8-thread setting (SURVEY 6's yardstick); 0 = skip")
+    ap.add_argument("--no-variant-cpu", action="store_true", help="skip the CPU leg + parity field of every variant")
     ap.add_argument("--kernel-iters", type=int, default=200, help="step-kernel launches for the roofline timing")
     ap.add_argument("--throughput-images", type=int, default=64,
                     help="also time ONE full fit of this many images per GPU (BASELINE configs[2] = 512/8) and report it "
@@ -261,31 +263,69 @@ def main():
     update_us = seq.update_avg_us - 0.5 * excess
     flop_per_launch = STEP_FLOP_PER_POINT * N * B
     achieved = flop_per_launch / (kernel_ms * 1e-3) / 1e12
-    # HBM bytes per launch of this kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes of
-    # this same command; profiles/r02_e_pmc_step_kernel.json) - only quoted for the configuration it was measured on
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "r02_e_pmc_step_kernel.json")
-    if B == 1 and S == 256 and os.path.exists(tf):
-        with open(tf) as f:
-            traffic = json.load(f).get("traffic_bytes_per_launch")
+    # HBM bytes per launch of this kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of
+    # this same command: tools/profile_r03.sh).  A --pmc pass cannot run inside this process, so the figure is read from the
+    # committed summary of the newest round that has one and only quoted for the configuration it was measured on;
+    # `traffic_source` names the file.  `algorithmic_bytes`: SURVEY 8(d)'s 4-12 B per point (targets [+ grid + logits]) PLUS what
+    # this design adds on purpose - one gradient slab per workgroup (wgs x PS x 4 B written here, read by the update kernel) and
+    # the parameter image every workgroup copies into LDS - so `traffic_over_algorithmic` separates "wasted re-reads" (none: ~1.0)
+    # from the slab round trip the design pays for (`traffic_over_survey_bytes`).
+    traffic, traffic_source = None, None
+    for tag in ("r03_c", "r03_b", "r03_a", "r02_e"):
+        tf = os.path.join(ROOT, "profiles", f"{tag}_pmc_step_kernel.json")
+        if B == 1 and S == 256 and os.path.exists(tf):
+            with open(tf) as f:
+                traffic = json.load(f).get("traffic_bytes_per_launch")
+            traffic_source = os.path.relpath(tf, ROOT)
+            break
+    lib0 = A._lib.load()
+    wgs = int(lib0.inrfit_slabs_per_image(N, B))
+    slab_cols = (19222 + 31) // 32 * 32 if spec.n_hidden == 130 and spec.in_features == 2 else None   # Cfg<130,2>::SL_COLS (icnn_step.h), rows on 128-byte lines
+    survey_bytes = 12 * N * B                                   # <= 8 B grid + 4 B target per point
+    design_bytes = None
+    if slab_cols is not None:
+        design_bytes = 4 * N * B + B * wgs * slab_cols * 4 + 8 * 77 * 1024   # targets + slabs + the parameter image once per XCD
     # what a launch of nothing but independent fp32 MFMAs on all 1024 SIMDs reaches on THIS box (~2.1 GHz under that load instead
     # of the 2.4 GHz the nominal peak assumes): the practical ceiling, reported next to `peak`, never instead of it
     mfma_stream = A.icnn.mfma_stream_tflops(dev)
     roofline = {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": traffic,
+                "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "algorithmic_bytes": design_bytes, "survey_bytes_per_launch": survey_bytes,
+                "traffic_over_algorithmic": round(traffic / design_bytes, 3) if traffic and design_bytes else None,
+                "traffic_over_survey_bytes": round(traffic / survey_bytes, 1) if traffic else None,
                 "kernel": "icnn_step_kernel<130,2,train>", "kernel_us": round(kernel_ms * 1e3, 2),
                 "kernel_samples": seq.samples, "kernel_us_back_to_back": round(kernel_b2b_ms * 1e3, 2),
                 "update_kernel_us": round(update_us, 2), "event_bracket_excess_us": round(excess, 2),
                 "flop_per_launch": flop_per_launch, "mfma_only_stream_tflops": round(mfma_stream, 1),
                 "frac_of_mfma_only_stream": round(achieved / mfma_stream, 4)}
 
+    # ---- which devices the ranks sat on: (rank, local rank, PCI bus id / uuid, the backend's world size), gathered so that the
+    # driver's record can show that the N-rank line came from N distinct GPUs over RCCL -------------------------------------
+    props = torch.cuda.get_device_properties(dev)
+    dev_id = str(getattr(props, "uuid", "")) or ""
+    pci = f"{getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', 0):02x}:{getattr(props, 'pci_device_id', 0):02x}"
+    me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "pci_bus_id": pci, "uuid": dev_id,
+          "name": props.name, "backend": (dist.get_backend() if dist is not None else None),
+          "world_size": (dist.get_world_size() if dist is not None else 1)}
+    if dist is not None:
+        placements = [None] * world
+        dist.all_gather_object(placements, me)
+    else:
+        placements = [me]
+
     # ---- throughput mode (extra, not `value`): configs[2]'s per-GPU share, one complete E-step fit of a batch ---------
+    # image i of rank r = configs[2]'s image r*TB + i: blob seed s, initial weights torch.manual_seed(s) + the reference's default
+    # init - so that the first images coincide with the reference classes' own fits in tests/golden/fits_blob256_multi_{a,b}.npz
     thr = None
     if args.throughput_images > 0:
         TB = args.throughput_images
-        tseeds = [1000 + rank * TB + i for i in range(TB)]
+        tseeds = [rank * TB + i for i in range(TB)]
         tun = torch.stack([convex_blob_unaries(S, s).reshape(-1) for s in tseeds]).to(dev)
-        tinit = init[:1].repeat(TB, 1).contiguous()   # same seeded init for every image (weights are per image on device)
+        tinit = []
+        for s in tseeds:
+            torch.manual_seed(s)
+            tinit.append(ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=1).flat_parameters())
+        tinit = torch.stack(tinit).to(dev)
         A.fit(spec, tinit.clone(), grid, tun, 20, lr=2e-3, record_loss=False, want_logits=False)  # warm
         barrier()
         t1 = time.perf_counter()
@@ -299,6 +339,8 @@ def main():
                "nonfinite_fits": int((tres.status != 0).sum().item()), "min_iou_vs_unaries": round(float(tiou.min()), 5),
                "us_per_optimizer_step_per_image": round(tdt / E / TB * 1e6, 2), "miou_vs_unaries": round(float(tiou.mean()), 5),
                "note": "one complete E-step fit of the batch; all images step together (BASELINE configs[2] per-GPU share)"}
+        if rank == 0 and S == 256 and E == 2000:
+            thr.update(miou_delta_vs_reference(tseeds, tiou.cpu(), (torch.sigmoid(tres.logits) > 0.5).cpu()))
 
     # parity of the timed workload with the real reference classes: rank 0's image 0 is exactly the problem of the golden
     # fixture tests/golden/fit_blob256_reference.npz (tools/gen_golden.py gen_fit_blob256: same seeds, E = 2000, 256x256)
@@ -335,11 +377,12 @@ def main():
             "miou_vs_unaries": round(miou, 5), "nonfinite_fits": status_bad, **reference_parity, **determinism,
             "us_per_optimizer_step": round(elapsed / args.steps / E * 1e6, 2),
             "roofline": roofline,
+            "placements": placements,
         }
         if thr is not None:
             out["throughput_mode"] = thr
         if world == 1 and not args.no_variants:
-            out["variants"] = path_variants(dev, S)
+            out["variants"] = path_variants(dev, S, cpu_legs=not args.no_variant_cpu)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, init[0].cpu(), unaries[0].cpu(), spec)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
@@ -349,12 +392,69 @@ def main():
         dist.destroy_process_group()
 
 
-def path_variants(dev, S, steps=300):
+def miou_delta_vs_reference(seeds, iou, masks):
+    """Per-image parity of the batched fit with the REFERENCE CLASSES' own 2000-step fits of the same problems
+    (tests/golden/fits_blob256_multi_{a,b}.npz: tools/gen_golden_scale.py, two runs of the reference with different OpenMP
+    thread counts - their disagreement is the reference's own run-to-run floor): the dataset-mean difference north_star bounds
+    by 1e-3, and the histogram of per-image |dIoU| next to the reference-vs-reference one."""
+    import numpy as np
+    fa, fb = (os.path.join(ROOT, "tests", "golden", f"fits_blob256_multi_{t}.npz") for t in "ab")
+    if not (os.path.exists(fa) and os.path.exists(fb)):
+        return {}
+    za, zb = np.load(fa), np.load(fb)
+    common = [k for k, s in enumerate(seeds) if f"s{s}.final_miou" in za.files and f"s{s}.final_miou" in zb.files]
+    if not common:
+        return {}
+    ra = np.array([float(za[f"s{seeds[k]}.final_miou"]) for k in common])
+    rb = np.array([float(zb[f"s{seeds[k]}.final_miou"]) for k in common])
+    hip = np.array([float(iou[k]) for k in common])
+    edges = [0.0, 1e-4, 3e-4, 1e-3, 3e-3, 1e-2, 1.0]
+    d_hip = np.minimum(np.abs(hip - ra), np.abs(hip - rb))        # distance to the nearer of the two reference runs
+    d_ref = np.abs(ra - rb)
+    px = []
+    for k in common:
+        m = np.unpackbits(za[f"s{seeds[k]}.final_mask_bits"])[: masks.shape[1]].astype(bool)
+        px.append(int((masks[k].numpy() != m).sum()))
+    return {"miou_delta_hist": {"images": len(common), "bin_edges": edges,
+                                "hip_vs_reference": np.histogram(d_hip, edges)[0].tolist(),
+                                "reference_vs_reference": np.histogram(d_ref, edges)[0].tolist(),
+                                "max_hip_vs_reference": round(float(d_hip.max()), 6), "max_reference_vs_reference": round(float(d_ref.max()), 6),
+                                "mean_miou_hip": round(float(hip.mean()), 6),
+                                "mean_miou_reference": [round(float(ra.mean()), 6), round(float(rb.mean()), 6)],
+                                "mean_abs_diff_of_means": round(float(abs(hip.mean() - 0.5 * (ra.mean() + rb.mean()))), 6),
+                                "mask_pixels_differing_from_reference_run_a": px,
+                                "source": "tests/golden/fits_blob256_multi_{a,b}.npz (reference classes, tools/gen_golden_scale.py)"}}
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def _host_threads():
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    return max(1, cores)
+
+
+def path_variants(dev, S, steps=300, cpu_legs=True):
     """Extra, never part of `value`: the other priors on the same path (one image / sequence on this GPU): ICNN L=2,
-    ConvexDiffeomorphismNet, PathConnectedNet (RealNVP) on (x, y) and on (x, y, t).  Per variant: microseconds per optimizer
-    step of the fused fit (wall clock over `steps` steps), a `roofline` object on the ALGORITHMIC flops of one step (3 x the
-    forward flops of the ICNN and of the deformation, SURVEY.md 8d's convention; bound = the fp32 matrix/vector peak, which are
-    the same number on this chip) and a `check`: the loss of the timed fit is finite and falls."""
+    ConvexDiffeomorphismNet, PathConnectedNet (RealNVP) on (x, y) and on (x, y, t), and the fused joint-training step of
+    configs[4].  Per variant: microseconds per optimizer step of the fused fit (wall clock over `steps` steps), a `roofline` object
+    on the ALGORITHMIC flops of one step (3 x the forward flops of the ICNN and of the deformation, SURVEY.md 8d's convention;
+    bound = the fp32 matrix/vector peak, which are the same number on this chip), a `check` (the loss of the timed fit is finite
+    and falls), and - from ONE short run of the CPU oracle's loop on the same problem from the same parameters - `cpu` (its time per
+    step on this host) and `parity` (the head of the HIP loss curve against the oracle's, relative)."""
     import torch
     import awesome_amd as A
     from awesome_amd.dataset import SyntheticSequenceDataset, convex_blob_unaries
@@ -363,17 +463,34 @@ def path_variants(dev, S, steps=300):
     def icnn_fwd_flop(h, c, layers):          # 4h + L(2h^2 + 4h) + 2h + 4 for c = 2 (2hc + L(2h^2 + 2hc) + 2h + 2c in general)
         return 2 * h * c + layers * (2 * h * h + 2 * h * c) + 2 * h + 2 * c
 
-    def entry(us, n_points, fwd_flop_icnn, fwd_flop_flow, hist):
+    threads = min(_host_threads(), 16)
+
+    def entry(us, n_points, fwd_flop_icnn, fwd_flop_flow, hist, oracle=None, oracle_steps=0):
         flop = 3.0 * (fwd_flop_icnn + fwd_flop_flow) * n_points
         tf = flop / (us * 1e-6) / 1e12
         h = hist.float().cpu()
-        return {"us_per_step": us,
-                "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4), "flop_per_step": int(flop),
-                             "flop_per_point_icnn_fwd": fwd_flop_icnn, "flop_per_point_flow_fwd": fwd_flop_flow,
-                             "basis": "wall clock per optimizer step (all kernels of the step), not one kernel"},
-                "check": {"loss_first": round(float(h[0]), 6), "loss_last": round(float(h[-1]), 6),
-                          "ok": bool(torch.isfinite(h).all() and h[-1] < h[0])}}
+        e = {"us_per_step": us,
+             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4), "flop_per_step": int(flop),
+                          "flop_per_point_icnn_fwd": fwd_flop_icnn, "flop_per_point_flow_fwd": fwd_flop_flow,
+                          "basis": "wall clock per optimizer step (all kernels of the step), not one kernel"},
+             "check": {"loss_first": round(float(h[0]), 6), "loss_last": round(float(h[-1]), 6),
+                       "ok": bool(torch.isfinite(h).all() and h[-1] < h[0])}}
+        if oracle is not None and cpu_legs:
+            from oracle import inr_oracle as O   # noqa: F401  (checker + CPU baseline leg only)
+            torch.set_num_threads(threads)
+            oracle(1)                                               # warm-up (allocator, thread pool)
+            t0 = time.perf_counter()
+            losses = oracle(oracle_steps)
+            dt = time.perf_counter() - t0
+            ref = torch.tensor(losses, dtype=torch.float32)
+            rel = ((h[:oracle_steps] - ref).abs() / ref.abs().clamp_min(1e-12))
+            e["cpu"] = {"ms_per_step": round(dt / oracle_steps * 1e3, 2), "threads": threads, "kind": "port",
+                        "sample": f"{oracle_steps} optimizer steps of the oracle's loop on the same problem ({dt:.1f} s)",
+                        "speedup": round(dt / oracle_steps * 1e6 / us, 1)}
+            e["parity"] = {"loss_head_steps": oracle_steps, "loss_head_max_rel_diff_vs_oracle": float(f"{float(rel.max()):.3e}"),
+                           "first_loss_hip": float(h[0]), "first_loss_oracle": float(ref[0])}
+        return e
 
     def timed(fn):
         fn(10)
@@ -383,58 +500,171 @@ def path_variants(dev, S, steps=300):
         torch.cuda.synchronize()
         return round((time.perf_counter() - t0) / steps * 1e6, 1), res.loss_hist[0]
 
+    from oracle import inr_oracle as O   # the checker / CPU leg (never on the product path)
     torch.manual_seed(0)
     N = S * S
     un = convex_blob_unaries(S, 0).reshape(1, -1).to(dev)
+    un_img = un.reshape(1, 1, S, S).cpu()
     grid = A.Grid.linspace(S, S, dev)
+    grid_t = O.positional_grid(S, S)[None]
     out = {"unit": "us per optimizer step", "steps": steps}
     m2 = ConvexNextNet(n_hidden=130, n_hidden_layers=2, in_features=2)
     p2 = m2.flat_parameters()[None].to(dev)
+    sd2 = {k: v.detach().clone() for k, v in m2.state_dict().items()}
     us, h = timed(lambda n: A.fit(m2.spec, p2.clone(), grid, un, n, lr=2e-3, record_loss=True, want_logits=False))
-    out[f"ConvexNextNet_L2_{S}x{S}"] = entry(us, N, icnn_fwd_flop(130, 2, 2), 0, h)
+    out[f"ConvexNextNet_L2_{S}x{S}"] = entry(us, N, icnn_fwd_flop(130, 2, 2), 0, h,
+                                             lambda n: O.fit_icnn(sd2, grid_t, un_img, n, lr=2e-3)[1], 20)
     cdn = ConvexDiffeomorphismNet(n_hidden=130, n_hidden_layers=2, nf_layers=6, nf_hidden=130,
                                   diffeo_args=dict(backbone="normal_block")).to(dev)   # the reference configs' form
+    sdc = {k: v.detach().cpu().clone() for k, v in cdn.state_dict().items()}
     us, h = timed(lambda n: cdn.fit_images(grid, un, num_epochs=n))
-    out[f"ConvexDiffeomorphismNet_K6_w130_L2_{S}x{S}"] = entry(us, N, icnn_fwd_flop(130, 2, 2), 6 * 8 * 130, h)   # 8 w flop per coupling
+    out[f"ConvexDiffeomorphismNet_K6_w130_L2_{S}x{S}"] = entry(
+        us, N, icnn_fwd_flop(130, 2, 2), 6 * 8 * 130, h,   # 8 w flop per coupling
+        lambda n: O.fit_convex_diffeo(sdc, grid_t, un_img, n, 6, lr=3e-3, loss_kind="bce", weight_decay_on_weight_g=5e-5,
+                                      plateau=dict(patience=200, factor=0.5))[1], 8)
+
+    def pcn_oracle(model, rows, un_rows, C, F):
+        _, rspec = model._specs()
+        sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()
+               if v.dtype == torch.float32 and not k.startswith("flow_net.norm") and not k.endswith("data_dep_init_done")}
+        masks = O.rnvp_masks(C, F)
+        return lambda n: O.fit_pcn(sd0, rows, un_rows, n, masks, torch.tensor(rspec.vmin), torch.tensor(rspec.vmax), lr=1e-3,
+                                   optimizer="adamax", flow_weight_decay=1e-5, plateau=dict(patience=200, factor=0.5))[1]
+
     pc2 = real_nvp_path_connected_net(channels=2, hidden_units=32, flow_n_flows=12, flow_output_fn="tanh").to(dev)
+    pc2._actnorm_init_if_needed(pc2._first_image_coords(grid))
+    rows2 = O.pixelize(grid_t)
     us, h = timed(lambda n: pc2.fit_images(grid, un, num_epochs=n))
-    out[f"PathConnectedNet_RealNVP_C2_F12_L2_{S}x{S}"] = entry(us, N, icnn_fwd_flop(130, 2, 2), 12 * 32 * 2 * 2 * 2, h)   # F hid 2 nets C 2
+    out[f"PathConnectedNet_RealNVP_C2_F12_L2_{S}x{S}"] = entry(us, N, icnn_fwd_flop(130, 2, 2), 12 * 32 * 2 * 2 * 2, h,   # F hid 2 nets C 2
+                                                               pcn_oracle(pc2, rows2, un.cpu().reshape(-1, 1), 2, 12), 6)
     ds = SyntheticSequenceDataset(1, 128, 16)
     g3, u3 = A.Grid.explicit(ds.coords().to(dev)), ds.batch([0]).to(dev)
     pc3 = real_nvp_path_connected_net(channels=3, hidden_units=32, flow_n_flows=18, flow_output_fn="tanh").to(dev)
+    pc3._actnorm_init_if_needed(pc3._first_image_coords(g3))
     us, h = timed(lambda n: pc3.fit_images(g3, u3, num_epochs=n))
-    out["PathConnectedNet_RealNVP_C3_F18_L2_128x128x16"] = entry(us, 128 * 128 * 16, icnn_fwd_flop(130, 3, 2), 18 * 32 * 2 * 3 * 2, h)
+    out["PathConnectedNet_RealNVP_C3_F18_L2_128x128x16"] = entry(us, 128 * 128 * 16, icnn_fwd_flop(130, 3, 2), 18 * 32 * 2 * 3 * 2, h,
+                                                                 pcn_oracle(pc3, ds.coords().t().contiguous(), u3.cpu().reshape(-1, 1), 3, 18), 3)
+    out["joint_step_configs4"] = joint_step_variant(dev, S, icnn_fwd_flop)
     return out
 
 
+def joint_step_variant(dev, S, icnn_fwd_flop, steps=300):
+    """BASELINE configs[4]'s training step (TorchAgent._perform_step with FBMSJointLoss on noisy 256x256 pseudo-labels), fused: per
+    step the torch backbone (a 3x3 convolution stand-in for the UNet, which is out of scope) + ONE C-ABI call for everything behind
+    its output.  Wall clock per step over a round-robin of 8 images whose priors sit in a PriorBank, for the convexity prior and for
+    the path-connected one (RealNVP), fused and through the autograd bridges (round 2's path); `c_abi_call_us` = the device time of
+    the fused call alone (HIP events around 200 calls)."""
+    import torch
+    import awesome_amd as A
+    from awesome_amd import joint as J
+    from awesome_amd.agent import JointTrainer
+    from awesome_amd.dataset import SyntheticPriorDataset
+    from awesome_amd.measures import FBMSJointLoss
+    from awesome_amd.model import ConvSegStandIn, ConvexNextNet, WrapperModule, real_nvp_path_connected_net
+    from awesome_amd.prior_bank import PriorBank, _ordered_parameters
+    n_img, N = 8, S * S
+    torch.manual_seed(3)
+    ds = SyntheticPriorDataset(n_images=n_img, size=S, kind="noisy_blob")
+    items = [ds[i] for i in range(n_img)]
+    feat = torch.zeros(1, 1, 1, 1, device=dev)
+    batch = [((it[0][0][None].to(dev), feat, it[0][2][None].to(dev)), it[1][None].to(dev)) for it in items]
+    res = {"unit": "us per joint training step", "images_round_robin": n_img, "steps": steps,
+           "note": "segmentation backbone = 3x3 conv stand-in in torch (UNet out of scope); loss FBMSJointLoss(sssdms BCE, clip), Adam"}
+
+    def run(factory, fused, launches, fwd_flop_icnn, fwd_flop_flow):
+        seg = ConvSegStandIn().to(dev)
+        wrapper = WrapperModule(seg, factory().to(dev), use_segmentation_output_inversion=True).to(dev)
+        bank = PriorBank(lambda: factory().to(dev), n_images=n_img, device=dev)
+        for k in range(n_img):
+            bank.row(k)
+        for b in wrapper.prior_module.buffers():
+            pass
+        for name, b in wrapper.prior_module.named_buffers():
+            if name.endswith("data_dep_init_done"):
+                b.fill_(1.0)
+        opt = torch.optim.Adam(list(seg.parameters()) + list(_ordered_parameters(wrapper.prior_module)), lr=1e-3)
+        tr = JointTrainer(wrapper, bank, FBMSJointLoss(alpha=1.0, beta=1.0), opt, fused=fused)
+        first = None
+        for k in range(2 * n_img):   # warm
+            loss, _ = tr.perform_step(k % n_img, *batch[k % n_img])
+            first = first if first is not None else float(loss)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            loss, _ = tr.perform_step(k % n_img, *batch[k % n_img])
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / steps * 1e6
+        flop = 3.0 * (fwd_flop_icnn + fwd_flop_flow) * N
+        e = {"us_per_step": round(us, 1), "kernel_launches_per_step_behind_the_backbone": launches,
+             "loss_first": round(first, 6), "loss_last": round(float(loss), 6), "ok": bool(torch.isfinite(loss))}
+        if fused:
+            tf = flop / (us * 1e-6) / 1e12
+            e["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4), "flop_per_step": int(flop),
+                             "basis": "wall clock per joint step incl. the torch backbone and Python, on 3 x the prior's forward flops"}
+        return e
+
+    icnn = lambda: ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=1)   # noqa: E731
+    pcn = lambda: real_nvp_path_connected_net(channels=2, hidden_units=32, flow_n_flows=12, flow_output_fn="tanh")   # noqa: E731
+    res["convex_prior_fused"] = run(icnn, True, 8, icnn_fwd_flop(130, 2, 1), 0)
+    res["convex_prior_autograd_bridges"] = run(icnn, False, None, icnn_fwd_flop(130, 2, 1), 0)
+    res["path_connected_prior_fused"] = run(pcn, True, 13, icnn_fwd_flop(130, 2, 2), 12 * 32 * 2 * 2 * 2)
+    res["path_connected_prior_autograd_bridges"] = run(pcn, False, None, icnn_fwd_flop(130, 2, 2), 12 * 32 * 2 * 2 * 2)
+    # the C-ABI call alone
+    m = ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=1)
+    row, opt_state = m.flat_parameters().to(dev), torch.zeros(2 * m.spec.n_params + 8, device=dev)
+    grid = A.Grid.linspace(S, S, dev)
+    seg = torch.sigmoid(items[0][0][0].reshape(-1).to(dev))
+    tgt = items[0][1].reshape(-1).to(dev)
+    desc = J.joint_desc()
+    for t in range(1, 11):
+        J.joint_step(m.spec, row, opt_state, grid, seg, tgt, desc, step=t, lr=1e-3)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for t in range(11, 211):
+        J.joint_step(m.spec, row, opt_state, grid, seg, tgt, desc, step=t, lr=1e-3)
+    e1.record()
+    torch.cuda.synchronize()
+    res["convex_prior_fused"]["c_abi_call_us"] = round(e0.elapsed_time(e1) / 200 * 1e3, 1)
+    return res
+
+
 def cpu_baseline(args, flat0, unaries0, spec):
-    """The CPU oracle (pure torch restatement of the reference loop, parity-pinned to the reference's golden vectors)
-    timed on this host: `cpu_sample_steps` optimizer steps of the same 256x256 fit, extrapolated to E steps."""
+    """The CPU oracle (pure torch restatement of the reference loop, parity-pinned to the reference's golden vectors) timed on
+    this host on a bounded sample of the SAME 256x256 fit, extrapolated linearly to E steps: all host threads (`value`) and the
+    8-thread setting SURVEY 6 measured the reference classes at (77 ms per step in the build container)."""
     import torch
     import awesome_amd as A
     from oracle import inr_oracle as O   # the thing being timed as the CPU baseline (kind = "port")
 
     S, E = args.size, args.epochs
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    threads = max(1, min(cores, 16))   # the GPU box's CPU share for one GPU; more threads oversubscribe and run slower
-    torch.set_num_threads(threads)
+    cores = _host_threads()
     p = A.unpack_params(spec, flat0)
     grid = O.positional_grid(S, S)[None]
     un = unaries0.reshape(1, 1, S, S)
-    O.fit_icnn(p, grid, un, 3, lr=2e-3)   # warm-up
+
+    def leg(threads, n):
+        torch.set_num_threads(threads)
+        O.fit_icnn(p, grid, un, 3, lr=2e-3)   # warm-up
+        t0 = time.perf_counter()
+        O.fit_icnn(p, grid, un, n, lr=2e-3)
+        dt = time.perf_counter() - t0
+        return dt, dt / n
+
+    threads = max(1, min(cores, 16))   # the GPU box's CPU share for one GPU; more threads oversubscribe and run slower
     n = args.cpu_sample_steps
-    t0 = time.perf_counter()
-    O.fit_icnn(p, grid, un, n, lr=2e-3)
-    dt = time.perf_counter() - t0
-    s_per_step = dt / n
-    return {"value": round(1.0 / (s_per_step * E), 6), "unit": "fits/s", "cores": threads, "kind": "port",
-            "sample": f"{n} of {E} optimizer steps of the same {S}x{S} fit ({dt:.1f} s, {s_per_step * 1e3:.1f} ms/step), "
-                      f"torch {torch.__version__} CPU, extrapolated linearly",
-            "ms_per_optimizer_step": round(s_per_step * 1e3, 2)}
+    dt, s_per_step = leg(threads, n)
+    out = {"value": round(1.0 / (s_per_step * E), 6), "unit": "fits/s", "cores": threads, "kind": "port",
+           "cpu_model": _cpu_model(), "host_threads_available": cores,
+           "sample": f"{n} of {E} optimizer steps of the same {S}x{S} fit ({dt:.1f} s, {s_per_step * 1e3:.1f} ms/step), "
+                     f"torch {torch.__version__} CPU, extrapolated linearly",
+           "ms_per_optimizer_step": round(s_per_step * 1e3, 2)}
+    if args.cpu_sample_steps_8 > 0 and cores >= 8:
+        dt8, sp8 = leg(8, args.cpu_sample_steps_8)
+        out["threads_8"] = {"value": round(1.0 / (sp8 * E), 6), "unit": "fits/s", "cores": 8, "ms_per_optimizer_step": round(sp8 * 1e3, 2),
+                            "sample": f"{args.cpu_sample_steps_8} optimizer steps ({dt8:.1f} s)",
+                            "survey_reference_classes_8_threads_ms_per_step": 77.0}
+    return out
 
 
 if __name__ == "__main__":

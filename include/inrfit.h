@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define INRFIT_ABI_VERSION 4
+#define INRFIT_ABI_VERSION 5
 
 enum {
     INR_OK = 0,
@@ -302,24 +302,80 @@ int inrfit_pcn_fit(const InrModelDesc* model, const InrRnvpDesc* rnvp, float* ic
                    float* loss_hist, float* final_logits, int32_t* status, void* workspace, int64_t workspace_bytes,
                    void* stream);
 
-/* ---- joint segmentation + prior training step: FBMSJointLoss (awesome/measures/fbms_joint_loss.py:35-59) on the device.
- * output [batch][2][hw] = [seg, prior] probabilities (the WrapperModule's output, image mode), target [batch][hw]:
+/* ---- joint segmentation + prior training: the composite losses on the device (row a12).
+ * INR_JOINT_FBMS - FBMSJointLoss (awesome/measures/fbms_joint_loss.py:35-59).  output [batch][2][hw] = [seg, prior] probabilities (the
+ * WrapperModule's output, image mode), target [batch][hw]:
  *     loss = alpha * mean(w (.) crit(seg, target)) + clip(beta * mean((seg - prior)^2))
  * crit = kind (INR_LOSS_SE | INR_LOSS_BCE = torch.nn.BCELoss), w = UnariesWeightedLoss weights by weight_mode / ratio with the
  * fg/bg counts taken over the whole batch (unaries_weighted_loss.py:35-69), clip: the penalty is rescaled to the segmentation
  * loss when it exceeds it (factor detached).  The reference takes that decision on the host - one sync per training step; here
- * nothing leaves the device.  loss_out [4] (device): loss, mean weighted crit (before alpha), mean penalty (before beta), the
- * clip factor.  doutput (optional) [batch][2][hw]: d loss / d output, BOTH channels (the penalty pulls seg and prior together). */
+ * nothing leaves the device.
+ * INR_JOINT_AWESOME_IMAGE - AwesomeImageLoss (awesome/measures/awesome_image_loss.py:34-53), same layout:
+ *     loss = mean(w crit(seg, t)) + alpha * mean(w' pcrit(prior, t));   extra_penalty (the runner's hook, awesome_runner.py:351-371):
+ *     loss = gamma * loss + beta * mean((prior - (seg > 0.5))^2)
+ * pcrit / w' = prior_kind / prior_weight_mode / prior_ratio.
+ * INR_JOINT_AWESOME_PIXEL - AwesomeLoss (awesome/measures/awesome_loss.py:45-65), pixel mode: output [batch][hw][2] = (seg, prior) per
+ * pixel, the first n_scribble pixels carry targets [batch][n_scribble], the others are random pixels of the align term:
+ *     loss = mean(w crit(seg_s, t)) + alpha * mean(w crit(prior_s, t));   extra_penalty and n_scribble < hw:
+ *     loss = gamma * loss + beta * mean((prior_r - (seg_r > 0.5))^2) over pixels [hw - n_scribble, hw)   (the reference's slice, :58-59;
+ *     its constants are gamma = 0.1, beta = 100; prior_kind / prior_weight_mode are taken equal to kind / weight_mode).
+ * loss_out [4] (device): loss, mean weighted crit(seg) (before alpha / gamma), mean penalty (before beta), FBMS's clip factor.
+ * doutput (optional), laid out like output: d loss / d output, BOTH channels. */
+enum { INR_JOINT_FBMS = 0, INR_JOINT_AWESOME_IMAGE = 1, INR_JOINT_AWESOME_PIXEL = 2 };
 typedef struct InrJointLossDesc {
     int32_t kind;
     int32_t weight_mode;
     float ratio;
     float alpha, beta;
-    int32_t clip_penalty;
+    int32_t clip_penalty;     /* INR_JOINT_FBMS */
+    int32_t form;             /* INR_JOINT_* (0 = FBMS: a zero-initialised tail keeps ABI v4 callers' meaning) */
+    int32_t prior_kind;       /* INR_JOINT_AWESOME_IMAGE: criterion / weights of the prior term */
+    int32_t prior_weight_mode;
+    float prior_ratio;
+    float gamma;              /* AWESOME_*: factor on the data terms once extra_penalty is on */
+    int32_t extra_penalty;
+    int64_t n_scribble;       /* INR_JOINT_AWESOME_PIXEL: leading pixels with targets (0 = all) */
 } InrJointLossDesc;
 int64_t inrfit_joint_loss_workspace_bytes(int64_t n_elems);
 int inrfit_joint_loss(const float* output, const float* target, int batch, int64_t hw, const InrJointLossDesc* desc,
                       float* loss_out, float* doutput, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- ONE fused training step of the joint segmentation + prior optimisation for one image:
+ * TorchAgent._perform_step (awesome/agent/torch_agent.py:428-551) with the PriorManager swap (awesome/dataset/prior_dataset.py:96-110)
+ * reduced to "which parameter row".  The segmentation network stays a torch module; everything behind its output runs here:
+ *     prior forward (this image's parameters) -> sigmoid -> composite loss (value + d loss / d seg) -> prior backward FROM THE
+ *     ACTIVATIONS OF THAT SAME PASS (the fused step kernel; no second forward) -> Adam / Adamax on the row in place -> enforce_convexity
+ * seg [n_points]: the segmentation module's probabilities of this image (output channel 0 of the WrapperModule, after its sigmoid /
+ * inversion, wrapper_module.py:230-273); target [n_points].  dseg [n_points] (out) = d loss / d seg for the torch backbone's own
+ * backward.  prior_logits [n_points] (out, optional): the prior's pre-sigmoid output of this step's forward.  loss_out [4] as in
+ * inrfit_joint_loss.  params / opt_state: ONE row (inrfit_param_count / inrfit_opt_state_floats floats); the reference keeps ONE
+ * optimizer state for the single prior model whose VALUES are swapped per image (torch_agent.py:812-839), so a caller reproduces it
+ * by passing the same opt_state with every row and `step` = the global step count; a state per row with its own count is the
+ * per-image variant.  `step` >= 1 is torch's state['step'] after this step (bias corrections); the learning rate is opt->lr (host
+ * schedulers stay on the host), opt->plateau is ignored.  A non-finite loss leaves the row untouched and sets *status (optional).
+ * Forms: INR_JOINT_FBMS, and INR_JOINT_AWESOME_IMAGE while extra_penalty is off (with it on the prior has two data terms: use
+ * inrfit_joint_loss + inrfit_backward; returns INR_EUNSUPPORTED).
+ * How the clip stays on the device with a single prior pass: the prior's gradient is linear in the penalty's coefficient, so the step
+ * kernel runs with the unclipped coefficient, its own loss column gives the penalty, and the update kernel multiplies the reduced
+ * gradient by the (detached) clip factor. */
+int64_t inrfit_joint_step_workspace_bytes(const InrModelDesc* model, const InrGridDesc* grid);
+int inrfit_joint_step(const InrModelDesc* model, float* params, float* opt_state, const InrGridDesc* grid, const float* seg,
+                      const float* target, const InrJointLossDesc* desc, const InrOptDesc* opt, int step, float* loss_out,
+                      float* dseg, float* prior_logits, int32_t* status, void* workspace, int64_t workspace_bytes, void* stream);
+/* The same step with the path-connected priors (ICNN behind a learned deformation of the grid): PathConnectedNet with the RealNVP
+ * flow (optimizer over ICNN + flow_net + 1x1 linear, `flow_weight_decay` on the flow_net parameters) and ConvexDiffeomorphismNet
+ * (weight decay `wd_on_weight_g` on every *weight_g; opt->kind must be INR_OPT_ADAM).  Workspace: inrfit_pcn_workspace_bytes /
+ * inrfit_cdn_workspace_bytes (n_images = 1) + inrfit_joint_loss_workspace_bytes(n_points). */
+int inrfit_pcn_joint_step(const InrModelDesc* model, const InrRnvpDesc* rnvp, float* icnn_params, float* flow_params,
+                          float* icnn_opt_state, float* flow_opt_state, const InrGridDesc* grid, const float* seg,
+                          const float* target, const InrJointLossDesc* desc, const InrOptDesc* opt, float flow_weight_decay,
+                          int step, float* loss_out, float* dseg, float* prior_logits, int32_t* status, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+int inrfit_cdn_joint_step(const InrModelDesc* model, const InrFlowDesc* flow, float* icnn_params, float* flow_params,
+                          float* icnn_opt_state, float* flow_opt_state, const InrGridDesc* grid, const float* seg,
+                          const float* target, const InrJointLossDesc* desc, const InrOptDesc* opt, float wd_on_weight_g,
+                          int step, float* loss_out, float* dseg, float* prior_logits, int32_t* status, void* workspace,
+                          int64_t workspace_bytes, void* stream);
 
 /* Measurement hook (bench.py, rocprof): launch ONLY the fused forward+loss+backward step kernel `iters` times
  * back-to-back on `stream` (no optimizer step), so its average duration can be bracketed with events. */
@@ -340,6 +396,11 @@ int inrfit_mfma_stream(int workgroups, int iters, double* flop, void* scratch, v
  * of the two brackets with the un-instrumented time per optimizer step. */
 int inrfit_timing_begin(int max_samples);
 int inrfit_timing_end(float* avg_step_bracket_us, float* avg_update_bracket_us, int* n_samples);
+
+/* Test hook (tests/test_gpu_rnvp.py): the kernels' own tanh / exp of the coupling outputs (awesome_amd/csrc/rnvp.h fast_tanh /
+ * fast_exp) evaluated on x [n] -> tanh_out [n], exp_out [n], so their error bounds are asserted against float64 on the device
+ * that runs them. */
+int inrfit_debug_tanh_exp(const float* x, int64_t n, float* tanh_out, float* exp_out, void* stream);
 
 const char* inrfit_strerror(int code);
 

@@ -33,6 +33,8 @@ ALIASES = {
     "awesome.measures.se.SE": "awesome_amd.measures.SE",
     "awesome.measures.unaries_weighted_loss.UnariesWeightedLoss": "awesome_amd.measures.UnariesWeightedLoss",
     "awesome.measures.fbms_joint_loss.FBMSJointLoss": "awesome_amd.measures.FBMSJointLoss",
+    "awesome.measures.unaries_conversion_loss.UnariesConversionLoss": "awesome_amd.measures.UnariesConversionLoss",
+    "awesome.measures.awesome_loss.AwesomeLoss": "awesome_amd.measures.AwesomeLoss",
     "awesome.measures.awesome_image_loss.AwesomeImageLoss": "awesome_amd.measures.AwesomeImageLoss",
     "awesome.model.forward_module.ForwardModule": "awesome_amd.model.ForwardModule",
     "awesome.model.wrapper_module.WrapperModule": "awesome_amd.model.WrapperModule",
@@ -174,76 +176,58 @@ def main(cfg):
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    report = []
-    if mine:                                    # a rank without images still joins every collective below
-        agent._pretrain(wrapper, torch.utils.data.Subset(ds, mine), None, use_progress_bar=False)
-        report = wrapper.prior_module.pretrain_report
-    # ---- joint training epochs (TorchAgent._perform_step, torch_agent.py:428-551): segmentation module + per-image priors +
-    # the composite loss (FBMSJointLoss / AwesomeImageLoss), the priors resident on the device in a PriorBank.  Each rank trains
-    # its own copy of the segmentation stand-in on its shard (sharing a backbone over ranks is ordinary DDP, out of scope §8e).
-    joint_epochs = int((cfg.get("agent_args") or {}).get("joint_epochs", 0))
-    joint_losses = []
-    if joint_epochs > 0 and mine and criterion is not None and not _fusable(criterion):
-        from awesome_amd.agent import JointTrainer
-        from awesome_amd.prior_bank import PriorBank
-        seg_type = dynamic_import(cfg.get("segmentation_model_type", "awesome_amd.model.ConvSegStandIn"))
-        seg = seg_type(**dict(cfg.get("segmentation_model_args") or {})).to(device)
-        prior = wrapper.prior_module
-        jw = WrapperModule(seg, prior, use_segmentation_output_inversion=True).to(device)
-        bank = PriorBank(lambda: model_type(**model_args).to(device), n_images=len(mine), device=device, keys=mine)
-        cache0 = ds.__prior_cache__
-        for k in mine:
-            prior.load_state_dict({n: v.to(device) for n, v in cache0[k].items()})
-            bank.row(k).copy_(torch.cat([p.detach().reshape(-1) for p in bank_params(prior)]))
-        params = [p for p in seg.parameters()] + bank_params(prior)
-        opt = torch.optim.Adam(params, lr=float(opt_args.get("lr", 1e-3)))
-        trainer = JointTrainer(jw, bank, criterion, opt)
-        for epoch in range(joint_epochs):
-            # the runner's extra-penalty hook (awesome/run/awesome_runner.py:351-371; config fields awesome_config.py:164-173): from
-            # epoch N on the loss adds its penalty term, optionally with the learning rate scaled once
-            if (cfg.get("use_extra_penalty_hook") and epoch >= int(cfg.get("extra_penalty_after_n_epochs", 200))
-                    and hasattr(criterion, "extra_penalty") and not criterion.extra_penalty):
-                criterion.extra_penalty = True
-                if cfg.get("use_reduce_lr_in_extra_penalty_hook"):
-                    for group in opt.param_groups:
-                        group["lr"] = group["lr"] * float(cfg.get("reduce_lr_in_extra_penalty_hook_factor", 0.05))
-            acc = torch.zeros((), device=device)
-            for k in mine:
-                (_, _), ((image, feat, xy), target) = ds[k]
-                loss, _ = trainer.perform_step(k, (image[None].to(device), feat[None].to(device), xy[None].to(device)),
-                                               target[None].to(device))
-                acc = acc + loss
-            joint_losses.append(float(acc) / len(mine))
-        for k in mine:   # the jointly trained priors replace the pretrained ones in the cache
-            with bank.manager(prior, k):
-                cache0[k] = {n: v.detach().cpu().clone() for n, v in prior.state_dict().items()}
+    report, joint_losses, joint_epochs, error = [], [], int((cfg.get("agent_args") or {}).get("joint_epochs", 0)), None
+    try:                                        # rank-local work: an exception here must not strand the other ranks (below)
+        report, joint_losses = _fit_shard(cfg, ds, mine, agent, wrapper, criterion, model_type, model_args, opt_args, device, joint_epochs)
+    except Exception as err:   # noqa: BLE001 - reported, agreed on by all ranks, and turned into a non-zero exit
+        import traceback
+        traceback.print_exc()
+        error = err
+    # One flag all-reduce BEFORE the data collectives: if any rank failed (e.g. ValueError("Loss is nan or inf!") from pretrain),
+    # every rank reports and exits non-zero together instead of hanging in max_over_ranks / gather_per_image / barrier.
+    if parallel.any_rank_failed(error is not None, device):
+        print(f"[run.py] rank {rank}: " + (f"failed: {error!r}" if error is not None else "another rank failed; exiting"),
+              file=sys.stderr, flush=True)
+        parallel.shutdown()
+        raise SystemExit(1)
     torch.cuda.synchronize()
     dt = parallel.max_over_ranks(time.perf_counter() - t0, device)
 
     cache = ds.__prior_cache__
-    f32 = lambda xs: torch.tensor(xs, dtype=torch.float32, device=device).reshape(len(mine))  # noqa: E731
-    iou = f32([0.0 if r["skipped"] else r["iou"] for r in report])
-    retries = f32([r["retries"] for r in report])
-    gt_iou = noisy_iou = None
-    if hasattr(ds, "ground_truth_batch") and dataset_args.get("kind") == "noisy_blob":
-        # refinement configs: score the fitted prior (and the input labels) against the clean mask
-        prior, size = wrapper.prior_module, ds.size
-        vals, nvals = [], []
-        for k in mine:
-            prior.load_state_dict({n: v.to(device) for n, v in cache[k].items()})
-            (_, _), ((_, _, xy), _) = ds[k]
-            with torch.no_grad():
-                p = torch.sigmoid(prior(xy[None].to(device))).reshape(1, -1)
-            gt = ds.ground_truth(k).reshape(1, -1).to(device)
-            vals.append(float(A.miou(p, gt)[0]))
-            nvals.append(float(A.miou(ds.unaries(k).reshape(1, -1).to(device), gt)[0]))
-        gt_iou, noisy_iou = f32(vals), f32(nvals)
-    masks_saved = 0
-    if cfg.get("save_masks") and mine:
-        # evaluation + export on the device (reference: get_result / split_model_result / save_result_mask per image on the host,
-        # run/functions.py:2111-2151, 2315-2361, 2432-2487): every rank writes the masks of its own images into the shared folder
-        from awesome_amd.run import evaluate_dataset
-        masks_saved = len(evaluate_dataset(wrapper, ds, indices=mine, out_dir=os.path.join(out_dir, "masks"))["indices"])
+    iou = retries = gt_iou = noisy_iou = None
+    masks_saved, error = 0, None
+    try:                                        # second rank-local phase (scores, mask export): same agreement as above
+        f32 = lambda xs: torch.tensor(xs, dtype=torch.float32, device=device).reshape(len(mine))  # noqa: E731
+        iou = f32([0.0 if r["skipped"] else r["iou"] for r in report])
+        retries = f32([r["retries"] for r in report])
+        gt_iou = noisy_iou = None
+        if hasattr(ds, "ground_truth_batch") and dataset_args.get("kind") == "noisy_blob":
+            # refinement configs: score the fitted prior (and the input labels) against the clean mask
+            prior, size = wrapper.prior_module, ds.size
+            vals, nvals = [], []
+            for k in mine:
+                prior.load_state_dict({n: v.to(device) for n, v in cache[k].items()})
+                (_, _), ((_, _, xy), _) = ds[k]
+                with torch.no_grad():
+                    p = torch.sigmoid(prior(xy[None].to(device))).reshape(1, -1)
+                gt = ds.ground_truth(k).reshape(1, -1).to(device)
+                vals.append(float(A.miou(p, gt)[0]))
+                nvals.append(float(A.miou(ds.unaries(k).reshape(1, -1).to(device), gt)[0]))
+            gt_iou, noisy_iou = f32(vals), f32(nvals)
+        if cfg.get("save_masks") and mine:
+            # evaluation + export on the device (reference: get_result / split_model_result / save_result_mask per image on the host,
+            # run/functions.py:2111-2151, 2315-2361, 2432-2487): every rank writes the masks of its own images into the shared folder
+            from awesome_amd.run import evaluate_dataset
+            masks_saved = len(evaluate_dataset(wrapper, ds, indices=mine, out_dir=os.path.join(out_dir, "masks"))["indices"])
+    except Exception as err:   # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+        error = err
+    if parallel.any_rank_failed(error is not None, device):
+        print(f"[run.py] rank {rank}: " + (f"failed: {error!r}" if error is not None else "another rank failed; exiting"),
+              file=sys.stderr, flush=True)
+        parallel.shutdown()
+        raise SystemExit(1)
     iou_all = parallel.gather_per_image(iou, len(ds), rank, world)
     retries_all = parallel.gather_per_image(retries, len(ds), rank, world)
     if gt_iou is not None:
@@ -288,6 +272,55 @@ def main(cfg):
     parallel.barrier()
 
 
+def _fit_shard(cfg, ds, mine, agent, wrapper, criterion, model_type, model_args, opt_args, device, joint_epochs):
+    """This rank's share of the work: the per-image pretrain fits, then the joint-training epochs.  -> (report, joint_losses)"""
+    import torch
+    from awesome_amd.model import WrapperModule
+    report = []
+    if mine:                                    # a rank without images still joins every collective below
+        agent._pretrain(wrapper, torch.utils.data.Subset(ds, mine), None, use_progress_bar=False)
+        report = wrapper.prior_module.pretrain_report
+    # ---- joint training epochs (TorchAgent._perform_step, torch_agent.py:428-551): segmentation module + per-image priors +
+    # the composite loss (FBMSJointLoss / AwesomeImageLoss), the priors resident on the device in a PriorBank.  Each rank trains
+    # its own copy of the segmentation stand-in on its shard (sharing a backbone over ranks is ordinary DDP, out of scope §8e).
+    joint_losses = []
+    if joint_epochs > 0 and mine and criterion is not None and not _fusable(criterion):
+        from awesome_amd.agent import JointTrainer
+        from awesome_amd.prior_bank import PriorBank
+        seg_type = dynamic_import(cfg.get("segmentation_model_type", "awesome_amd.model.ConvSegStandIn"))
+        seg = seg_type(**dict(cfg.get("segmentation_model_args") or {})).to(device)
+        prior = wrapper.prior_module
+        jw = WrapperModule(seg, prior, use_segmentation_output_inversion=True).to(device)
+        bank = PriorBank(lambda: model_type(**model_args).to(device), n_images=len(mine), device=device, keys=mine)
+        cache0 = ds.__prior_cache__
+        for k in mine:
+            prior.load_state_dict({n: v.to(device) for n, v in cache0[k].items()})
+            bank.row(k).copy_(torch.cat([p.detach().reshape(-1) for p in bank_params(prior)]))
+        params = [p for p in seg.parameters()] + bank_params(prior)
+        opt = torch.optim.Adam(params, lr=float(opt_args.get("lr", 1e-3)))
+        trainer = JointTrainer(jw, bank, criterion, opt)
+        for epoch in range(joint_epochs):
+            # the runner's extra-penalty hook (awesome/run/awesome_runner.py:351-371; config fields awesome_config.py:164-173): from
+            # epoch N on the loss adds its penalty term, optionally with the learning rate scaled once
+            if (cfg.get("use_extra_penalty_hook") and epoch >= int(cfg.get("extra_penalty_after_n_epochs", 200))
+                    and hasattr(criterion, "extra_penalty") and not criterion.extra_penalty):
+                criterion.extra_penalty = True
+                if cfg.get("use_reduce_lr_in_extra_penalty_hook"):
+                    for group in opt.param_groups:
+                        group["lr"] = group["lr"] * float(cfg.get("reduce_lr_in_extra_penalty_hook_factor", 0.05))
+            acc = torch.zeros((), device=device)
+            for k in mine:
+                (_, _), ((image, feat, xy), target) = ds[k]
+                loss, _ = trainer.perform_step(k, (image[None].to(device), feat[None].to(device), xy[None].to(device)),
+                                               target[None].to(device))
+                acc = acc + loss
+            joint_losses.append(float(acc) / len(mine))
+        for k in mine:   # the jointly trained priors replace the pretrained ones in the cache
+            with bank.manager(prior, k):
+                cache0[k] = {n: v.detach().cpu().clone() for n, v in prior.state_dict().items()}
+    return report, joint_losses
+
+
 def bank_params(prior):
     """The prior module's Parameter objects in the order of its flat vector (what PriorBank rows hold)."""
     op = prior._ordered_params()
@@ -313,15 +346,27 @@ def _run_sequence(cfg, A, parallel, rank, world, device, model_type, model_args,
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    cache, ious = {}, []
-    for i in mine:
-        torch.manual_seed(int(cfg.get("seed", 42)) + i)
-        model = model_type(**model_args).to(device)
-        un = dataset.batch([i]).to(device)
-        res = model.fit_images(grid, un, **kw)
-        ious.append(float(A.miou(torch.sigmoid(res.logits), un)[0]))
-        model.load_flat(res.icnn_params[0], res.flow_params[0])
-        cache[str(i)] = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cache, ious, error = {}, [], None
+    try:
+        for i in mine:
+            torch.manual_seed(int(cfg.get("seed", 42)) + i)
+            model = model_type(**model_args).to(device)
+            un = dataset.batch([i]).to(device)
+            res = model.fit_images(grid, un, **kw)
+            if int(res.status[0]) != 0:
+                raise ValueError(f"Loss is nan or inf! (sequence {i})")
+            ious.append(float(A.miou(torch.sigmoid(res.logits), un)[0]))
+            model.load_flat(res.icnn_params[0], res.flow_params[0])
+            cache[str(i)] = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    except Exception as err:   # noqa: BLE001 - agreed on by all ranks before the collectives (see main)
+        import traceback
+        traceback.print_exc()
+        error = err
+    if parallel.any_rank_failed(error is not None, device):
+        print(f"[run.py] rank {rank}: " + (f"failed: {error!r}" if error is not None else "another rank failed; exiting"),
+              file=sys.stderr, flush=True)
+        parallel.shutdown()
+        raise SystemExit(1)
     torch.cuda.synchronize()
     dt = parallel.max_over_ranks(time.perf_counter() - t0, device)
     iou_all = parallel.gather_per_image(torch.tensor(ious, dtype=torch.float32, device=device).reshape(len(mine)), len(dataset), rank, world)

@@ -93,8 +93,11 @@ class _SegStandIn(torch.nn.Module):
         return self.conv(image)
 
 
-def test_configs4_joint_steps_on_noisy_pseudo_labels(dev):
-    """BASELINE configs[4] at its full grid size (256x256 noisy pseudo-labels): two epochs over three images, every step = swap
+@pytest.mark.parametrize("fused", [True, False])
+def test_configs4_joint_steps_on_noisy_pseudo_labels(dev, fused):
+    """(fused = True: everything behind the segmentation output is ONE C-ABI call per step, `inrfit_joint_step`; False: the
+    autograd bridges + torch.optim.  Both against the same oracle.)
+    BASELINE configs[4] at its full grid size (256x256 noisy pseudo-labels): two epochs over three images, every step = swap
     the image's prior in, WrapperModule forward, FBMSJointLoss, backward, Adam, enforce_convexity.  HIP vs the oracle (six CPU
     steps at 65 536 points): losses, the shared segmentation weights and every image's prior parameters."""
     from awesome_amd.agent import JointTrainer
@@ -126,7 +129,8 @@ def test_configs4_joint_steps_on_noisy_pseudo_labels(dev):
     init_states = [dict(s) for s in factory_states[:n]]
     crit = FBMSJointLoss(alpha=alpha, beta=beta)              # default criterion: UnariesWeightedLoss(BCELoss, 'sssdms')
     opt = torch.optim.Adam(list(seg.parameters()) + list(wrapper.prior_module._ordered_params()), lr=lr)
-    trainer = JointTrainer(wrapper, bank, crit, opt)
+    trainer = JointTrainer(wrapper, bank, crit, opt, fused=fused)
+    assert trainer.fused == fused
     order = [0, 1, 2, 0, 1, 2]
     feat = torch.zeros(1, 1, 1, 1, device=dev)
     losses = []
@@ -223,3 +227,179 @@ def test_configs3_full_size_xyt_loss_and_gradients(dev):
     for k, v in got.items():
         ref = sdo[k].grad.numpy()
         np.testing.assert_allclose(v.numpy().reshape(ref.shape), ref, rtol=5e-3, atol=5e-5 * float(np.abs(ref).max()) + 1e-9, err_msg=k)
+
+
+def _joint_setup(dev, prior_factory, S=48, n=2, seed=5):
+    from awesome_amd.dataset import SyntheticPriorDataset
+    from awesome_amd.model import WrapperModule
+    from awesome_amd.prior_bank import PriorBank
+    torch.manual_seed(seed)
+    ds = SyntheticPriorDataset(n_images=n, size=S, kind="noisy_blob")
+    items = [ds[i] for i in range(n)]
+    seg = _SegStandIn()
+    wrapper = WrapperModule(seg, prior_factory(), use_segmentation_output_inversion=True).to(dev)
+    bank = PriorBank(lambda: prior_factory().to(dev), n_images=n, device=dev)
+    for k in range(n):
+        bank.row(k)
+    return items, seg, wrapper, bank
+
+
+def _run_joint(dev, prior_factory, crit_factory, fused, steps, lr=2e-3, opt_type=torch.optim.Adam, perturb=None):
+    """`steps` joint steps from identical starting points; returns (losses, seg weights, bank rows)."""
+    from awesome_amd.agent import JointTrainer
+    items, seg, wrapper, bank = _joint_setup(dev, prior_factory)
+    if perturb is not None:
+        perturb(wrapper.prior_module, bank)
+    crit = crit_factory()
+    from awesome_amd.prior_bank import _ordered_parameters
+    opt = opt_type(list(seg.parameters()) + list(_ordered_parameters(wrapper.prior_module)), lr=lr)
+    trainer = JointTrainer(wrapper, bank, crit, opt, fused=fused)
+    assert trainer.fused == fused
+    feat = torch.zeros(1, 1, 1, 1, device=dev)
+    losses, outs = [], []
+    for s in range(steps):
+        i = s % len(items)
+        (image, _, xy), target = items[i]
+        loss, out = trainer.perform_step(i, (image[None].to(dev), feat, xy[None].to(dev)), target[None].to(dev))
+        losses.append(float(loss))
+        outs.append(out.cpu())
+    return losses, seg.conv.weight.detach().cpu().clone(), bank.params.detach().cpu().clone(), outs, trainer
+
+
+def _nonzero_last_layers(model, bank):
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(3)
+        for i in range(len(bank)):
+            with bank.manager(model, i):
+                for name, p in model.named_parameters():
+                    if ".net.2." in name or "out_linear" in name or "linear2" in name:
+                        p.add_((0.05 * torch.randn(p.shape, generator=g)).to(p.device))
+        for b_name, b in model.named_buffers():
+            if b_name.endswith("data_dep_init_done"):
+                b.fill_(1.0)
+
+
+@pytest.mark.parametrize("family", ["pcn", "cdn"])
+def test_fused_joint_step_with_path_connected_priors(dev, family):
+    """inrfit_pcn_joint_step / inrfit_cdn_joint_step (one C-ABI call per step: deformation forward, ICNN step kernel with the
+    coordinate gradient, the composite loss with the clip on the device, both update kernels with the detached clip factor) against
+    the autograd step (WrapperModule forward -> fused FBMSJointLoss -> HIP backward bridges -> torch.optim.Adam -> enforce_convexity)
+    from the same start: losses, outputs, the segmentation weights and every prior row.  (The autograd step itself is pinned on the
+    oracle in test_prior_bank_with_path_connected_prior_joint_step / test_configs4...)"""
+    from awesome_amd.measures import FBMSJointLoss
+    from awesome_amd.model import ConvexDiffeomorphismNet, real_nvp_path_connected_net
+    if family == "pcn":
+        factory = lambda: real_nvp_path_connected_net(channels=2, hidden_units=16, flow_n_flows=4, flow_output_fn="tanh",   # noqa: E731
+                                                      convex_net_hidden_units=64, convex_net_hidden_layers=2)
+    else:
+        factory = lambda: ConvexDiffeomorphismNet(n_hidden=64, n_hidden_layers=2, nf_layers=4, nf_hidden=24,                # noqa: E731
+                                                  diffeo_args=dict(backbone="normal_block"))
+    for beta in (2.0, 400.0):   # without and with the penalty clip
+        crit = lambda: FBMSJointLoss(alpha=1.0, beta=beta)   # noqa: E731
+        lf, wf, rf, of, tf = _run_joint(dev, factory, crit, True, 4, perturb=_nonzero_last_layers)
+        la, wa, ra, oa, _ = _run_joint(dev, factory, crit, False, 4, perturb=_nonzero_last_layers)
+        assert int(tf.last_status[0]) == 0
+        np.testing.assert_allclose(lf, la, rtol=2e-5)
+        for a, b in zip(of, oa):
+            np.testing.assert_allclose(a.numpy(), b.numpy(), atol=2e-5)
+        np.testing.assert_allclose(wf.numpy(), wa.numpy(), rtol=2e-4, atol=2e-6)
+        # Adam's first steps move every parameter by ~lr whatever the gradient's size: compare on that scale
+        np.testing.assert_allclose(rf.numpy(), ra.numpy(), rtol=1e-3, atol=2e-5)
+        assert not np.allclose(rf.numpy(), _joint_setup(dev, factory)[3].params.cpu().numpy())   # ... and they did move
+
+
+def test_fused_joint_step_awesome_image_loss_and_adamax(dev):
+    """AwesomeImageLoss (before its extra penalty) in the fused joint step, Adam and Adamax, against the autograd step; with the
+    extra penalty on the trainer takes the autograd step by itself (two data terms on the prior have no fused form)."""
+    from awesome_amd.measures import AwesomeImageLoss, SE, UnariesWeightedLoss
+    from awesome_amd.model import ConvexNextNet
+    factory = lambda: ConvexNextNet(n_hidden=64, in_features=2, n_hidden_layers=2)   # noqa: E731
+    for opt_type, crit in ((torch.optim.Adam, lambda: AwesomeImageLoss(alpha=0.7)),
+                           (torch.optim.Adamax, lambda: AwesomeImageLoss(criterion=UnariesWeightedLoss(SE("mean"), mode="sssdms"),
+                                                                         prior_criterion=UnariesWeightedLoss(torch.nn.BCELoss(), mode="equal"),
+                                                                         alpha=1.3))):
+        lf, wf, rf, of, _ = _run_joint(dev, factory, crit, True, 4, opt_type=opt_type)
+        la, wa, ra, oa, _ = _run_joint(dev, factory, crit, False, 4, opt_type=opt_type)
+        np.testing.assert_allclose(lf, la, rtol=2e-5)
+        np.testing.assert_allclose(wf.numpy(), wa.numpy(), rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(rf.numpy(), ra.numpy(), rtol=1e-3, atol=2e-5)
+
+    def with_penalty():
+        c = AwesomeImageLoss(alpha=0.7)
+        c.extra_penalty = True
+        return c
+    from awesome_amd.agent import JointTrainer
+    items, seg, wrapper, bank = _joint_setup(dev, factory)
+    c = with_penalty()
+    tr = JointTrainer(wrapper, bank, c, torch.optim.Adam(list(seg.parameters()) + list(wrapper.prior_module._ordered_params()), lr=1e-3))
+    (image, _, xy), target = items[0]
+    loss, out = tr.perform_step(0, (image[None].to(dev), torch.zeros(1, 1, 1, 1, device=dev), xy[None].to(dev)), target[None].to(dev))
+    assert torch.isfinite(loss) and tr.last_status is None        # the fused call refused (INR_EUNSUPPORTED is never reached: planned out)
+
+
+def test_fused_joint_step_nonfinite_loss_freezes_the_row(dev):
+    """A NaN in the segmentation output: status = 1, the prior row and its optimizer state stay untouched."""
+    import awesome_amd as A
+    from awesome_amd import joint as J
+    from awesome_amd.model import ConvexNextNet
+    torch.manual_seed(0)
+    m = ConvexNextNet(n_hidden=64, in_features=2, n_hidden_layers=1)
+    row = m.flat_parameters().to(dev)
+    keep = row.clone()
+    S = 32
+    grid = A.Grid.linspace(S, S, dev)
+    seg = torch.rand(S * S, device=dev) * 0.9 + 0.05
+    tgt = (torch.rand(S * S, device=dev) > 0.5).float()
+    opt = torch.zeros(2 * m.spec.n_params + 8, device=dev)
+    good = J.joint_step(m.spec, row, opt, grid, seg, tgt, J.joint_desc(), step=1, lr=1e-3)
+    assert int(good.status[0]) == 0 and not torch.equal(row, keep) and torch.isfinite(good.loss).all()
+    row2, opt2 = keep.clone(), torch.zeros_like(opt)
+    seg_bad = seg.clone()
+    seg_bad[7] = float("nan")
+    bad = J.joint_step(m.spec, row2, opt2, grid, seg_bad, tgt, J.joint_desc(), step=1, lr=1e-3)
+    assert int(bad.status[0]) == 1 and torch.equal(row2, keep) and float(opt2[: 2 * m.spec.n_params].abs().sum()) == 0.0
+
+
+def test_awesome_image_and_pixel_losses_on_device(dev, golden_dir):
+    """Row a12: AwesomeImageLoss (with and without extra_penalty) and AwesomeLoss (pixel mode) as forms of inrfit_joint_loss: values
+    against the reference classes' fixtures (losses.npz, pixel_losses.npz), gradients against autograd through the same classes'
+    torch composition on the CPU (which the CPU suite pins on the same fixtures)."""
+    from awesome_amd.measures import AwesomeImageLoss, AwesomeLoss, SE, UnariesWeightedLoss
+    z = np.load(os.path.join(golden_dir, "losses.npz"))
+    out2, tb = torch.from_numpy(z["output2"]), torch.from_numpy(z["target_bin"])
+    for penalty, key in ((False, "ail.plain"), (True, "ail.penalty")):
+        crit = AwesomeImageLoss(alpha=0.7)
+        crit.extra_penalty = penalty
+        assert crit.joint_desc() is not None
+        o_h = out2.to(dev).requires_grad_(True)
+        l_h = crit(o_h, tb.to(dev))
+        l_h.backward()
+        assert float(l_h.detach()) == pytest.approx(float(z[key]), rel=3e-6)
+        o_c = out2.clone().requires_grad_(True)
+        crit(o_c, tb).backward()                                           # CPU tensors: the torch composition
+        np.testing.assert_allclose(o_h.grad.cpu().numpy(), o_c.grad.numpy(), rtol=3e-5, atol=1e-9)
+    torch.manual_seed(11)
+    out_c = torch.rand(3, 2, 17, 13) * 0.96 + 0.02
+    tgt_c = (torch.rand(3, 1, 17, 13) > 0.8).float()
+    for penalty in (False, True):
+        crit = AwesomeImageLoss(criterion=UnariesWeightedLoss(SE("mean"), mode="sssdms"),
+                                prior_criterion=UnariesWeightedLoss(torch.nn.BCELoss(), mode="ratio", ratio=0.5), alpha=1.4, beta=30.0, gamma=0.2)
+        crit.extra_penalty = penalty
+        o_h, o_c = out_c.to(dev).requires_grad_(True), out_c.clone().requires_grad_(True)
+        l_h, l_c = crit(o_h, tgt_c.to(dev)), crit(o_c, tgt_c)
+        l_h.backward()
+        l_c.backward()
+        assert float(l_h.detach()) == pytest.approx(float(l_c.detach()), rel=5e-6)
+        np.testing.assert_allclose(o_h.grad.cpu().numpy(), o_c.grad.numpy(), rtol=5e-5, atol=1e-9)
+    zp = np.load(os.path.join(golden_dir, "pixel_losses.npz"))
+    out, tgt = torch.from_numpy(zp["al.output"]), torch.from_numpy(zp["al.target"])
+    for penalty, key in ((False, "al.plain"), (True, "al.penalty")):
+        crit = AwesomeLoss(alpha=0.6, scribble_percentage=0.75)
+        crit.extra_penalty = penalty
+        assert crit.joint_desc(out.shape[-2]) is not None
+        o_h, o_c = out.to(dev).requires_grad_(True), out.clone().requires_grad_(True)
+        l_h = crit(o_h, tgt.to(dev))
+        l_h.backward()
+        crit(o_c, tgt).backward()
+        assert float(l_h.detach()) == pytest.approx(float(zp[key]), rel=3e-6)
+        np.testing.assert_allclose(o_h.grad.cpu().numpy(), o_c.grad.numpy(), rtol=3e-5, atol=1e-9)

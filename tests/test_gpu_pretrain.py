@@ -278,6 +278,108 @@ def test_pretrain_convex_diffeomorphism_net_warm_start_chain(dev):
         np.testing.assert_allclose(got.numpy(), prev.cpu().numpy(), rtol=2e-5, atol=1e-7, err_msg=f"frame {i}")
 
 
+def test_pretrain_path_connected_net_warm_start_chain_keeps_actnorm(dev):
+    """with reuse_state (the default) frame k starts from frame k-1's fitted state, loaded in the reference with
+    load_state_dict (path_connected_net.py:867-870) - data_dep_init_done = 1 included - so ActNorm is NOT re-initialised from the
+    data and the short refit continues from the previous deformation.  Against the same chain on the HIP API by hand: frame 0 cold
+    (ActNorm init + num_epochs), frames 1.. = previous fit -> reuse_state_epochs, no init; and against the wrong chain (init before
+    every frame), which must differ."""
+    import awesome_amd as A
+    from awesome_amd import rnvp as R
+    from awesome_amd.dataset import convex_blob_unaries
+    from awesome_amd.model import real_nvp_path_connected_net
+    args = dict(channels=2, hidden_units=16, flow_n_flows=4, flow_output_fn="tanh", convex_net_hidden_units=64, convex_net_hidden_layers=1)
+    pre = dict(num_epochs=80, lr=2e-3, reuse_state=True, reuse_state_epochs=25, proper_prior_fit_threshold=0.0)
+    base = (convex_blob_unaries(256, 3).reshape(256, 256)[::8, ::8] > 0.5).float()
+    frames = [torch.roll(base, shifts=(0, 2 * k), dims=(0, 1)) for k in range(3)]
+    torch.manual_seed(17)
+    ds, wrapper, agent = _setup(dev, real_nvp_path_connected_net, args, n=3, size=32)
+    ds._inner.unaries = lambda i: frames[i]
+    state = wrapper.pretrain(train_set=ds, test_set=None, device=dev, agent=agent, use_progress_bar=False, **pre)
+    torch.manual_seed(17)
+    ds2, wrapper2, _ = _setup(dev, real_nvp_path_connected_net, args, n=3, size=32)
+    ds2._inner.unaries = lambda i: frames[i]
+    items = [_item(ds2, i, dev) for i in range(3)]
+    m = wrapper2.prior_module
+    ispec, rspec = m._specs()
+    P = ispec.n_params
+    grid = A.Grid.explicit(ds2._xy.reshape(2, -1).to(dev))
+
+    def chain(reinit: bool):
+        flat = m._engine_pack(items[0][0]).to(dev)[None]
+        ip, fp = flat[:, :P].contiguous(), flat[:, P:].contiguous()
+        out = []
+        for k in range(3):
+            if k == 0 or reinit:
+                R.actnorm_init(rspec, fp, grid)
+            res = R.pcn_fit(ispec, rspec, ip, fp, grid, items[k][1][None], 80 if k == 0 else 25, lr=2e-3, optimizer="adamax",
+                            flow_weight_decay=1e-5, plateau=dict(patience=200, factor=0.5))
+            ip, fp = res.icnn_params.clone(), res.flow_params.clone()
+            out.append(torch.cat([ip[0], fp[0]]).cpu())
+        return out
+
+    good, wrong = chain(False), chain(True)
+    for k in range(3):
+        got = m._engine_pack(state["cache"][str(k)])
+        np.testing.assert_allclose(got.numpy(), good[k].numpy(), rtol=2e-5, atol=1e-7, err_msg=f"frame {k}")
+    assert not np.allclose(good[2].numpy(), wrong[2].numpy(), rtol=1e-3, atol=1e-5)
+    # the ActNorm parameters ENTERING frame 1 are frame 0's fitted ones: after 0 refit epochs they are unchanged
+    torch.manual_seed(17)
+    ds3, wrapper3, agent3 = _setup(dev, real_nvp_path_connected_net, args, n=2, size=32)
+    ds3._inner.unaries = lambda i: frames[i]
+    st3 = wrapper3.pretrain(train_set=ds3, test_set=None, device=dev, agent=agent3, use_progress_bar=False, **dict(pre, reuse_state_epochs=0))
+    for key in st3["cache"]["0"]:
+        if key.endswith(".s") or key.endswith(".t"):
+            assert torch.equal(st3["cache"]["1"][key], st3["cache"]["0"][key]), key
+
+
+def test_flow_priors_freeze_without_a_status_array(dev):
+    """inrfit_cdn_fit / inrfit_pcn_fit called with status == NULL (a direct C-ABI caller) on an image whose loss
+    is non-finite: the ICNN AND its deformation stay at their parameters - the flow updates read the frozen flag the ICNN update
+    wrote into the optimizer header, not `status`."""
+    import ctypes as C
+    from awesome_amd import _lib as L, flow as FL, icnn as K, rnvp as R
+    from awesome_amd.model import ConvexDiffeomorphismNet, real_nvp_path_connected_net
+    import awesome_amd as A
+    lib = L.load()
+    g = A.Grid.linspace(32, 32, dev)
+    un = (torch.rand(1, 32 * 32, device=dev) > 0.5).float()
+    un[0, 5] = float("nan")
+    od = L.InrOptDesc(L.OPT_KINDS["adam"], 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 0, 200, 0.5, 1e-4, 0.0, 1e-8, 0, 0, 0)
+    ld = K._loss_desc("bce", "none", 1.0, 0.0, 0.0)
+    torch.manual_seed(4)
+    cdn = ConvexDiffeomorphismNet(n_hidden=64, n_hidden_layers=1, nf_layers=4, nf_hidden=24, diffeo_args=dict(backbone="normal_block"))
+    ispec, fspec = cdn._specs()
+    flat = cdn._engine_pack(cdn.state_dict()).to(dev)[None]
+    ip, fp = flat[:, :ispec.n_params].contiguous(), flat[:, ispec.n_params:].contiguous()
+    ip0, fp0 = ip.clone(), fp.clone()
+    iopt, fopt = K.new_opt_state(ispec, 1, dev), torch.zeros(1, 2 * fspec.n_params, device=dev)
+    ws = FL._ws(ispec, fspec, g, 1)
+    md, fd, gd = ispec.desc(), fspec.desc(), g.desc()
+    rc = lib.inrfit_cdn_fit(C.byref(md), C.byref(fd), ip.data_ptr(), fp.data_ptr(), iopt.data_ptr(), fopt.data_ptr(), C.byref(gd),
+                            un.data_ptr(), C.byref(ld), C.byref(od), 5e-5, 1, 4, 0, None, None, None, ws.data_ptr(), ws.numel() * 4,
+                            K._stream_ptr(dev))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(ip, ip0) and torch.equal(fp, fp0)
+    pcn = real_nvp_path_connected_net(channels=2, hidden_units=16, flow_n_flows=4, flow_output_fn="tanh", convex_net_hidden_units=64)
+    ispec, rspec = pcn._specs()
+    flat = pcn._engine_pack(pcn.state_dict()).to(dev)[None]
+    ip, fp = flat[:, :ispec.n_params].contiguous(), flat[:, ispec.n_params:].contiguous()
+    R.actnorm_init(rspec, fp, g)
+    ip0, fp0 = ip.clone(), fp.clone()
+    iopt, fopt = K.new_opt_state(ispec, 1, dev), torch.zeros(1, 2 * rspec.n_params, device=dev)
+    ws = R._ws(ispec, rspec, g, 1)
+    md, rd = ispec.desc(), rspec.desc()
+    ld = K._loss_desc("se", "none", 1.0, 0.0, 0.0)
+    rc = lib.inrfit_pcn_fit(C.byref(md), C.byref(rd), ip.data_ptr(), fp.data_ptr(), iopt.data_ptr(), fopt.data_ptr(), C.byref(gd),
+                            un.data_ptr(), C.byref(ld), C.byref(od), 1e-5, 1, 4, 0, None, None, None, ws.data_ptr(), ws.numel() * 4,
+                            K._stream_ptr(dev))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(ip, ip0) and torch.equal(fp, fp0)
+
+
 def test_pretrain_agent_saves_and_reloads_pretrain_state(dev, tmp_path):
     """PretrainAgent._pretrain = TorchAgent._pretrain (:553-627): runs the pretraining once, writes pretrain_state.pth, and a
     second agent pointed at the file loads it instead of fitting."""

@@ -534,3 +534,28 @@ def test_learn_flow_identity_with_zoo(dev, tmp_path):
     assert changed > 0
     h3 = m2.learn_flow_identity(grid, lr=5e-3, max_iter=30, zoo=zoo)      # other hyper-parameters: a miss, fits again
     assert not torch.equal(h3.cpu(), h1.cpu())
+
+
+def test_fast_tanh_exp_error_bounds(dev):
+    """The kernels' own tanh / exp of the coupling outputs (rnvp.h fast_tanh / fast_exp: v_exp_f32 / v_rcp_f32 forms with a
+    compensated argument, an odd polynomial near 0) against float64 on the device that runs them, with EXPLICIT bounds on the
+    RELATIVE error (libm's float32 functions: ~1e-7): tanh <= 5e-7 everywhere incl. tiny arguments (the couplings start at exactly
+    0, so absolute-error forms are not good enough), exp <= 2.5e-7 on [-10, 10] (the log-scales are tanh-bounded)."""
+    import ctypes as C
+    from awesome_amd import _lib as L
+    from awesome_amd import icnn as K
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.linspace(-10, 10, 200001), (torch.rand(100000, generator=g) - 0.5) * 1.3, torch.logspace(-30, 0, 4000),
+                   -torch.logspace(-30, 0, 4000), torch.tensor([0.0, 0.625, -0.625, 0.6249999, 20.0, -20.0, 50.0])]).float()
+    xd = x.to(dev)
+    th, ex = torch.empty_like(xd), torch.empty_like(xd)
+    L.check(L.load().inrfit_debug_tanh_exp(xd.data_ptr(), xd.numel(), th.data_ptr(), ex.data_ptr(), K._stream_ptr(dev)), "debug_tanh_exp")
+    x64 = x.double()
+    t64, e64 = torch.tanh(x64), torch.exp(x64)
+    rel_t = ((th.cpu().double() - t64).abs() / t64.abs().clamp_min(1e-300))[x != 0]
+    assert float(th.cpu()[x == 0].abs().max()) == 0.0
+    assert float(rel_t.max()) <= 5e-7, float(rel_t.max())
+    sel = x.abs() <= 10
+    rel_e = ((ex.cpu().double() - e64).abs() / e64)[sel]
+    assert float(rel_e.max()) <= 2.5e-7, float(rel_e.max())
+    print(f"fast_tanh max rel err {float(rel_t.max()):.3e}, fast_exp max rel err {float(rel_e.max()):.3e}")

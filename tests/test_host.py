@@ -325,3 +325,17 @@ def test_synthetic_prior_dataset_follows_the_dataset_contract():
     ds.return_prior = False
     (image2, _, _), _ = ds[1]
     assert torch.equal(image2, image)
+
+
+def test_unaries_conversion_loss_and_targets():
+    """awesome/measures/unaries_conversion_loss.py:25-27: the criterion on (target >= 0.5); the fused fits get the binarised targets."""
+    from awesome_amd.measures import SE, UnariesConversionLoss, UnariesWeightedLoss, criterion_targets, criterion_to_desc
+    out, tgt = torch.rand(2, 1, 5, 7), torch.rand(2, 1, 5, 7)
+    tgt[0, 0, 0, 0] = 0.5
+    crit = UnariesConversionLoss(SE("mean"))
+    assert float(crit(out, tgt)) == pytest.approx(float(((out - (tgt >= 0.5).float()) ** 2).mean()))
+    assert crit.get_name() == "UCMSE"
+    assert criterion_to_desc(crit) == ("se", "none", 1.0)
+    assert criterion_to_desc(UnariesConversionLoss(UnariesWeightedLoss(torch.nn.BCELoss(), mode="sssdms"))) == ("bce", "sssdms", 1.0)
+    assert torch.equal(criterion_targets(crit, tgt), (tgt >= 0.5).float())
+    assert criterion_targets(SE("mean"), tgt) is tgt
