@@ -18,6 +18,7 @@
 //                           weight_g only, awesome/util/torch.py:19-35), and the new effective weights for the next step
 #pragma once
 #include "icnn_step.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -88,27 +89,99 @@ __device__ __forceinline__ f32x2 step01(f32x2 pre) {
     return r;
 }
 
-// Points per lane.  Measured at one image (256x256, K=6, W=130; one wave per SIMD): forward 22 us / backward 29 us with one
-// point per lane; two points per lane (half the record reads, half the waves) 27 / 36 us; requesting the records one group
-// ahead behind sched_barriers 30 / 29 us (one point) and 29 / 36 us (two) - hipcc's own order of the plain loop wins.
-constexpr int FLOW_PPL = 1;
+// ---- tanh / exp of the coupling outputs ---------------------------------------------------------------------------------------
+// libm's tanhf / expf cost ~35 / ~12 VALU instructions each (denormal / overflow handling, an IEEE division); the coupling needs
+// 2 tanh + 1 exp per point, flow and output channel, a third of the forward's instructions.  The forms below keep
+// libm's accuracy class - RELATIVE error, so tiny outputs of the zero-initialised nets stay exact to rounding - at ~19 / 5:
+//   exp:  e^x = 2^hi (1 + lo ln 2) with x log2(e) = hi + lo split exactly by one fma (v_exp_f32: 1 ulp), |x| <~ 80;
+//         measured max rel. error 1.3e-7 on [-10, 10] (tests/test_gpu_rnvp.py::test_fast_tanh_exp_error_bounds asserts 2.5e-7)
+//   tanh: |x| < 0.625: odd minimax polynomial x + x^3 P(x^2) (the Cephes tanhf coefficients); else 1 - 2 / (e^{2|x|} + 1) with the exp
+//         above and v_rcp_f32 (1 ulp); measured max rel. error 2.4e-7 (asserted: 5e-7; libm: 1.2e-7).
+// A first attempt in round 1 (tanh x = 1 - 2/(1 + e^2x) for ALL x, plain v_exp_f32 of x log2e) had ABSOLUTE error 2e-7, i.e. large
+// relative error near 0 where the couplings start: "3x noisier" gradients.  The relative-error forms do not have that problem
+// (test_accuracy_against_float64 holds with the same x4 bar as libm).
+__device__ __forceinline__ float fast_exp(float x) {
+    constexpr float L2E = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-8f, LN2 = 0.693147182464599609375f;
+    const float hi = x * L2E;
+    const float lo = fmaf(x, L2E_LO, fmaf(x, L2E, -hi));   // x log2(e) - hi
+    const float e = __builtin_amdgcn_exp2f(hi);
+    return fmaf(e * LN2, lo, e);
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float ax = fabsf(x);
+    const float z = x * x;
+    float p = fmaf(-5.70498872745e-3f, z, 2.06390887954e-2f);
+    p = fmaf(p, z, -5.37397155531e-2f);
+    p = fmaf(p, z, 1.33314422036e-1f);
+    p = fmaf(p, z, -3.33332819422e-1f);
+    const float small = fmaf(p * z, x, x);
+    const float e = fast_exp(fminf(2.f * ax, 40.f));        // tanh saturates to 1 long before; keeps 2^hi finite
+    const float big = fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
+    return ax < 0.625f ? small : copysignf(big, x);
+}
+
+// ---- where the effective weights come from, and what bounds the point kernels -----------------------------------------------------------
+// The weights are WAVE-UNIFORM (every lane evaluates the same nets on its own point) and are read from an LDS copy of the image with
+// broadcast ds_read_b128, 2 per hidden unit.  Round 3 took round 2's "VALU-issue bound at 0.6 busy" apart with four experiments
+// (rocprofv3 kernel stats of tools/kbench_{pcn,cdn}.py in profiles/r03_*; the table is in profiles/NOTES.md):
+//   * a fifth fewer VALU instructions (mask-specialised bodies, tanh / exp at ~19 / 5 instructions instead of libm's ~35 / ~12): the
+//     forward kernels did not move (55.7 vs 53.2 us at configs[3], 18.2 vs 18.3 at 256x256): not VALU issue;
+//   * the scalar data path (image read from HBM through a constant-address-space pointer -> s_load_dwordx4/x8 into SGPRs, RecK below;
+//     no LDS traffic at all): 2-3x SLOWER (coupling-flow forward 64 vs 21.5 us): the scalar cache cannot feed the loop;
+//   * Q = 2 / 4 points per lane (a record read serves Q points; 64-thread blocks so the fewer waves still spread over all CUs):
+//     1.1-1.6x SLOWER, with and without the pipelining below: not LDS return bandwidth either;
+//   * software-pipelined unit loops (the next 4 units' records requested before the current 4 are evaluated; hipcc's own order was
+//     "reads -> wait -> arithmetic -> next reads"): RealNVP backward at 256x256 38.1 -> 28.9 us, coupling-flow backward 27.6 -> 25.4,
+//     forward kernels +-1 us, configs[3] (4 waves per SIMD) unchanged.  KEPT.
+// What is left is the size of the problem: one 256x256 image is 1024 waves for 1024 SIMDs - ONE wave per SIMD, 66 clocks per hidden
+// unit for 16 clocks of VALU issue - and a fit step is a chain of such launches.
+typedef const float __attribute__((address_space(4))) kfloat;
+typedef const f32x4 __attribute__((address_space(4))) kf32x4;
+struct RecK {   // image in global memory, scalar loads
+    static constexpr bool SCALAR = true;
+    const kfloat* p;
+    __device__ __forceinline__ f32x4 v4(int off) const { return *(const kf32x4*)(p + off); }
+    __device__ __forceinline__ float f(int off) const { return p[off]; }
+    __device__ __forceinline__ RecK at(int off) const { return RecK{p + off}; }
+};
+struct RecL {   // image in LDS
+    static constexpr bool SCALAR = false;
+    const float* p;
+    __device__ __forceinline__ f32x4 v4(int off) const { return *(const f32x4*)(p + off); }
+    __device__ __forceinline__ float f(int off) const { return p[off]; }
+    __device__ __forceinline__ RecL at(int off) const { return RecL{p + off}; }
+};
+__device__ __forceinline__ RecK rec_global(const float* image) { return RecK{(const kfloat*)image}; }
+
+// Launch shape of the point kernels: points per lane Q and threads per block.  Fixed at Q = 1 and 256 threads: Q = 2 / 4 and
+// 64-thread blocks were measured slower at every size, before AND after the unit loops were software-pipelined (see above and
+// profiles/NOTES.md); the kernels keep Q and blockDim.x general.
+struct FlowShape { int Q, threads, blocks; };
+inline FlowShape flow_launch_shape(long long n_points, int /*n_images*/, int /*cv*/, int /*max_q*/) {
+    FlowShape s;
+    s.Q = 1;
+    s.threads = 256;
+    s.blocks = (int)((n_points + 255) / 256);
+    return s;
+}
 
 // (NB_s(u), NB_t(u)) of one coupling for both nets at once on packed f32 pairs (v_pk_fma_f32: half the VALU
 // instructions of two scalar evaluations); DU adds the derivatives d(pre-tanh)/du: every unit adds (w1 w2') step(pre)
-template <bool DU>
-__device__ __forceinline__ void nb_pair_forward(const float* e, int W, const float (&u)[FLOW_PPL], f32x2 (&st)[FLOW_PPL],
-                                                f32x2 (&dpre_du)[FLOW_PPL]) {
-    const f32x4 tail = *(const f32x4*)(e + 8 * W);
-    f32x2 acc[FLOW_PPL], d[FLOW_PPL];
+template <bool DU, int Q, class Rec>
+__device__ __forceinline__ void nb_pair_forward(const Rec e, int W, const float (&u)[Q], f32x2 (&st)[Q], f32x2 (&dpre_du)[Q]) {
+    const f32x4 tail = e.v4(8 * W);
+    f32x2 acc[Q], d[Q];
 #pragma unroll
-    for (int q = 0; q < FLOW_PPL; ++q) {
+    for (int q = 0; q < Q; ++q) {
         acc[q] = pk_fma(f32x2{tail[2], tail[3]}, splat2(u[q]), f32x2{tail[0], tail[1]});
         d[q] = f32x2{tail[2], tail[3]};
     }
     auto unit = [&](const f32x4& lo, const f32x4& hi) {   // lo = (w1s, w1t, b1s, b1t), hi = (w2's, w2't, w1s w2's, w1t w2't)
 #pragma unroll
-        for (int q = 0; q < FLOW_PPL; ++q) {
-            const f32x2 pre = pk_fma(f32x2{lo[0], lo[1]}, splat2(u[q]), f32x2{lo[2], lo[3]});
+        for (int q = 0; q < Q; ++q) {
+            f32x2 pre;
+            if constexpr (Rec::SCALAR) pre = f32x2{lo[0], lo[1]} * splat2(u[q]) + f32x2{lo[2], lo[3]};   // one SGPR pair per instruction
+            else pre = pk_fma(f32x2{lo[0], lo[1]}, splat2(u[q]), f32x2{lo[2], lo[3]});
             if (DU) {
                 const f32x2 sp = step01(pre);
                 acc[q] = pk_fma(f32x2{hi[0], hi[1]}, pre * sp, acc[q]);
@@ -118,20 +191,37 @@ __device__ __forceinline__ void nb_pair_forward(const float* e, int W, const flo
             }
         }
     };
-    int j = 0;
-    for (; j + 4 <= W; j += 4) {
-        f32x4 r[8];
+    // Software-pipelined over batches of 4 units (two register sets, ping-pong): the records of the NEXT batch are requested before the
+    // current batch is evaluated.  hipcc's own order for the plain loop was "6 reads -> wait -> 16 VALU -> the next 6 reads": with one
+    // wave per SIMD (a 256x256 image = 1024 waves) nothing covers the LDS latency of every batch - 66 clocks per unit for 16 clocks of
+    // VALU issue (round 3, flow.h header).  Reads past the last unit stay inside the LDS allocation (the launch adds slack) and are unused.
+    auto load4 = [&](f32x4 (&r)[8], int j0) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) r[k] = *(const f32x4*)(e + 8 * j + 4 * k);
+        for (int k = 0; k < 8; ++k) r[k] = e.v4(8 * j0 + 4 * k);
+    };
+    auto eval4 = [&](const f32x4 (&r)[8]) {
         unit(r[0], r[1]);
         unit(r[2], r[3]);
         unit(r[4], r[5]);
         unit(r[6], r[7]);
+    };
+    int j = 0;
+    if (W >= 8) {
+        f32x4 ra[8], rb[8];
+        load4(ra, 0);
+        for (; j + 8 <= W; j += 8) {
+            load4(rb, j + 4);
+            __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the arithmetic
+            eval4(ra);
+            load4(ra, j + 8);
+            __builtin_amdgcn_sched_barrier(0);
+            eval4(rb);
+        }
     }
-    for (; j < W; ++j) unit(*(const f32x4*)(e + 8 * j), *(const f32x4*)(e + 8 * j + 4));
+    for (; j < W; ++j) unit(e.v4(8 * j), e.v4(8 * j + 4));
 #pragma unroll
-    for (int q = 0; q < FLOW_PPL; ++q) {
-        st[q] = f32x2{tanhf(acc[q][0]), tanhf(acc[q][1])};
+    for (int q = 0; q < Q; ++q) {
+        st[q] = f32x2{fast_tanh(acc[q][0]), fast_tanh(acc[q][1])};
         dpre_du[q] = d[q];
     }
 }
@@ -144,39 +234,40 @@ struct FlowFwdArgs {
     FlowMap m;
 };
 
-// grid: x = blocks of 256 * FLOW_PPL points (lane t of the block owns points base + q * 256 + t), y = image
+// grid: x = blocks of blockDim.x * Q points (lane t of the block owns points base + q * blockDim.x + t), y = image
+template <int Q>
 __global__ __launch_bounds__(256) void flow_fwd_kernel(const FlowFwdArgs a) {
     const int img = blockIdx.y;
-    const int N = (int)a.N;
+    const int N = (int)a.N, BS = blockDim.x;
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     flow_weights_to_lds(a.FE + (size_t)img * a.m.FE, fsm, a.m.FE);
-    const float* e = fsm;
-    int p[FLOW_PPL];
-    float x1[FLOW_PPL], x2[FLOW_PPL];
+    const RecL e{fsm};
+    int p[Q];
+    float x1[Q], x2[Q];
 #pragma unroll
-    for (int q = 0; q < FLOW_PPL; ++q) {
-        p[q] = (blockIdx.x * FLOW_PPL + q) * 256 + threadIdx.x;
+    for (int q = 0; q < Q; ++q) {
+        p[q] = (blockIdx.x * Q + q) * BS + threadIdx.x;
         float xin[2];
         load_coords2(a.grid, img, a.N, p[q] < N ? p[q] : N - 1, xin);
-        x1[q] = fmaf(e[0], xin[0], fmaf(e[1], xin[1], e[4]));
-        x2[q] = fmaf(e[2], xin[0], fmaf(e[3], xin[1], e[5]));
+        x1[q] = fmaf(e.f(0), xin[0], fmaf(e.f(1), xin[1], e.f(4)));
+        x2[q] = fmaf(e.f(2), xin[0], fmaf(e.f(3), xin[1], e.f(5)));
     }
     for (int i = 0; i < a.m.K; ++i) {
-        float u[FLOW_PPL];
-        f32x2 st[FLOW_PPL], dd[FLOW_PPL];
+        float u[Q];
+        f32x2 st[Q], dd[Q];
 #pragma unroll
-        for (int q = 0; q < FLOW_PPL; ++q) u[q] = (i & 1) ? x2[q] : x1[q];
-        nb_pair_forward<false>(e + a.m.e_nb + i * a.m.e_cp_stride, a.m.W, u, st, dd);
-        const float sc = e[a.m.e_scale + i];
+        for (int q = 0; q < Q; ++q) u[q] = (i & 1) ? x2[q] : x1[q];
+        nb_pair_forward<false, Q>(e.at(a.m.e_nb + i * a.m.e_cp_stride), a.m.W, u, st, dd);
+        const float sc = e.f(a.m.e_scale + i);
 #pragma unroll
-        for (int q = 0; q < FLOW_PPL; ++q) {
-            const float ex = expf(sc * st[q][0]);
+        for (int q = 0; q < Q; ++q) {
+            const float ex = fast_exp(sc * st[q][0]);
             if (i & 1) x1[q] = fmaf(ex, x1[q], st[q][1]);
             else x2[q] = fmaf(ex, x2[q], st[q][1]);
         }
     }
 #pragma unroll
-    for (int q = 0; q < FLOW_PPL; ++q)
+    for (int q = 0; q < Q; ++q)
         if (p[q] < N) {
             a.xd[((size_t)img * 2) * N + p[q]] = x1[q];
             a.xd[((size_t)img * 2 + 1) * N + p[q]] = x2[q];
@@ -195,14 +286,13 @@ struct FlowBwdArgs {
     int S1;             // K (dscale) + 2K (db2 s,t) + 6 (dA, db)
 };
 
-template <int K>
+template <int K, int Q>
 __global__ __launch_bounds__(256) void flow_bwd_points_kernel(const FlowBwdArgs a) {
-    constexpr int Q = FLOW_PPL;
     const int img = blockIdx.y;
-    const int N = (int)a.N, W = a.m.W;
+    const int N = (int)a.N, W = a.m.W, BS = blockDim.x;
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     flow_weights_to_lds(a.FE + (size_t)img * a.m.FE, fsm, a.m.FE);
-    const float* e = fsm;
+    const RecL e{fsm};
     int p[Q];
     bool valid[Q];
     float xin[Q][2];
@@ -211,11 +301,11 @@ __global__ __launch_bounds__(256) void flow_bwd_points_kernel(const FlowBwdArgs 
     float x1[Q], x2[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        p[q] = (blockIdx.x * Q + q) * 256 + threadIdx.x;
+        p[q] = (blockIdx.x * Q + q) * BS + threadIdx.x;
         valid[q] = p[q] < N;
         load_coords2(a.grid, img, a.N, valid[q] ? p[q] : N - 1, xin[q]);
-        x1[q] = fmaf(e[0], xin[q][0], fmaf(e[1], xin[q][1], e[4]));
-        x2[q] = fmaf(e[2], xin[q][0], fmaf(e[3], xin[q][1], e[5]));
+        x1[q] = fmaf(e.f(0), xin[q][0], fmaf(e.f(1), xin[q][1], e.f(4)));
+        x2[q] = fmaf(e.f(2), xin[q][0], fmaf(e.f(3), xin[q][1], e.f(5)));
     }
 #pragma unroll
     for (int i = 0; i < K; ++i) {
@@ -227,15 +317,15 @@ __global__ __launch_bounds__(256) void flow_bwd_points_kernel(const FlowBwdArgs 
             x2s[i][q] = x2[q];
             u[q] = (i & 1) ? x2[q] : x1[q];
         }
-        nb_pair_forward<true>(e + a.m.e_nb + i * a.m.e_cp_stride, W, u, st, dd);
-        const float sc = e[a.m.e_scale + i];
+        nb_pair_forward<true, Q>(e.at(a.m.e_nb + i * a.m.e_cp_stride), W, u, st, dd);
+        const float sc = e.f(a.m.e_scale + i);
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             sv[i][q] = st[q][0];
             tv[i][q] = st[q][1];
             dsu[i][q] = dd[q][0];
             dtu[i][q] = dd[q][1];
-            ev[i][q] = expf(sc * sv[i][q]);
+            ev[i][q] = fast_exp(sc * sv[i][q]);
             if (i & 1) x1[q] = fmaf(ev[i][q], x1[q], tv[i][q]);
             else x2[q] = fmaf(ev[i][q], x2[q], tv[i][q]);
         }
@@ -255,7 +345,7 @@ __global__ __launch_bounds__(256) void flow_bwd_points_kernel(const FlowBwdArgs 
             const float tpre = odd ? x1s[i][q] : x2s[i][q];
             const float dpost = odd ? d1 : d2;
             const float de = dpost * tpre;                // d/d exp(s)
-            const float sc = e[a.m.e_scale + i];
+            const float sc = e.f(a.m.e_scale + i);
             const float dse = de * ev[i][q];              // d/d (scale * s_raw)
             acc[i] += dse * sv[i][q];                     // d/d scale_i
             const float gqs = dse * sc * (1.f - sv[i][q] * sv[i][q]);   // d/d pre-tanh of the s net
@@ -297,7 +387,9 @@ __global__ __launch_bounds__(256) void flow_bwd_points_kernel(const FlowBwdArgs 
     __syncthreads();
     if (threadIdx.x < 3 * K + 6) {
         const int k = threadIdx.x;
-        a.slab1[((size_t)img * gridDim.x + blockIdx.x) * a.S1 + k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+        float v = red[0][k];
+        for (int w2 = 1; w2 < (BS >> 6); ++w2) v += red[w2][k];   // fixed order
+        a.slab1[((size_t)img * gridDim.x + blockIdx.x) * a.S1 + k] = v;
     }
 }
 

@@ -889,7 +889,8 @@ namespace {
 struct CdnWs {
     Workspace icnn;       // ICNN workspace (explicit grid = deformed coordinates)
     float *xd, *dxd, *FE, *ps, *slab1, *slab2;
-    int blocks1, chunks, Wp, S1;
+    int blocks1, chunks, Wp, S1;   // blocks1 = blocks of the backward point kernel (rows of slab1)
+    FlowShape sf, sb;              // launch shapes of the forward / backward point kernels (flow.h: flow_launch_shape)
     FlowMap fm;
     long long bytes;
     InrGridDesc dgrid;    // the deformed grid handed to the ICNN kernels
@@ -906,7 +907,9 @@ CdnWs carve_cdn(const KernelEntry* e, const InrFlowDesc* f, const InrGridDesc* g
     CdnWs w;
     const long long N = grid->n_points;
     w.fm = make_flow_map(f->width, f->num_coupling, f->backbone == INR_FLOW_SIMPLE ? 0.f : LEAKY_SLOPE);
-    w.blocks1 = (int)((N + 256 * FLOW_PPL - 1) / (256 * FLOW_PPL));
+    w.sf = flow_launch_shape(N, n_images, 20, 4);
+    w.sb = flow_launch_shape(N, n_images, 40, 2);
+    w.blocks1 = w.sb.blocks;
     w.Wp = (f->width + 63) / 64 * 64;
     w.chunks = 64;   // x 2K nets x 4 waves: enough waves for 1024 SIMDs at one image
     while (w.chunks > 1 && N / w.chunks < 256) w.chunks /= 2;
@@ -971,7 +974,22 @@ void launch_flow_fwd(const CdnWs& w, const InrGridDesc* grid, int n_images, floa
     a.grid = *grid;
     a.N = grid->n_points;
     a.m = w.fm;
-    hipLaunchKernelGGL(flow_fwd_kernel, dim3(w.blocks1, n_images), dim3(256), w.fm.FE * sizeof(float), s, a);
+    const dim3 g(w.sf.blocks, n_images), b(w.sf.threads);
+    const size_t lds = (w.fm.FE + 64) * sizeof(float);   // + slack: the pipelined unit loop reads one batch ahead
+    hipLaunchKernelGGL(flow_fwd_kernel<1>, g, b, lds, s, a);   // (Q > 1: measured slower, flow.h)
+}
+
+void launch_flow_bwd_points(const CdnWs& w, int K, int n_images, const FlowBwdArgs& a, hipStream_t s) {
+    const dim3 g1(w.sb.blocks, n_images), b1(w.sb.threads);
+    const size_t lds = (w.fm.FE + 64) * sizeof(float);
+#define INR_FLOW_BWD(KK) hipLaunchKernelGGL((flow_bwd_points_kernel<KK, 1>), g1, b1, lds, s, a)
+    switch (K) {
+        case 2: INR_FLOW_BWD(2); break;
+        case 4: INR_FLOW_BWD(4); break;
+        case 6: INR_FLOW_BWD(6); break;
+        default: INR_FLOW_BWD(8); break;
+    }
+#undef INR_FLOW_BWD
 }
 
 void launch_flow_bwd(const CdnWs& w, const InrFlowDesc* f, const InrGridDesc* grid, int n_images, hipStream_t s) {
@@ -984,13 +1002,7 @@ void launch_flow_bwd(const CdnWs& w, const InrFlowDesc* f, const InrGridDesc* gr
     a.N = grid->n_points;
     a.m = w.fm;
     a.S1 = w.S1;
-    const dim3 g1(w.blocks1, n_images), b1(256);
-    switch (f->num_coupling) {
-        case 2: hipLaunchKernelGGL(flow_bwd_points_kernel<2>, g1, b1, w.fm.FE * sizeof(float), s, a); break;
-        case 4: hipLaunchKernelGGL(flow_bwd_points_kernel<4>, g1, b1, w.fm.FE * sizeof(float), s, a); break;
-        case 6: hipLaunchKernelGGL(flow_bwd_points_kernel<6>, g1, b1, w.fm.FE * sizeof(float), s, a); break;
-        default: hipLaunchKernelGGL(flow_bwd_points_kernel<8>, g1, b1, w.fm.FE * sizeof(float), s, a); break;
-    }
+    launch_flow_bwd_points(w, f->num_coupling, n_images, a, s);
     FlowUnitsArgs ua{};
     ua.FE = w.FE;
     ua.ps = w.ps;
@@ -1173,7 +1185,8 @@ struct PcnWs {
     Workspace icnn;
     float *xd, *dxd, *zs, *ps, *slab1, *slab2, *RE, *lossp;
     int blocksL;
-    int blocks1, chunks, S1, Q;   // Q = points per lane of the point kernels
+    int blocks1, chunks, S1;      // blocks1 = blocks of the backward point kernel (rows of slab1)
+    FlowShape sf, sb;             // launch shapes of the forward / backward point kernels (flow.h: flow_launch_shape)
     RnvpMap rm;
     long long bytes;
     InrGridDesc dgrid;
@@ -1221,9 +1234,9 @@ PcnWs carve_pcn(const KernelEntry* e, const InrRnvpDesc* r, const InrGridDesc* g
     const long long N = grid->n_points;
     w.rm = make_rnvp_map(r);
     const int C = w.rm.C, F = w.rm.F;
-    w.Q = 1;   // one point per lane: two (half the record reads per point) measured slower even at 262144 points - 73 vs 70 us
-               // forward, 155 vs 137 us backward; the loops are VALU-bound, not LDS-bound - and are no longer instantiated
-    w.blocks1 = (int)((N + 256 * w.Q - 1) / (256 * w.Q));
+    w.sf = flow_launch_shape(N, n_images, 20, 4);
+    w.sb = flow_launch_shape(N, n_images, 40, 2);
+    w.blocks1 = w.sb.blocks;
     w.chunks = 64;   // x F flows x 4 waves: enough waves for the 1024 SIMDs
     while (w.chunks > 1 && N / w.chunks < 1024) w.chunks /= 2;
     w.S1 = F * 4 * C + 2 * C;
@@ -1318,13 +1331,10 @@ void launch_rnvp_fwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, i
     a.grid = *grid;
     a.N = grid->n_points;
     a.m = w.rm;
-    const dim3 g(w.blocks1, n_images);
-    const size_t lds = (size_t)w.rm.LDSF * sizeof(float);
-    if (w.rm.C == 2) {
-        hipLaunchKernelGGL((rnvp_fwd_kernel<2, 1>), g, dim3(256), lds, s, a);
-    } else {
-        hipLaunchKernelGGL((rnvp_fwd_kernel<3, 1>), g, dim3(256), lds, s, a);
-    }
+    const dim3 g(w.sf.blocks, n_images), b(w.sf.threads);
+    const size_t lds = (size_t)(w.rm.LDSF + 64) * sizeof(float);   // + slack: the pipelined unit loop reads one batch ahead
+    if (w.rm.C == 2) hipLaunchKernelGGL((rnvp_fwd_kernel<2, 1>), g, b, lds, s, a);   // (Q > 1: measured slower, flow.h)
+    else hipLaunchKernelGGL((rnvp_fwd_kernel<3, 1>), g, b, lds, s, a);
 }
 
 void launch_rnvp_bwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, int n_images, hipStream_t s) {
@@ -1338,13 +1348,10 @@ void launch_rnvp_bwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, i
     a.N = grid->n_points;
     a.m = w.rm;
     a.S1 = w.S1;
-    const dim3 g1(w.blocks1, n_images);
+    const dim3 g1(w.sb.blocks, n_images), b1(w.sb.threads);
     const size_t lds = (size_t)(w.rm.LDSF + 4 * w.S1) * sizeof(float);
-    if (w.rm.C == 2) {
-        hipLaunchKernelGGL((rnvp_bwd_points_kernel<2, 1>), g1, dim3(256), lds, s, a);
-    } else {
-        hipLaunchKernelGGL((rnvp_bwd_points_kernel<3, 1>), g1, dim3(256), lds, s, a);
-    }
+    if (w.rm.C == 2) hipLaunchKernelGGL((rnvp_bwd_points_kernel<2, 1>), g1, b1, lds, s, a);
+    else hipLaunchKernelGGL((rnvp_bwd_points_kernel<3, 1>), g1, b1, lds, s, a);
     RnvpUnitsArgs ua{};
     ua.RP = rp;
     ua.zs = w.zs;
@@ -1434,7 +1441,7 @@ int inrfit_rnvp_actnorm_init(const InrRnvpDesc* rnvp, float* flow_params, const 
     a.grid = *grid;
     a.N = grid->n_points;
     a.m = w.rm;
-    const size_t lds = (size_t)(RNVP_HDR + w.rm.fl) * sizeof(float);
+    const size_t lds = (size_t)(RNVP_HDR + w.rm.fl + 64) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     const long long N = grid->n_points;
     if (N >= 16384) {
@@ -1494,7 +1501,7 @@ int inrfit_rnvp_inverse(const InrRnvpDesc* rnvp, const float* flow_params, const
     a.in_image_stride = in_image_stride;
     a.m = w.rm;
     const dim3 gr((unsigned)((n_points + 255) / 256), n_images);
-    const size_t lds = (size_t)w.rm.LDSF * sizeof(float);
+    const size_t lds = (size_t)(w.rm.LDSF + 64) * sizeof(float);   // + slack: the pipelined unit loop reads one batch ahead
     if (w.rm.C == 2) hipLaunchKernelGGL(rnvp_inverse_kernel<2>, gr, dim3(256), lds, s, a);
     else hipLaunchKernelGGL(rnvp_inverse_kernel<3>, gr, dim3(256), lds, s, a);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;

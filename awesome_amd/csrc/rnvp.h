@@ -30,7 +30,7 @@ namespace {
 
 constexpr int RNVP_MAX_FLOWS = 32;
 constexpr int RNVP_REC = 8;     // LDS floats per hidden unit: (W1s,W1t)[NIN] (b1s,b1t) (W2s,W2t)[NOUT], 2(C+1) <= 8
-constexpr int RNVP_TAIL = 12;   // per flow: (b2s,b2t)[2] | exp(as)[3] | at[3] | pad
+constexpr int RNVP_TAIL = 16;   // per flow: (b2s,b2t)[2] | exp(as)[3] | at[3] | pad (records stay 32-byte aligned)
 constexpr int RNVP_HDR = 16;    // a[3] | b[3] | pad
 
 struct RnvpMap {
@@ -68,36 +68,7 @@ __host__ __device__ inline FlowIdx flow_idx(unsigned mask) {
     return x;
 }
 
-// ---- tanh / exp of the coupling outputs ---------------------------------------------------------------------------------------
-// libm's tanhf / expf cost ~35 / ~12 VALU instructions each (denormal / overflow handling, an IEEE division); the coupling needs
-// 2 tanh + 1 exp per point, flow and output channel, a third of the forward's instructions.  The forms below keep
-// libm's accuracy class - RELATIVE error, so tiny outputs of the zero-initialised nets stay exact to rounding - at ~19 / 5:
-//   exp:  e^x = 2^hi (1 + lo ln 2) with x log2(e) = hi + lo split exactly by one fma (v_exp_f32: 1 ulp), |x| <~ 80;
-//         measured max rel. error 1.3e-7 on [-10, 10] (tests/test_gpu_rnvp.py::test_fast_tanh_exp_error_bounds asserts 2.5e-7)
-//   tanh: |x| < 0.625: odd minimax polynomial x + x^3 P(x^2) (the Cephes tanhf coefficients); else 1 - 2 / (e^{2|x|} + 1) with the exp
-//         above and v_rcp_f32 (1 ulp); measured max rel. error 2.4e-7 (asserted: 5e-7; libm: 1.2e-7).
-// A first attempt in round 1 (tanh x = 1 - 2/(1 + e^2x) for ALL x, plain v_exp_f32 of x log2e) had ABSOLUTE error 2e-7, i.e. large
-// relative error near 0 where the couplings start: "3x noisier" gradients.  The relative-error forms do not have that problem
-// (test_accuracy_against_float64 holds with the same x4 bar as libm).
-__device__ __forceinline__ float fast_exp(float x) {
-    constexpr float L2E = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-8f, LN2 = 0.693147182464599609375f;
-    const float hi = x * L2E;
-    const float lo = fmaf(x, L2E_LO, fmaf(x, L2E, -hi));   // x log2(e) - hi
-    const float e = __builtin_amdgcn_exp2f(hi);
-    return fmaf(e * LN2, lo, e);
-}
-__device__ __forceinline__ float fast_tanh(float x) {
-    const float ax = fabsf(x);
-    const float z = x * x;
-    float p = fmaf(-5.70498872745e-3f, z, 2.06390887954e-2f);
-    p = fmaf(p, z, -5.37397155531e-2f);
-    p = fmaf(p, z, 1.33314422036e-1f);
-    p = fmaf(p, z, -3.33332819422e-1f);
-    const float small = fmaf(p * z, x, x);
-    const float e = fast_exp(fminf(2.f * ax, 40.f));        // tanh saturates to 1 long before; keeps 2^hi finite
-    const float big = fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
-    return ax < 0.625f ? small : copysignf(big, x);
-}
+// (fast_tanh / fast_exp: flow.h)
 // coupling log-scale: tanh-bounded -> fast_exp; unbounded (output_fn none) -> libm
 template <bool BOUNDED>
 __device__ __forceinline__ float coupling_exp(float s) {
@@ -206,12 +177,23 @@ __global__ __launch_bounds__(256) void rnvp_pack_kernel(const RnvpPackArgs a) {
     rnvp_flow_image<C>(rp, dst + RNVP_HDR + f * a.m.fl, a.m, f);
 }
 
+// ---- where the flow records come from ----------------------------------------------------------------------------------------------
+// The records (weights of the two MLPs of a flow) are WAVE-UNIFORM: every lane of a point kernel needs the same 8 floats per hidden
+// unit.  Read from LDS that is one ds_read_b128 pair per unit and wave, and the LDS return path (128 B per clock and CU) delivers
+// 64 lanes x 16 B = 8 clocks per read whatever the address pattern: 64 reads per flow x 8 clocks x 16 waves per CU put the LDS pipe at
+// 100 % - rounds 1-2 called these kernels "VALU-issue bound" at 0.62 VALU busy; they were LDS-return bound (the arithmetic gives
+// 61 us for configs[3]'s forward, measured 53).  Uniform data belongs on the SCALAR data path: the packed image in HBM is read through
+// a constant-address-space pointer with uniform addresses, which hipcc selects as s_load_dwordx4/x8 into SGPRs (scalar cache, no LDS,
+// no VGPRs); VALU instructions take one SGPR pair as an operand directly.  (One SGPR pair per instruction: pre = w1 z + b1 is issued
+// as v_pk_mul + v_pk_add instead of v_mov x2 + v_pk_fma.)  The one-flow init / unit-gradient kernels keep their small LDS image.
+// (RecK / RecL: flow.h)
+
 // pre-activation outputs o[q][k] = (o_s, o_t) of the two MLPs of one flow for the NOUT active output channels of Q points
 // per lane (a record read from LDS serves all Q); DU: also J[q][k][m] = d o[k] / d zin[m] (packed for both nets).
-template <int NIN, int NOUT, bool DU, int Q>
-__device__ __forceinline__ void rnvp_nets(const float* rec, int HID, const float (&zin)[Q][NIN], f32x2 (&o)[Q][NOUT],
+template <int NIN, int NOUT, bool DU, int Q, class Rec>
+__device__ __forceinline__ void rnvp_nets(const Rec rec, int HID, const float (&zin)[Q][NIN], f32x2 (&o)[Q][NOUT],
                                           f32x2 (&J)[Q][NOUT][NIN]) {
-    const f32x4 tl = *(const f32x4*)(rec + HID * RNVP_REC);
+    const f32x4 tl = rec.v4(HID * RNVP_REC);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         o[q][0] = f32x2{tl[0], tl[1]};
@@ -221,15 +203,21 @@ __device__ __forceinline__ void rnvp_nets(const float* rec, int HID, const float
 #pragma unroll
             for (int mm = 0; mm < NIN; ++mm) J[q][k][mm] = f32x2{0.f, 0.f};
     }
-#pragma unroll 4
-    for (int j = 0; j < HID; ++j) {
-        const f32x4 r0 = *(const f32x4*)(rec + RNVP_REC * j), r1 = *(const f32x4*)(rec + RNVP_REC * j + 4);
+    auto unit = [&](const f32x4& r0, const f32x4& r1) {
         const float v[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            f32x2 pre = f32x2{v[2 * NIN], v[2 * NIN + 1]};
+            f32x2 pre;
+            if constexpr (Rec::SCALAR) {   // one SGPR pair per instruction: mul, (fma,) add
+                pre = f32x2{v[0], v[1]} * splat2(zin[q][0]);
 #pragma unroll
-            for (int mm = 0; mm < NIN; ++mm) pre = pk_fma(f32x2{v[2 * mm], v[2 * mm + 1]}, splat2(zin[q][mm]), pre);
+                for (int mm = 1; mm < NIN; ++mm) pre = pk_fma(f32x2{v[2 * mm], v[2 * mm + 1]}, splat2(zin[q][mm]), pre);
+                pre = pre + f32x2{v[2 * NIN], v[2 * NIN + 1]};
+            } else {
+                pre = f32x2{v[2 * NIN], v[2 * NIN + 1]};
+#pragma unroll
+                for (int mm = 0; mm < NIN; ++mm) pre = pk_fma(f32x2{v[2 * mm], v[2 * mm + 1]}, splat2(zin[q][mm]), pre);
+            }
             if (DU) {
                 const f32x2 st = step01(pre);
                 const f32x2 h = pre * st;
@@ -249,12 +237,38 @@ __device__ __forceinline__ void rnvp_nets(const float* rec, int HID, const float
                 for (int k = 0; k < NOUT; ++k) o[q][k] = pk_fma(f32x2{v[2 * (NIN + 1 + k)], v[2 * (NIN + 1 + k) + 1]}, h, o[q][k]);
             }
         }
+    };
+    // software-pipelined over batches of 4 units, two register sets (see flow.h nb_pair_forward: the next batch's records are
+    // requested before the current batch is evaluated; reads past the last unit stay inside the allocation and are unused)
+    auto load4 = [&](f32x4 (&r)[8], int j0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = rec.v4(RNVP_REC * j0 + 4 * k);
+    };
+    auto eval4 = [&](const f32x4 (&r)[8]) {
+        unit(r[0], r[1]);
+        unit(r[2], r[3]);
+        unit(r[4], r[5]);
+        unit(r[6], r[7]);
+    };
+    int j = 0;
+    if (HID >= 8) {
+        f32x4 ra[8], rb[8];
+        load4(ra, 0);
+        for (; j + 8 <= HID; j += 8) {
+            load4(rb, j + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            eval4(ra);
+            load4(ra, j + 8);
+            __builtin_amdgcn_sched_barrier(0);
+            eval4(rb);
+        }
     }
+    for (; j < HID; ++j) unit(rec.v4(RNVP_REC * j), rec.v4(RNVP_REC * j + 4));
 }
 
 // one flow on z (MaskedAffineFlow, then ActNorm unless !ACTNORM), channel roles fixed at compile time
-template <int C, unsigned MASK, bool ACTNORM, bool TANH, int Q>
-__device__ __forceinline__ void rnvp_flow_forward_m(const float* rec, const RnvpMap& m, float (&z)[Q][C]) {
+template <int C, unsigned MASK, bool ACTNORM, bool TANH, int Q, class Rec>
+__device__ __forceinline__ void rnvp_flow_forward_m(const Rec rec, const RnvpMap& m, float (&z)[Q][C]) {
     using M = MaskT<C, MASK>;
     constexpr int NIN = M::NIN, NOUT = M::NOUT;
     float zin[Q][NIN];
@@ -265,7 +279,7 @@ __device__ __forceinline__ void rnvp_flow_forward_m(const float* rec, const Rnvp
         if constexpr (NIN > 1) zin[q][NIN - 1] = z[q][M::in1];
     }
     rnvp_nets<NIN, NOUT, false, Q>(rec, m.HID, zin, o, J);
-    const float* tl = rec + m.HID * RNVP_REC;
+    const Rec tl = rec.at(m.HID * RNVP_REC);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
 #pragma unroll
@@ -282,14 +296,14 @@ __device__ __forceinline__ void rnvp_flow_forward_m(const float* rec, const Rnvp
         }
         if (ACTNORM) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) z[q][c] = fmaf(z[q][c], tl[4 + c], tl[7 + c]);
+            for (int c = 0; c < C; ++c) z[q][c] = fmaf(z[q][c], tl.f(4 + c), tl.f(7 + c));
         }
     }
 }
 
 // run-time mask (wave-uniform) and output function -> the specialised body
-template <int C, bool ACTNORM, int Q>
-__device__ __forceinline__ void rnvp_flow_forward(const float* rec, const RnvpMap& m, unsigned mask, float (&z)[Q][C]) {
+template <int C, bool ACTNORM, int Q, class Rec>
+__device__ __forceinline__ void rnvp_flow_forward(const Rec rec, const RnvpMap& m, unsigned mask, float (&z)[Q][C]) {
     with_mask<C>(mask, [&](auto mk) {
         constexpr unsigned MASK = decltype(mk)::value;
         if (m.out_fn) rnvp_flow_forward_m<C, MASK, ACTNORM, true, Q>(rec, m, z);
@@ -328,15 +342,17 @@ __global__ __launch_bounds__(256) void rnvp_fwd_kernel(const RnvpFwdArgs a) {
     const int N = (int)a.N;
     extern __shared__ __attribute__((aligned(16))) float rsm[];
     flow_weights_to_lds(a.RE + (size_t)img * a.m.LDSF, rsm, a.m.LDSF);
+    const RecL img_rec{rsm};   // (flow.h: why LDS and why Q points per lane)
+    const int BS = blockDim.x;
     int p[Q];
     float z[Q][C];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        p[q] = (blockIdx.x * Q + q) * 256 + threadIdx.x;
+        p[q] = (blockIdx.x * Q + q) * BS + threadIdx.x;
         float x[C];
         load_coords<C>(a.grid, img, a.N, p[q] < N ? p[q] : N - 1, x);
 #pragma unroll
-        for (int c = 0; c < C; ++c) z[q][c] = minmax_fwd(fmaf(rsm[c], x[c], rsm[3 + c]), a.m.vmin[c], a.m.vmax[c], a.m.nmin, a.m.nmax);
+        for (int c = 0; c < C; ++c) z[q][c] = minmax_fwd(fmaf(img_rec.f(c), x[c], img_rec.f(3 + c)), a.m.vmin[c], a.m.vmax[c], a.m.nmin, a.m.nmax);
     }
     for (int f = 0; f < a.m.F; ++f) {
         if (a.zs != nullptr) {
@@ -347,7 +363,7 @@ __global__ __launch_bounds__(256) void rnvp_fwd_kernel(const RnvpFwdArgs a) {
                     for (int c = 0; c < C; ++c) a.zs[(((size_t)img * a.m.F + f) * C + c) * N + p[q]] = z[q][c];
                 }
         }
-        rnvp_flow_forward<C, true, Q>(rsm + RNVP_HDR + f * a.m.fl, a.m, a.m.masks[f], z);
+        rnvp_flow_forward<C, true, Q>(img_rec.at(RNVP_HDR + f * a.m.fl), a.m, a.m.masks[f], z);
     }
 #pragma unroll
     for (int q = 0; q < Q; ++q)
@@ -377,16 +393,17 @@ __global__ __launch_bounds__(256) void rnvp_inverse_kernel(const RnvpInvArgs a) 
     const int N = (int)a.N;
     extern __shared__ __attribute__((aligned(16))) float rsm[];
     flow_weights_to_lds(a.RE + (size_t)img * a.m.LDSF, rsm, a.m.LDSF);
+    const RecL img_rec{rsm};
     const int pc = p < N ? p : N - 1;
     float z[1][C];
 #pragma unroll
     for (int c = 0; c < C; ++c)
         z[0][c] = minmax_fwd(a.in[(size_t)img * a.in_image_stride + (size_t)c * N + pc], a.m.vmin[c], a.m.vmax[c], a.m.nmin, a.m.nmax);
     for (int f = a.m.F - 1; f >= 0; --f) {
-        const float* rec = rsm + RNVP_HDR + f * a.m.fl;
-        const float* tl = rec + a.m.HID * RNVP_REC;
+        const RecL rec = img_rec.at(RNVP_HDR + f * a.m.fl);
+        const RecL tl = rec.at(a.m.HID * RNVP_REC);
 #pragma unroll
-        for (int c = 0; c < C; ++c) z[0][c] = (z[0][c] - tl[7 + c]) / tl[4 + c];   // ActNorm^-1
+        for (int c = 0; c < C; ++c) z[0][c] = (z[0][c] - tl.f(7 + c)) / tl.f(4 + c);   // ActNorm^-1
         with_mask<C>(a.m.masks[f], [&](auto mk) {
             using M = MaskT<C, decltype(mk)::value>;
             constexpr int NIN = M::NIN, NOUT = M::NOUT;
@@ -413,7 +430,7 @@ __global__ __launch_bounds__(256) void rnvp_inverse_kernel(const RnvpInvArgs a) 
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float v = minmax_fwd(z[0][c], a.m.nmin, a.m.nmax, a.m.vmin[c], a.m.vmax[c]);
-            a.out[((size_t)img * C + c) * N + p] = (1.f / rsm[c]) * (v - rsm[3 + c]);   // inverse_1b1_linear (:87-104)
+            a.out[((size_t)img * C + c) * N + p] = (1.f / img_rec.f(c)) * (v - img_rec.f(3 + c));   // inverse_1b1_linear (:87-104)
         }
     }
 }
@@ -435,7 +452,7 @@ struct RnvpBwdArgs {
 // flow's ActNorm); out: g = d loss / d (state in front of the flow), per-lane partial sums of the per-point-scalar gradients in
 // acc (db2s [C] | db2t [C] | das [C] | dat [C]), and per point the gradients at the MLP outputs in ps (do_s [NOUT] | do_t [NOUT]).
 template <int C, unsigned MASK, bool TANH, int Q>
-__device__ __forceinline__ void rnvp_flow_backward_m(const RnvpBwdArgs& a, const float* rec, const float* tl, int img, int f, int N,
+__device__ __forceinline__ void rnvp_flow_backward_m(const RnvpBwdArgs& a, const RecL rec, const RecL tl, int img, int f, int N,
                                                      const int (&p)[Q], const int (&pc)[Q], const bool (&valid)[Q], float (&g)[Q][C],
                                                      float (&acc)[4 * C]) {
     using M = MaskT<C, MASK>;
@@ -475,7 +492,7 @@ __device__ __forceinline__ void rnvp_flow_backward_m(const RnvpBwdArgs& a, const
         float gz[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const float ea = tl[4 + c];
+            const float ea = tl.f(4 + c);
             acc[2 * C + c] += g[q][c] * zc[c] * ea;
             acc[3 * C + c] += g[q][c];
             gz[c] = g[q][c] * ea;
@@ -516,15 +533,17 @@ __global__ __launch_bounds__(256) void rnvp_bwd_points_kernel(const RnvpBwdArgs 
     const int N = (int)a.N, F = a.m.F;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     extern __shared__ __attribute__((aligned(16))) float rsm[];
-    float* red = rsm + a.m.LDSF;   // [4][S1]
+    float* red = rsm + a.m.LDSF;   // [waves][S1]
     flow_weights_to_lds(a.RE + (size_t)img * a.m.LDSF, rsm, a.m.LDSF);
+    const RecL img_rec{rsm};
+    const int BS = blockDim.x;
     int p[Q], pc[Q];
     bool valid[Q];
     // gradient at the flow output: through MinMax.inverse_transform
     float g[Q][C];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        p[q] = (blockIdx.x * Q + q) * 256 + threadIdx.x;
+        p[q] = (blockIdx.x * Q + q) * BS + threadIdx.x;
         valid[q] = p[q] < N;
         pc[q] = valid[q] ? p[q] : N - 1;
 #pragma unroll
@@ -534,8 +553,8 @@ __global__ __launch_bounds__(256) void rnvp_bwd_points_kernel(const RnvpBwdArgs 
         }
     }
     for (int f = F - 1; f >= 0; --f) {
-        const float* rec = rsm + RNVP_HDR + f * a.m.fl;
-        const float* tl = rec + a.m.HID * RNVP_REC;
+        const RecL rec = img_rec.at(RNVP_HDR + f * a.m.fl);
+        const RecL tl = rec.at(a.m.HID * RNVP_REC);
         float acc[4 * C];   // db2s[C] | db2t[C] | das[C] | dat[C]
 #pragma unroll
         for (int k = 0; k < 4 * C; ++k) acc[k] = 0.f;
@@ -575,8 +594,11 @@ __global__ __launch_bounds__(256) void rnvp_bwd_points_kernel(const RnvpBwdArgs 
         }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < a.S1; k += 256)
-        a.slab1[((size_t)img * gridDim.x + blockIdx.x) * a.S1 + k] = ((red[k] + red[a.S1 + k]) + red[2 * a.S1 + k]) + red[3 * a.S1 + k];
+    for (int k = threadIdx.x; k < a.S1; k += BS) {
+        float v = red[k];
+        for (int w2 = 1; w2 < (BS >> 6); ++w2) v += red[w2 * a.S1 + k];   // fixed order
+        a.slab1[((size_t)img * gridDim.x + blockIdx.x) * a.S1 + k] = v;
+    }
 }
 
 // ---- backward, lane = hidden unit -----------------------------------------------------------------------------------------
@@ -967,7 +989,7 @@ __global__ __launch_bounds__(1024) void rnvp_actnorm_init_kernel(const RnvpInitA
             float z[1][C];
 #pragma unroll
             for (int c = 0; c < C; ++c) z[0][c] = zb[(size_t)c * N + p];
-            rnvp_flow_forward<C, false, 1>(rsm + RNVP_HDR, a.m, mask, z);
+            rnvp_flow_forward<C, false, 1>(RecL{rsm + RNVP_HDR}, a.m, mask, z);
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 zb[(size_t)c * N + p] = z[0][c];
@@ -1095,7 +1117,7 @@ __global__ __launch_bounds__(256) void rnvp_init_couple_kernel(const RnvpInitPar
 #pragma unroll
             for (int c = 0; c < C; ++c) z[0][c] = fmaf(zb[(size_t)c * N + p], sc[c], sh[c]);
         }
-        rnvp_flow_forward<C, false, 1>(rsm + RNVP_HDR, a.b.m, mask, z);
+        rnvp_flow_forward<C, false, 1>(RecL{rsm + RNVP_HDR}, a.b.m, mask, z);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             zb[(size_t)c * N + p] = z[0][c];

@@ -197,9 +197,10 @@ def test_configs2_batch_of_64_matches_single_fits_and_reference(amd, golden_dir)
       top of that full-batch Adam at lr 2e-3 produces loss spikes (within the last 200 steps the loss moves by a factor 1.14 in
       the median image, up to 2.5), and a fit that happens to end inside a spike has a visibly worse mask: measured over these 64
       images between two summation orders, |dIoU| has median 1e-4 and a tail up to 1.8e-2 (image 43), whichever order is
-      taken as the base.  So the bars are: identical early trajectory; per-image fg-IoU within 1e-3 in the median and 5e-2 at
-      worst; and the DATASET mIoU - the number the reference reports and north_star bounds by +-1e-3 - within 1e-3 (measured:
-      0.99849 vs 0.99816).
+      taken as the base.  So the bars HERE (HIP against HIP, two summation orders) are: identical early trajectory; per-image
+      fg-IoU within 1e-3 in the median and 2.5e-2 at worst; and the DATASET mIoU - the number the reference reports and north_star
+      bounds by +-1e-3 - within 1e-3 (measured: 0.99849 vs 0.99816).  The bars against the REFERENCE (its own 16 fits of these images,
+      run twice; per-image bar = its own run-to-run floor x 2) are in tests/test_gpu_scale_parity.py.
     * Image 0 against the reference classes' own fit of the same problem (golden fit_blob256_reference.npz)."""
     import os
     seeds = tuple(range(64))
@@ -211,13 +212,13 @@ def test_configs2_batch_of_64_matches_single_fits_and_reference(amd, golden_dir)
     z = np.load(os.path.join(golden_dir, "fit_blob256_reference.npz"))
     np.testing.assert_allclose(res.loss_hist[0, :100].cpu().numpy(), z["losses"][:100], rtol=5e-4)
     assert abs(float(res.loss_hist[0, -1]) - float(z["losses"][-1])) <= 0.1 * float(z["losses"][-1])
-    assert abs(float(iou[0]) - float(z["final_miou"])) <= 5e-2
+    assert abs(float(iou[0]) - float(z["final_miou"])) <= 5e-3
     iou_single = []
     for k in range(64):
         single = amd.fit(spec, init[k:k + 1].clone(), grid, un[k:k + 1], E, lr=2e-3, record_loss=True, want_logits=True)
         m1, i1 = _mask_iou(amd, single, un[k:k + 1])
         iou_single.append(float(i1[0]))
-        assert abs(float(i1[0]) - float(iou[k])) <= 5e-2, (k, float(i1[0]), float(iou[k]))
+        assert abs(float(i1[0]) - float(iou[k])) <= 2.5e-2, (k, float(i1[0]), float(iou[k]))
         np.testing.assert_allclose(single.loss_hist[0, :50].cpu().numpy(), res.loss_hist[k, :50].cpu().numpy(), rtol=2e-4)
     assert abs(float(np.mean(iou_single)) - float(iou.mean())) <= 1e-3, (float(np.mean(iou_single)), float(iou.mean()))
     assert float(np.median(np.abs(np.asarray(iou_single) - iou.cpu().numpy()))) <= 1e-3
