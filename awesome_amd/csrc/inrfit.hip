@@ -44,7 +44,10 @@ struct UpdArgs {
     float* loss_out;      // mode 1: [n_images]
     int32_t* status;      // [n_images] or null
     InrOptDesc opt;
-    int P, PS, wgs, n_images;   // PS: slab stride in floats; the slab's column layout is img.sl_* (icnn_step.h, Cfg: gradient slab)
+    int P, PS, wgs, n_images;   // P: parameters of the KERNEL's shape (slab column P = the loss); PS: slab stride in floats; the slab's
+                                // column layout is img.sl_* (icnn_step.h, Cfg: gradient slab)
+    int Pu, hu;                 // the CALLER's model: parameter count and n_hidden (hu == img.H: same shape; hu < img.H: the model runs
+                                // zero-padded on the next compiled width, user_param_index below)
     int t;                // 1-based optimizer step index
     double bc1;           // 1 - beta1^t
     float bc2_sqrt;       // sqrt(1 - beta2^t)
@@ -56,6 +59,46 @@ struct UpdArgs {
     int input_hi;                    // opt.freeze_input: flat range [0, input_hi) = input.weight | input.bias is never updated
     const float* gscale;             // [n_images] factor on the reduced gradient (device; the joint step's detached clip factor), or null
 };
+
+// A model whose n_hidden has no compiled kernel runs ZERO-PADDED on the next compiled width H (SURVEY 7 hard part 3): the padded
+// hidden units have W_in = b_in = 0 rows, zero rows AND columns in every hidden layer and w_o = 0, so their activations, their relu
+// masks (pre-activation 0 is "off") and every gradient that touches them are exactly 0 - the fit of the h real units is the same
+// arithmetic with zeros added to the sums.  Nothing padded is ever stored: parameters, optimizer state and gradients keep the CALLER's
+// flat layout (include/inrfit.h, with h), and the two kernels that touch it translate indices.
+// Kernel-shape flat index j (layout with H = m.H) -> caller's flat index (layout with h), or -1 for a padded entry.
+__host__ __device__ __forceinline__ int user_param_index(const ImgMap& m, int h, int j) {
+    const int H = m.H, C = m.C;
+    if (h == H) return j;
+    if (j < m.p_bin) {                       // input.weight [H][C]
+        const int i = j / C;
+        return i < h ? j : -1;
+    }
+    if (j < m.p_w[0]) {                      // input.bias [H]
+        const int i = j - m.p_bin;
+        return i < h ? h * C + i : -1;
+    }
+    int base_u = h * C + h;                  // caller's offset of skip.0.ln.weight
+    const int per_u = h * h + h + h * C;
+    for (int k = 0; k < m.L; ++k, base_u += per_u) {
+        if (j < m.p_b[k]) {                  // skip.k.ln.weight [H][H]
+            const int q = j - m.p_w[k], o = q / H, i = q - o * H;
+            return (o < h && i < h) ? base_u + o * h + i : -1;
+        }
+        if (j < m.p_s[k]) {                  // skip.k.ln.bias [H]
+            const int o = j - m.p_b[k];
+            return o < h ? base_u + h * h + o : -1;
+        }
+        if (j < m.p_s[k] + H * C) {          // skip.k.skp.weight [H][C]
+            const int q = j - m.p_s[k], o = q / C;
+            return o < h ? base_u + h * h + h + q : -1;
+        }
+    }
+    if (j < m.p_bo) {                        // out.ln.weight [H]
+        const int i = j - m.p_wo;
+        return i < h ? base_u + i : -1;
+    }
+    return base_u + h + (j - m.p_bo);        // out.ln.bias, out.skp.weight [C]
+}
 
 constexpr int UPD_MAX_PARAMS = 256;  // most parameters per block
 constexpr int UPD_GROUPS = 16;       // slab groups summed in parallel, then combined in fixed order
@@ -91,20 +134,21 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
     __shared__ float redl[UPD_GROUPS];     // this step's loss partials (every block sums them: see `frozen` below)
     UPD_STAMP(0);
     const int jl = grp * blockDim.x + tx;  // the first ppb threads finish one slab column = one parameter each
-    const int j = jl < ppb ? slab_param_of_col(u.img, blockIdx.x * ppb + jl) : -1;   // flat parameter index, P = loss, -1 = none
+    const int j = jl < ppb ? slab_param_of_col(u.img, blockIdx.x * ppb + jl) : -1;   // flat parameter index (kernel shape), P = loss, -1 = none
+    const int ju = (j >= 0 && j < u.P) ? user_param_index(u.img, u.hu, j) : -1;       // ... in the caller's layout; -1: padding (gradient exactly 0)
     // The kernel is one dependent chain (slabs -> LDS -> optimizer -> stores) and at one image it is latency, not bandwidth,
     // that it pays for: everything the tail needs is requested up front, and all slab rows of a thread are in flight at once.
-    float* __restrict__ st = u.opt_state + (size_t)img * (2 * (size_t)u.P + INR_OPT_HEADER_FLOATS);
-    float* __restrict__ hdr = st + 2 * (size_t)u.P;
+    float* __restrict__ st = u.opt_state + (size_t)img * (2 * (size_t)u.Pu + INR_OPT_HEADER_FLOATS);
+    float* __restrict__ hdr = st + 2 * (size_t)u.Pu;
     float p_old = 0.f, m_old = 0.f, v_old = 0.f, lr_now = 0.f;
     bool bad_before = false;
     if (u.mode == 0 && j >= 0) {
         bad_before = hdr[6 + (u.t & 1)] != 0.f;   // written by the PREVIOUS step's launch (double buffer like the lr: no race)
         lr_now = hdr[u.t & 1];
-        if (j < u.P) {
-            p_old = u.params[(size_t)img * u.P + j];
-            m_old = st[j];
-            v_old = st[u.P + j];
+        if (ju >= 0) {
+            p_old = u.params[(size_t)img * u.Pu + ju];
+            m_old = st[ju];
+            v_old = st[u.Pu + ju];
         }
     }
     {
@@ -148,8 +192,8 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
 
     UPD_STAMP(2);
     if (u.mode == 1) {
-        if (j < u.P) u.grads_out[(size_t)img * u.P + j] = gsum;
-        else u.loss_out[img] = gsum;
+        if (ju >= 0) u.grads_out[(size_t)img * u.Pu + ju] = gsum;
+        else if (j == u.P) u.loss_out[img] = gsum;
         return;
     }
     // A non-finite loss freezes the image: no parameter, optimizer state or schedule changes at this step or any later one of
@@ -190,7 +234,7 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
         hdr[5] = loss;
         return;
     }
-    if (frozen || !isfinite(gsum)) return;
+    if (frozen || !isfinite(gsum) || ju < 0) return;
     if (u.opt.freeze_skips) {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -225,7 +269,7 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
         for (int k = 0; k < 3; ++k) in = in || (j >= u.clamp_lo[k] && j < u.clamp_hi[k]);
         if (in) p = fmaxf(p, 0.f);
     }
-    u.params[(size_t)img * u.P + j] = p;
+    u.params[(size_t)img * u.Pu + ju] = p;
     {
         int slot[2];
         const int ns = image_slots(u.img, j, slot);
@@ -233,8 +277,8 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
         wi[slot[0]] = p;
         if (ns > 1) wi[slot[1]] = p;
     }
-    st[j] = m;
-    st[u.P + j] = v;
+    st[ju] = m;
+    st[u.Pu + ju] = v;
     UPD_STAMP(3);
 }
 
@@ -256,11 +300,13 @@ __global__ __launch_bounds__(256) void pack_image_kernel(float* __restrict__ wim
 }
 
 __global__ __launch_bounds__(256) void pack_params_kernel(const float* __restrict__ params, float* __restrict__ wimg,
-                                                          const ImgMap m) {
+                                                          const ImgMap m, int hu, int Pu) {
     const int img = blockIdx.y;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m.P) return;
-    const float v = params[(size_t)img * m.P + j];
+    const int ju = user_param_index(m, hu, j);
+    if (ju < 0) return;   // padded entry: stays 0 (pack_image_kernel's background)
+    const float v = params[(size_t)img * Pu + ju];
     int slot[2];
     const int ns = image_slots(m, j, slot);
     float* __restrict__ wi = wimg + (size_t)img * m.floats;
@@ -431,11 +477,13 @@ const KernelEntry kEntries[] = {
     make_entry<32, 3>(),   make_entry2<130, 2>(), make_entry2<130, 3>(), make_entry2<64, 2>(), make_entry2<64, 3>(),
 };
 
+// the kernel a model runs on: its own shape if compiled, else the smallest compiled width above it (zero-padded, user_param_index)
 const KernelEntry* find_entry(const InrModelDesc* m) {
-    if (!m || m->kind != INR_MODEL_ICNN) return nullptr;
+    if (!m || m->kind != INR_MODEL_ICNN || m->n_hidden < 1) return nullptr;
+    const KernelEntry* best = nullptr;
     for (const auto& e : kEntries)
-        if (e.h == m->n_hidden && e.c == m->in_features && e.l == m->n_layers) return &e;
-    return nullptr;
+        if (e.c == m->in_features && e.l == m->n_layers && e.h >= m->n_hidden && (!best || e.h < best->h)) best = &e;
+    return best;
 }
 
 // Workgroups (= gradient slabs) per launch.  The chunk -> workgroup map fixes the order in which the points' gradient
@@ -500,6 +548,12 @@ struct Workspace {
     void set_step(int it) { slabs = slabs0 + (size_t)(it % INR_SLAB_BUFFERS) * slab_floats; }
     int act0 = INR_ACT_RELU;     // layer-0 activation of the model this workspace was prepared for
     float act_omega = 0.f;
+    int hu = 0, Pu = 0;          // the caller's n_hidden and parameter count (set_user; hu < e->h: zero-padded on the kernel's width)
+    void set_user(const KernelEntry* e, const InrModelDesc* m) {
+        hu = m ? m->n_hidden : e->h;
+        const long long h = hu, c = e->c, l = e->l;
+        Pu = (int)(h * c + h + l * (h * h + h + h * c) + h + 1 + c);
+    }
 };
 
 Workspace carve(const KernelEntry* e, long long n_points, int n_images, void* base) {
@@ -599,7 +653,7 @@ int64_t inrfit_workspace_bytes(const InrModelDesc* model, const InrGridDesc* gri
 
 static int launch_pack(const KernelEntry* e, const Workspace& w, const float* params, int n_images, hipStream_t s) {
     hipLaunchKernelGGL(pack_image_kernel, dim3((e->img.floats + 255) / 256, n_images), dim3(256), 0, s, w.wimg, e->img);
-    hipLaunchKernelGGL(pack_params_kernel, dim3((e->P + 255) / 256, n_images), dim3(256), 0, s, params, w.wimg, e->img);
+    hipLaunchKernelGGL(pack_params_kernel, dim3((e->P + 255) / 256, n_images), dim3(256), 0, s, params, w.wimg, e->img, w.hu, w.Pu);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 
@@ -668,6 +722,8 @@ static UpdArgs make_upd_args(const KernelEntry* e, const Workspace& w, float* pa
     u.status = status;
     u.opt = *opt;
     u.P = e->P;
+    u.Pu = w.Pu;
+    u.hu = w.hu;
     u.PS = w.PS;
     u.wgs = w.wgs;
     u.n_images = n_images;
@@ -702,6 +758,7 @@ static int prepare(const InrModelDesc* model, const InrGridDesc* grid, int n_ima
     int rc = check_grid(grid, e, n_images);
     if (rc) return rc;
     *w_out = carve(e, grid->n_points, n_images, workspace);
+    w_out->set_user(e, model);
     if (workspace_bytes < w_out->bytes) return INR_EWORKSPACE;
     if (model->act0 < INR_ACT_RELU || model->act0 > INR_ACT_SIN) return INR_EINVAL;
     w_out->act0 = model->act0;
@@ -718,6 +775,8 @@ static void launch_reduce(const KernelEntry* e, const Workspace& w, int n_images
     u.grads_out = grads;
     u.loss_out = loss_out;
     u.P = e->P;
+    u.Pu = w.Pu;
+    u.hu = w.hu;
     u.PS = w.PS;
     u.wgs = w.wgs;
     u.n_images = n_images;
@@ -845,7 +904,7 @@ int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const
     if ((rc = prepare(model, grid, n_images, workspace, workspace_bytes, &e, &w))) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(loss_coef_kernel, dim3(n_images), dim3(256), 0, s, targets, (long long)grid->n_points, *loss, w.coef);
-    hipLaunchKernelGGL(opt_init_kernel, dim3(n_images), dim3(64), 0, s, opt_state, e->P, *opt, step0);
+    hipLaunchKernelGGL(opt_init_kernel, dim3(n_images), dim3(64), 0, s, opt_state, w.Pu, *opt, step0);
     if (status) {
         if (hipMemsetAsync(status, 0, sizeof(int32_t) * n_images, s) != hipSuccess) return INR_ELAUNCH;
     }
@@ -1039,6 +1098,7 @@ int check_cdn(const InrModelDesc* model, const InrFlowDesc* flow, const InrGridD
     }
     *w_out = carve_cdn(e, flow, grid, n_images, workspace);
     if (workspace_bytes < w_out->bytes) return INR_EWORKSPACE;
+    if (e) w_out->icnn.set_user(e, model);
     if (e) {
         const int rc = set_lds(e);
         if (rc) return rc;
@@ -1144,13 +1204,13 @@ int inrfit_cdn_fit(const InrModelDesc* model, const InrFlowDesc* flow, float* ic
     if ((rc = check_cdn(model, flow, grid, n_images, workspace, workspace_bytes, true, &e, &w))) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(loss_coef_kernel, dim3(n_images), dim3(256), 0, s, targets, (long long)grid->n_points, *loss, w.icnn.coef);
-    hipLaunchKernelGGL(opt_init_kernel, dim3(n_images), dim3(64), 0, s, icnn_opt_state, e->P, *opt, step0);
+    hipLaunchKernelGGL(opt_init_kernel, dim3(n_images), dim3(64), 0, s, icnn_opt_state, w.icnn.Pu, *opt, step0);
     if (status && hipMemsetAsync(status, 0, sizeof(int32_t) * n_images, s) != hipSuccess) return INR_ELAUNCH;
     if ((rc = launch_pack(e, w.icnn, icnn_params, n_images, s))) return rc;
     launch_flow_update(w, flow, n_images, 2, flow_params, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0, s);  // effective weights
     UpdArgs u = make_upd_args(e, w.icnn, icnn_params, icnn_opt_state, loss_hist, status, opt, n_images, steps);
     const dim3 ugrid = upd_grid(e->img.sl_cols, n_images), ublock = upd_block(e->img.sl_cols);
-    const long long hdr_stride = 2 * (long long)e->P + INR_OPT_HEADER_FLOATS;
+    const long long hdr_stride = 2 * (long long)w.icnn.Pu + INR_OPT_HEADER_FLOATS;
     const bool gate_logits = final_logits && opt->logits_at_last_forward && steps > 0;   // see inrfit_fit
     for (int it = 0; it < steps; ++it) {
         w.icnn.set_step(step0 + it);
@@ -1166,7 +1226,7 @@ int inrfit_cdn_fit(const InrModelDesc* model, const InrFlowDesc* flow, float* ic
         launch_flow_bwd(w, flow, grid, n_images, s);
         // the learning rate of THIS step sits in header[t & 1] (the plateau thread wrote the next one into the other slot)
         launch_flow_update(w, flow, n_images, 0, flow_params, flow_opt_state, nullptr, opt, wd_on_weight_g, u.t,
-                           icnn_opt_state + 2 * (size_t)e->P, hdr_stride, s, status);
+                           icnn_opt_state + 2 * (size_t)w.icnn.Pu, hdr_stride, s, status);
     }
     if (hipGetLastError() != hipSuccess) return INR_ELAUNCH;
     if (final_logits && !gate_logits) {
@@ -1301,6 +1361,7 @@ int check_pcn(const InrModelDesc* model, const InrRnvpDesc* r, const InrGridDesc
     *w_out = carve_pcn(e, r, grid, n_images, workspace);
     if (workspace_bytes < w_out->bytes) return INR_EWORKSPACE;
     if (const int rc = rnvp_set_lds()) return rc;   // flow records of wide MLPs exceed the default 64 KB of dynamic LDS
+    if (e) w_out->icnn.set_user(e, model);
     if (e) {
         const int rc = set_lds(e);
         if (rc) return rc;
@@ -1597,12 +1658,12 @@ int inrfit_pcn_fit(const InrModelDesc* model, const InrRnvpDesc* rnvp, float* ic
     if ((rc = check_pcn(model, rnvp, grid, n_images, workspace, workspace_bytes, true, &e, &w))) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(loss_coef_kernel, dim3(n_images), dim3(256), 0, s, targets, (long long)grid->n_points, *loss, w.icnn.coef);
-    hipLaunchKernelGGL(opt_init_kernel, dim3(n_images), dim3(64), 0, s, icnn_opt_state, e->P, *opt, step0);
+    hipLaunchKernelGGL(opt_init_kernel, dim3(n_images), dim3(64), 0, s, icnn_opt_state, w.icnn.Pu, *opt, step0);
     if (status && hipMemsetAsync(status, 0, sizeof(int32_t) * n_images, s) != hipSuccess) return INR_ELAUNCH;
     if ((rc = launch_pack(e, w.icnn, icnn_params, n_images, s))) return rc;
     UpdArgs u = make_upd_args(e, w.icnn, icnn_params, icnn_opt_state, loss_hist, status, opt, n_images, steps);
     const dim3 ugrid = upd_grid(e->img.sl_cols, n_images), ublock = upd_block(e->img.sl_cols);
-    const long long hdr_stride = 2 * (long long)e->P + INR_OPT_HEADER_FLOATS;
+    const long long hdr_stride = 2 * (long long)w.icnn.Pu + INR_OPT_HEADER_FLOATS;
     const bool gate_logits = final_logits && opt->logits_at_last_forward && steps > 0;   // see inrfit_fit
     for (int it = 0; it < steps; ++it) {
         w.icnn.set_step(step0 + it);
@@ -1618,7 +1679,7 @@ int inrfit_pcn_fit(const InrModelDesc* model, const InrRnvpDesc* rnvp, float* ic
         launch_rnvp_bwd(w, flow_params, grid, n_images, s);
         // the learning rate of THIS step sits in header[t & 1] (the plateau thread wrote the next one into the other slot)
         RnvpUpdArgs ru = make_rnvp_upd_args(w, n_images, 0, flow_params, flow_opt_state, nullptr, opt, flow_weight_decay, u.t,
-                                            icnn_opt_state + 2 * (size_t)e->P, hdr_stride, status);
+                                            icnn_opt_state + 2 * (size_t)w.icnn.Pu, hdr_stride, status);
         ru.RE = w.RE;
         launch_rnvp_update_args(w, n_images, ru, s);
     }
@@ -1848,7 +1909,7 @@ int inrfit_joint_step(const InrModelDesc* model, float* params, float* opt_state
     float* jws = (float*)((char*)workspace + align256(w.bytes));
     float* logits = prior_logits ? prior_logits : (float*)((char*)jws + align256(inrfit_joint_loss_workspace_bytes(N)));
     JointCtx c;
-    if ((rc = joint_begin(desc, opt, seg, target, N, step, logits, jws, opt_state + 2 * (size_t)e->P, w.coef, s, &c))) return rc;
+    if ((rc = joint_begin(desc, opt, seg, target, N, step, logits, jws, opt_state + 2 * (size_t)w.Pu, w.coef, s, &c))) return rc;
     if (status && hipMemsetAsync(status, 0, sizeof(int32_t), s) != hipSuccess) return INR_ELAUNCH;
     if ((rc = launch_pack(e, w, params, 1, s))) return rc;
     w.set_step(step);
@@ -1881,7 +1942,7 @@ int inrfit_pcn_joint_step(const InrModelDesc* model, const InrRnvpDesc* rnvp, fl
     float* jws = (float*)((char*)workspace + align256(w.bytes));
     float* logits = prior_logits ? prior_logits : (float*)((char*)jws + align256(inrfit_joint_loss_workspace_bytes(N)));
     JointCtx c;
-    float* hdr = icnn_opt_state + 2 * (size_t)e->P;
+    float* hdr = icnn_opt_state + 2 * (size_t)w.icnn.Pu;
     if ((rc = joint_begin(desc, opt, seg, target, N, step, logits, jws, hdr, w.icnn.coef, s, &c))) return rc;
     if (status && hipMemsetAsync(status, 0, sizeof(int32_t), s) != hipSuccess) return INR_ELAUNCH;
     if ((rc = launch_pack(e, w.icnn, icnn_params, 1, s))) return rc;
@@ -1898,7 +1959,7 @@ int inrfit_pcn_joint_step(const InrModelDesc* model, const InrRnvpDesc* rnvp, fl
     hipLaunchKernelGGL(icnn_update_kernel, upd_grid(e->img.sl_cols, 1), upd_block(e->img.sl_cols), 0, s, u);
     launch_rnvp_bwd(w, flow_params, grid, 1, s);
     RnvpUpdArgs ru = make_rnvp_upd_args(w, 1, 0, flow_params, flow_opt_state, nullptr, &o, flow_weight_decay, step, hdr,
-                                        2 * (long long)e->P + INR_OPT_HEADER_FLOATS, status);
+                                        2 * (long long)w.icnn.Pu + INR_OPT_HEADER_FLOATS, status);
     ru.gscale = c.gscale;
     launch_rnvp_update_args(w, 1, ru, s);
     joint_dseg(c, dseg, s);
@@ -1922,7 +1983,7 @@ int inrfit_cdn_joint_step(const InrModelDesc* model, const InrFlowDesc* flow, fl
     float* jws = (float*)((char*)workspace + align256(w.bytes));
     float* logits = prior_logits ? prior_logits : (float*)((char*)jws + align256(inrfit_joint_loss_workspace_bytes(N)));
     JointCtx c;
-    float* hdr = icnn_opt_state + 2 * (size_t)e->P;
+    float* hdr = icnn_opt_state + 2 * (size_t)w.icnn.Pu;
     if ((rc = joint_begin(desc, opt, seg, target, N, step, logits, jws, hdr, w.icnn.coef, s, &c))) return rc;
     if (status && hipMemsetAsync(status, 0, sizeof(int32_t), s) != hipSuccess) return INR_ELAUNCH;
     if ((rc = launch_pack(e, w.icnn, icnn_params, 1, s))) return rc;
@@ -1940,7 +2001,7 @@ int inrfit_cdn_joint_step(const InrModelDesc* model, const InrFlowDesc* flow, fl
     hipLaunchKernelGGL(icnn_update_kernel, upd_grid(e->img.sl_cols, 1), upd_block(e->img.sl_cols), 0, s, u);
     launch_flow_bwd(w, flow, grid, 1, s);
     launch_flow_update(w, flow, 1, 0, flow_params, flow_opt_state, nullptr, &o, wd_on_weight_g, step, hdr,
-                       2 * (long long)e->P + INR_OPT_HEADER_FLOATS, s, status, c.gscale);
+                       2 * (long long)w.icnn.Pu + INR_OPT_HEADER_FLOATS, s, status, c.gscale);
     joint_dseg(c, dseg, s);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }

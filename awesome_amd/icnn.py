@@ -176,7 +176,9 @@ def _check_dev(t: Tensor, name: str) -> Tensor:
 
 def _check_spec(spec: IcnnSpec) -> None:
     if not spec.supported():
-        raise L.InrfitError(f"no compiled kernel for {spec} (built: n_hidden in {{32,64,130}} x in_features in {{2,3}} for L=1; n_hidden in {{64,130}} for L=2)")
+        raise L.InrfitError(f"no compiled kernel for {spec} (any n_hidden <= 130 runs - zero-padded on the next compiled width of "
+                            f"{{32, 64, 130}} (L = 1) / {{64, 130}} (L = 2); in_features in {{2, 3}}; wider hidden layers do not fit the LDS-resident "
+                            f"weight image of the fused kernel)")
 
 
 def _workspace(spec: IcnnSpec, grid: Grid, n_images: int) -> Tensor:

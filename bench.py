@@ -494,11 +494,15 @@ def path_variants(dev, S, steps=300, cpu_legs=True):
 
     def timed(fn):
         fn(10)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        res = fn(steps)
-        torch.cuda.synchronize()
-        return round((time.perf_counter() - t0) / steps * 1e6, 1), res.loss_hist[0]
+        best, res = None, None
+        for _ in range(2):   # best of two runs of `steps` steps (one run right after the 64-image fit was once seen at half speed)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = fn(steps)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return round(best / steps * 1e6, 1), res.loss_hist[0]
 
     from oracle import inr_oracle as O   # the checker / CPU leg (never on the product path)
     torch.manual_seed(0)
@@ -604,6 +608,20 @@ def joint_step_variant(dev, S, icnn_fwd_flop, steps=300):
                              "basis": "wall clock per joint step incl. the torch backbone and Python, on 3 x the prior's forward flops"}
         return e
 
+    # what the torch side of a step costs by itself (backbone forward + backward + its Adam step, same Python loop, no prior)
+    seg = ConvSegStandIn().to(dev)
+    opt = torch.optim.Adam(seg.parameters(), lr=1e-3)
+    dummy = torch.zeros(1, S, S, device=dev)
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps if rep else 16):
+            opt.zero_grad()
+            out = 1 - torch.sigmoid(seg(batch[k % n_img][0][0])[0])
+            out.backward(dummy)
+            opt.step()
+        torch.cuda.synchronize()
+    res["torch_backbone_only_us"] = round((time.perf_counter() - t0) / steps * 1e6, 1)
     icnn = lambda: ConvexNextNet(n_hidden=130, in_features=2, n_hidden_layers=1)   # noqa: E731
     pcn = lambda: real_nvp_path_connected_net(channels=2, hidden_units=32, flow_n_flows=12, flow_output_fn="tanh")   # noqa: E731
     res["convex_prior_fused"] = run(icnn, True, 8, icnn_fwd_flop(130, 2, 1), 0)

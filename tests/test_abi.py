@@ -39,8 +39,13 @@ def test_binding_matches_header_and_abi_version():
     md = _lib.InrModelDesc(_lib.INR_MODEL_ICNN, 130, 2, 1)
     assert lib.inrfit_param_count(ctypes.byref(md)) == 17813
     assert lib.inrfit_supported(ctypes.byref(md)) == 1
-    md2 = _lib.InrModelDesc(_lib.INR_MODEL_ICNN, 77, 2, 1)
-    assert lib.inrfit_supported(ctypes.byref(md2)) == 0
+    for h in (1, 31, 77, 100, 129):   # no kernel of their own: zero-padded on the next compiled width
+        md2 = _lib.InrModelDesc(_lib.INR_MODEL_ICNN, h, 2, 1)
+        assert lib.inrfit_supported(ctypes.byref(md2)) == 1
+        assert lib.inrfit_param_count(ctypes.byref(md2)) == h * 2 + h + (h * h + h + h * 2) + h + 1 + 2
+    for h, l in ((131, 1), (256, 1), (350, 2)):   # wider than the LDS-resident weight image allows
+        md2 = _lib.InrModelDesc(_lib.INR_MODEL_ICNN, h, 2, l)
+        assert lib.inrfit_supported(ctypes.byref(md2)) == 0
     assert lib.inrfit_strerror(-2).decode().startswith("model shape")
 
 
@@ -48,7 +53,7 @@ def test_argument_errors_are_reported_not_crashed():
     """Null pointers / unsupported shapes return negative codes before anything touches a device."""
     from awesome_amd import _lib
     lib = _lib.load()
-    md = _lib.InrModelDesc(_lib.INR_MODEL_ICNN, 77, 2, 1)
+    md = _lib.InrModelDesc(_lib.INR_MODEL_ICNN, 177, 2, 1)
     gd = _lib.InrGridDesc(0, 4, 4, 16, None, None, None, None, 0)
     assert lib.inrfit_workspace_bytes(ctypes.byref(md), ctypes.byref(gd), 1) == -2  # unsupported shape
     md = _lib.InrModelDesc(_lib.INR_MODEL_ICNN, 130, 2, 1)
