@@ -1,10 +1,13 @@
-"""The composition boundary: segmentation module (any torch module) + prior module (HIP path) -> (B, 2, H, W).
+"""The composition boundary: segmentation module (any torch module) + prior module (HIP path) -> (B, 2, H, W) / (img, n_pixels, 2).
 
-Mirrors the behaviour of the reference's WrapperModule for the configuration every path-connectedness / convexity config
-uses (awesome/model/wrapper_module.py:13-49, 157-340): `input_mode='image'`, `prior_arg_mode='param_clean_grid'` (the
-prior is evaluated on the clean xy grid = second positional extra argument), sigmoid on both outputs, optional 1-x
-inversion of the segmentation, channel-concat `[seg, prior]`, one image per batch element.  The segmentation module is
-out of scope of the HIP path and runs as it is (torch / MIOpen)."""
+Mirrors the behaviour of the reference's WrapperModule (awesome/model/wrapper_module.py:13-49, 79-155, 157-340) for its two input
+modes: `input_mode='image'` with `prior_arg_mode='param_clean_grid'` (every path-connectedness config: the prior is evaluated on the
+clean xy grid = second positional extra argument, channel-concat `[seg, prior]`, one image per batch element) and
+`input_mode='pixel'` with `prior_arg_mode='xy_c_preattached' | 'param_clean_grid'` (the scribble-trained convexity configs,
+`segmentation_training_mode: single`: input (img, n_pixels, F) with the pixel's coordinates as its first two features, outputs
+concatenated per pixel, trained with AwesomeLoss).  Sigmoid on both outputs, optional 1-x inversion of the segmentation.  The
+segmentation module is out of scope of the HIP path and runs as it is (torch / MIOpen); the prior module runs on the HIP kernels
+for both layouts ((B, C, H, W) and (N, C))."""
 from __future__ import annotations
 
 from typing import Any, Dict, List, Optional, Tuple
@@ -47,10 +50,11 @@ class WrapperModule(nn.Module, PretrainableModule):
                  prior_arg_mode: str = "param_clean_grid", input_mode: str = "image", use_segmentation_sigmoid: bool = True,
                  use_segmentation_output_inversion: bool = False, use_prior_sigmoid: bool = True, **kwargs):
         super().__init__()
-        if input_mode != "image":
-            raise NotImplementedError("only input_mode='image' (dense grids) is on the MI355X path")
-        if prior_arg_mode not in ("param_clean_grid", "none"):
-            raise NotImplementedError(f"prior_arg_mode {prior_arg_mode!r} is not supported")
+        if input_mode not in ("image", "pixel"):
+            raise ValueError(f"input_mode must be either 'pixel' or 'image' but is {input_mode}")
+        ok = ("param_clean_grid", "none") if input_mode == "image" else ("xy_c_preattached", "param_clean_grid", "none")
+        if prior_arg_mode not in ok:
+            raise NotImplementedError(f"prior_arg_mode {prior_arg_mode!r} is not supported with input_mode {input_mode!r}")
         self.segmentation_module, self.prior_module = segmentation_module, prior_module
         self.mode, self.prior_arg_mode, self.input_mode = mode, prior_arg_mode, input_mode
         self.use_segmentation_sigmoid = use_segmentation_sigmoid
@@ -62,14 +66,16 @@ class WrapperModule(nn.Module, PretrainableModule):
     def get_prior_args(self, _input: torch.Tensor, *args, segm: Optional[Any] = None, **kwargs) -> Tuple[List[Any], Dict[str, Any]]:
         if self.prior_arg_mode == "none":
             return [], {}
-        return [args[1]], {}   # param_clean_grid: (img, feat, xy_clean, ...) -> xy_clean   (wrapper_module.py:120-124)
+        if self.prior_arg_mode == "xy_c_preattached":   # pixel mode: the coordinates are the first two features (:93-96)
+            return [_input[..., 0:2]], {}
+        return [args[1]], {}   # param_clean_grid: (img, feat, xy_clean, ...) -> xy_clean   (wrapper_module.py:97-100, 120-124)
 
     def get_segmentation_module_args(self, primary: Any, args: Tuple[Any, ...], kwargs: Dict[str, Any]):
         seg_args = args[:1] + (args[2:] if len(args) > 2 else ())   # the clean grid is withheld from the seg. net (:142-155)
         return primary, seg_args, kwargs
 
     def process_segmentation_output(self, segm: torch.Tensor) -> torch.Tensor:
-        if segm.shape[0] == 1:
+        if segm.shape[0] == 1:   # (a batch dimension of one is removed; it is added again by the stack, :246-249)
             segm = segm[0]
         if self.use_segmentation_sigmoid:
             segm = torch.sigmoid(segm)
@@ -88,7 +94,28 @@ class WrapperModule(nn.Module, PretrainableModule):
         seg_in, seg_args, seg_kwargs = self.get_segmentation_module_args(xi, ai, kwargs or {})
         return self.process_segmentation_output(self.segmentation_module(seg_in, *seg_args, **seg_kwargs))
 
+    def _forward_pixels(self, _input: torch.Tensor, *args, **kwargs) -> torch.Tensor:
+        """input_mode='pixel' (:157-228): _input (img, n_pixels, F) [or (n_pixels, F)] -> (img, n_pixels, 2)."""
+        if _input.dim() == 2:
+            _input = _input[None]
+            args = tuple(a[None] if isinstance(a, torch.Tensor) and a.dim() == 2 else a for a in args)
+        res = []
+        for i in range(_input.shape[0]):
+            one = lambda t: t[i] if isinstance(t, torch.Tensor) else t  # noqa: E731   (get_assure_single_batch, pixel: _input[index])
+            xi, ai = one(_input), tuple(one(a) for a in args)
+            seg_in, seg_args, seg_kwargs = self.get_segmentation_module_args(xi, ai, kwargs)
+            seg = self.process_segmentation_output(self.segmentation_module(seg_in, *seg_args, **seg_kwargs))
+            if self.prior_module is not None and self.evaluate_prior:
+                pa, pk = self.get_prior_args(xi, *ai, segm=seg)
+                prior = self.process_prior_output(self.prior_module(*pa, **pk))
+                res.append(torch.cat([seg, prior], dim=-1))
+            else:
+                res.append(seg)
+        return torch.stack(res, dim=0)
+
     def forward(self, _input: torch.Tensor, *args, **kwargs) -> torch.Tensor:
+        if self.input_mode == "pixel":
+            return self._forward_pixels(_input, *args, **kwargs)
         if _input.dim() == 3:
             _input = _input[None]
             args = tuple(a[None] if isinstance(a, torch.Tensor) and a.dim() == 3 else a for a in args)
@@ -106,6 +133,12 @@ class WrapperModule(nn.Module, PretrainableModule):
         return torch.stack(res, dim=0)
 
     def split_model_output(self, output: torch.Tensor, additional_data=None) -> List[Tuple[torch.Tensor, Optional[torch.Tensor]]]:
+        if self.input_mode == "pixel":   # (n_pixels, 2) per image: split the last dimension (:296-303)
+            if output.dim() == 2:
+                output = output[None]
+            half = output.shape[-1] // 2
+            return [((output[b][..., :half], output[b][..., half:]) if self.prior_module is not None else (output[b], None))
+                    for b in range(output.shape[0])]
         if output.dim() == 3:
             output = output[None]
         out = []

@@ -50,6 +50,48 @@ def test_wrapper_module_forward_matches_reference_class(dev, golden_dir):
         np.testing.assert_allclose(ref.numpy(), z[f"out_inv{inv}"], atol=2e-6, rtol=1e-5)
 
 
+def test_wrapper_module_pixel_mode_matches_reference_class(dev, golden_dir):
+    """input_mode='pixel' (the scribble-trained convexity configs: segmentation_training_mode 'single', AwesomeLoss): forward on
+    (img, n_pixels, 5) pixels with the coordinates pre-attached, split, the prior's arguments, and AwesomeLoss (HIP loss kernel, form
+    INR_JOINT_AWESOME_PIXEL) with its gradients w.r.t. the prior (HIP backward bridge) and the segmentation module (torch), against
+    the reference WrapperModule / AwesomeLoss (fixture wrapper_module_pixel.npz; the fixture's header notes the reference's own
+    enum-vs-string slip in combine_outputs and the documented layout used here)."""
+    from awesome_amd.measures import AwesomeLoss
+    from awesome_amd.model import ConvexNextNet, WrapperModule
+    z = _z(golden_dir, "wrapper_module_pixel.npz")
+    prior = ConvexNextNet(n_hidden=32, in_features=2, n_hidden_layers=1)
+    prior.load_state_dict(O.load_npz_state(z, "prior."))
+    seg = torch.nn.Sequential(torch.nn.Linear(5, 8), torch.nn.ReLU(), torch.nn.Linear(8, 1))
+    seg.load_state_dict(O.load_npz_state(z, "seg."))
+    wm = WrapperModule(seg, prior, prior_arg_mode="xy_c_preattached", input_mode="pixel").to(dev)
+    x, tgt = torch.from_numpy(z["x"]).to(dev), torch.from_numpy(z["target"]).to(dev)
+    with torch.no_grad():
+        out = wm(x)
+    assert out.shape == (2, 40, 2)
+    np.testing.assert_allclose(out.cpu().numpy(), z["out"], atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(out.cpu().numpy()[..., 0], z["out_raw"][:, :40, 0], atol=2e-6, rtol=1e-5)   # the class's raw rows: seg ...
+    np.testing.assert_allclose(out.cpu().numpy()[..., 1], z["out_raw"][:, 40:, 0], atol=2e-6, rtol=1e-5)   # ... then prior
+    s1, p1 = wm.split_model_output(out)[1]
+    np.testing.assert_allclose(s1.cpu().numpy(), z["out"][1, :, :1], atol=2e-6)
+    np.testing.assert_allclose(p1.cpu().numpy(), z["out"][1, :, 1:], atol=2e-6)
+    pa, _ = wm.get_prior_args(x[0])
+    np.testing.assert_array_equal(pa[0].cpu().numpy(), z["prior_arg"])
+    for penalty, tag in ((False, "plain"), (True, "pen")):
+        crit = AwesomeLoss(alpha=0.6, scribble_percentage=0.75)
+        crit.extra_penalty = penalty
+        assert crit.joint_desc(40) is not None            # the HIP loss kernel is what runs on device tensors
+        wm.zero_grad()
+        loss = crit(wm(x), tgt)
+        loss.backward()
+        assert float(loss.detach()) == pytest.approx(float(z[f"loss_{tag}"]), rel=5e-6)
+        for k, p_ in prior.named_parameters():
+            ref = z[f"grad_{tag}.prior.{k}"]
+            np.testing.assert_allclose(p_.grad.cpu().numpy(), ref, rtol=3e-4, atol=3e-6 * float(np.abs(ref).max()) + 1e-9, err_msg=f"{tag} prior {k}")
+        for k, p_ in seg.named_parameters():
+            ref = z[f"grad_{tag}.seg.{k}"]
+            np.testing.assert_allclose(p_.grad.cpu().numpy(), ref, rtol=3e-4, atol=3e-6 * float(np.abs(ref).max()) + 1e-9, err_msg=f"{tag} seg {k}")
+
+
 @pytest.mark.parametrize("tag", ["l2_w130_k6", "l1_w24_k4"])
 def test_convex_diffeomorphism_net_class_fixture(dev, golden_dir, tag):
     """The class itself (both backbones: the configs' normal_block and the constructor's default SimpleBackbone): forward,

@@ -165,6 +165,50 @@ def gen_wrapper(ref, out):
     print("wrapper", rec["out_inv0"].shape)
 
 
+def gen_wrapper_pixel(ref, out):
+    """WrapperModule in PIXEL mode (the scribble-trained convexity configs, segmentation_training_mode 'single'): input (img, n_pixels,
+    5) = (x, y, r, g, b) per pixel, prior_arg_mode 'xy_c_preattached', outputs concatenated per pixel; AwesomeLoss on it with 75 %
+    scribble pixels, with and without the extra penalty: output, split, loss values and the gradient of every parameter."""
+    import awesome.measures.awesome_loss as al
+    seed_all(33)
+    prior = ref.convex_net.ConvexNextNet(n_hidden=32, in_features=2, n_hidden_layers=1)
+    seg = torch.nn.Sequential(torch.nn.Linear(5, 8), torch.nn.ReLU(), torch.nn.Linear(8, 1))   # stand-in per-pixel classifier
+    rng = np.random.RandomState(9)
+    x = torch.from_numpy(rng.uniform(0, 1, size=(2, 40, 5)).astype(np.float32))
+    tgt = torch.from_numpy((rng.uniform(size=(2, 30, 1)) > 0.5).astype(np.float32))
+    wm = ref.wrapper_module.WrapperModule(segmentation_module=seg, prior_module=prior, prior_arg_mode="xy_c_preattached",
+                                          input_mode="pixel", use_segmentation_sigmoid=True, use_prior_sigmoid=True)
+    rec = dict(x=x.numpy(), target=tgt.numpy())
+    rec.update(sd_np(prior, "prior."))
+    rec.update(sd_np(seg, "seg."))
+    # At this commit `combine_outputs` compares its InputMode ENUM with the string 'pixel' (wrapper_module.py:236), so even in pixel mode
+    # the two outputs are concatenated along dim 0: the class returns (img, 2 n_pixels, 1) = [seg pixels; prior pixels], not the
+    # (img, n_pixels, 2) its docstring and AwesomeLoss (awesome_loss.py:49-50) expect.  The fixture keeps the class's raw output AND the
+    # documented layout built from it (the same numbers, re-arranged); the losses are the reference's AwesomeLoss on the latter.
+    n = x.shape[1]
+
+    def documented(o):
+        return o if o.shape[-1] == 2 else torch.cat([o[:, :n], o[:, n:]], dim=-1)
+
+    o = wm(x)
+    rec["out_raw"] = o.detach().numpy()
+    rec["out"] = documented(o).detach().numpy()
+    pa, _ = wm.get_prior_args(x[0])
+    rec["prior_arg"] = pa[0].numpy()
+    for penalty in (False, True):
+        crit = al.AwesomeLoss(alpha=0.6, scribble_percentage=0.75)
+        crit.extra_penalty = penalty
+        wm.zero_grad()
+        loss = crit(documented(wm(x)), tgt)
+        loss.backward()
+        tag = "pen" if penalty else "plain"
+        rec[f"loss_{tag}"] = np.float32(loss.item())
+        rec.update({f"grad_{tag}.prior.{k}": p.grad.detach().numpy().copy() for k, p in prior.named_parameters()})
+        rec.update({f"grad_{tag}.seg.{k}": p.grad.detach().numpy().copy() for k, p in seg.named_parameters()})
+    np.savez_compressed(os.path.join(out, "wrapper_module_pixel.npz"), **rec)
+    print("wrapper pixel", rec["out"].shape, float(rec["loss_plain"]), float(rec["loss_pen"]))
+
+
 def gen_prior_cache(ref, out):
     """PriorCache.get_state() (fixture 8): the layout a fitted cache has on disk - key names, dtypes, the JSON of model_args -
     and the PriorManager swap (enter loads the state of a key, exit stores the model's state back)."""
@@ -332,10 +376,14 @@ def gen_teaser_star_shaped(out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+    ap.add_argument("--only", default=None, help="run a single generator, e.g. wrapper_pixel")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(4)
     ref = _import_reference()
+    if args.only == "wrapper_pixel":
+        return gen_wrapper_pixel(ref, args.out)
+    gen_wrapper_pixel(ref, args.out)
     gen_encode_notebooks(args.out)
     gen_teaser_rotation_symmetric(args.out)
     gen_teaser_star_shaped(args.out)
