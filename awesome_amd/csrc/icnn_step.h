@@ -152,12 +152,14 @@ struct ImgMap {
     int sl_tile;                // gradient slab: floats of ONE layer's tile region (Cfg::SL_TILE); L of them lead the slab
     int sl_cols;                // gradient slab: columns in use (Cfg::SL_COLS, or P + 1)
     int KG, kg_magic;           // column tiles per row tile; 65536 / KG + 1 (tile index / KG without a division: exact below 2^13)
+    int identity;               // 1: the "slab" is a plain gradient vector [P | loss] (the layer-by-layer path, wide.h): column = parameter
 };
 
 // Gradient slab column -> flat parameter index (P = the loss partial, -1 = padding); the inverse of the step kernels' stores:
 //   [layer 0 tiles (sl_tile floats)] ... [layer L-1 tiles] [W_in, b_in] [per layer: leftover rows of W, of b, of S] [w_o, b_o, s_o] [loss]
 // Straight-line selects on fields read with constant indices: it sits in front of the update kernel's first loads.
 __device__ __forceinline__ int slab_param_of_col(const ImgMap& m, int col) {
+    if (m.identity) return col < m.sl_cols ? col : -1;
     const int H = m.H, HM = m.HM, C = m.C, KG = m.KG, kgm = m.kg_magic, T = m.sl_tile, two = m.L > 1;
     const int e0 = m.ext[0], e1 = m.ext[1], e2 = m.ext[2], e3 = m.ext[3], pwo = m.p_wo, ncols = m.sl_cols;
     // tile regions

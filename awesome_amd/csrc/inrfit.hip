@@ -25,6 +25,7 @@
 #include "flow.h"
 #include "rnvp.h"
 #include "joint_loss.h"
+#include "wide.h"
 
 #include <vector>
 
@@ -33,6 +34,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------------
 // slab reduction + optimizer step
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr int UPD_RANGES = WIDE_MAX_LAYERS + 1;   // hidden layers of the widest supported net + the output layer
 struct UpdArgs {
     float* wimg;          // [n_images][img.floats] parameter images (kept in step with params)
     ImgMap img;
@@ -54,8 +56,8 @@ struct UpdArgs {
     float one_minus_b1, one_minus_b2;
     int hist_idx, hist_stride;
     int mode;             // 0 = optimizer step, 1 = write reduced grads + loss only
-    int clamp_lo[3], clamp_hi[3];  // flat ranges projected onto >= 0 (ln.weight of every hidden layer, out.ln.weight)
-    int freeze_lo[3], freeze_hi[3];  // flat ranges that are never updated (the skip weights when opt.freeze_skips)
+    int clamp_lo[UPD_RANGES], clamp_hi[UPD_RANGES];    // flat ranges projected onto >= 0 (ln.weight of every hidden layer, out.ln.weight)
+    int freeze_lo[UPD_RANGES], freeze_hi[UPD_RANGES];  // flat ranges that are never updated (the skip weights when opt.freeze_skips)
     int input_hi;                    // opt.freeze_input: flat range [0, input_hi) = input.weight | input.bias is never updated
     const float* gscale;             // [n_images] factor on the reduced gradient (device; the joint step's detached clip factor), or null
 };
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
     if (frozen || !isfinite(gsum) || ju < 0) return;
     if (u.opt.freeze_skips) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < UPD_RANGES; ++k)
             if (j >= u.freeze_lo[k] && j < u.freeze_hi[k]) return;
     }
     if (u.opt.freeze_input && j < u.input_hi) return;
@@ -266,11 +268,11 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
     if (u.opt.clamp) {
         bool in = false;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) in = in || (j >= u.clamp_lo[k] && j < u.clamp_hi[k]);
+        for (int k = 0; k < UPD_RANGES; ++k) in = in || (j >= u.clamp_lo[k] && j < u.clamp_hi[k]);
         if (in) p = fmaxf(p, 0.f);
     }
     u.params[(size_t)img * u.Pu + ju] = p;
-    {
+    if (u.wimg != nullptr) {   // (the layer-by-layer path has no parameter image)
         int slot[2];
         const int ns = image_slots(u.img, j, slot);
         float* __restrict__ wi = u.wimg + (size_t)img * u.img.floats;
@@ -631,7 +633,7 @@ int inrfit_slabs_per_image(int64_t n_points, int n_images) {
     return wgs_per_image(n_points, n_images);
 }
 
-int inrfit_supported(const InrModelDesc* model) { return find_entry(model) ? 1 : 0; }
+int inrfit_supported(const InrModelDesc* model) { return (find_entry(model) || wide_shape_ok(model)) ? 1 : 0; }
 
 int64_t inrfit_param_count(const InrModelDesc* m) {
     if (!m || m->kind != INR_MODEL_ICNN || m->n_hidden <= 0 || m->in_features <= 0 || m->n_layers < 0) return INR_EINVAL;
@@ -646,6 +648,11 @@ int64_t inrfit_opt_state_floats(const InrModelDesc* m) {
 
 int64_t inrfit_workspace_bytes(const InrModelDesc* model, const InrGridDesc* grid, int n_images) {
     const KernelEntry* e = find_entry(model);
+    if (!e && wide_shape_ok(model)) {
+        if (!grid || grid->n_points <= 0 || n_images <= 0) return INR_EINVAL;
+        return wide_total_bytes(make_wide_map(model->n_hidden, model->in_features, model->n_layers), grid->n_points,
+                                model->act0 != INR_ACT_RELU, n_images);
+    }
     if (!e) return INR_EUNSUPPORTED;
     if (!grid || grid->n_points <= 0 || n_images <= 0) return INR_EINVAL;
     return carve(e, grid->n_points, n_images, nullptr).bytes;
@@ -731,20 +738,20 @@ static UpdArgs make_upd_args(const KernelEntry* e, const Workspace& w, float* pa
     u.one_minus_b1 = (float)(1.0 - (double)opt->beta1);
     u.one_minus_b2 = (float)(1.0 - (double)opt->beta2);
     u.mode = 0;
-    for (int k = 0; k < 3; ++k) u.clamp_lo[k] = u.clamp_hi[k] = 0;
+    for (int k = 0; k < UPD_RANGES; ++k) u.clamp_lo[k] = u.clamp_hi[k] = 0;
     for (int k = 0; k < e->img.L; ++k) {
         u.clamp_lo[k] = e->img.p_w[k];
         u.clamp_hi[k] = e->img.p_w[k] + e->img.H * e->img.H;
     }
-    u.clamp_lo[2] = e->img.p_wo;
-    u.clamp_hi[2] = e->img.p_wo + e->img.H;
-    for (int k = 0; k < 3; ++k) u.freeze_lo[k] = u.freeze_hi[k] = 0;
+    u.clamp_lo[UPD_RANGES - 1] = e->img.p_wo;
+    u.clamp_hi[UPD_RANGES - 1] = e->img.p_wo + e->img.H;
+    for (int k = 0; k < UPD_RANGES; ++k) u.freeze_lo[k] = u.freeze_hi[k] = 0;
     for (int k = 0; k < e->img.L; ++k) {
         u.freeze_lo[k] = e->img.p_s[k];
         u.freeze_hi[k] = e->img.p_s[k] + e->img.H * e->img.C;
     }
-    u.freeze_lo[2] = e->img.p_so;
-    u.freeze_hi[2] = e->img.p_so + e->img.C;
+    u.freeze_lo[UPD_RANGES - 1] = e->img.p_so;
+    u.freeze_hi[UPD_RANGES - 1] = e->img.p_so + e->img.C;
     u.input_hi = e->img.p_w[0];
     return u;
 }
@@ -784,11 +791,134 @@ static void launch_reduce(const KernelEntry* e, const Workspace& w, int n_images
     hipLaunchKernelGGL(icnn_update_kernel, upd_grid(e->img.sl_cols, n_images), upd_block(e->img.sl_cols), 0, s, u);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the layer-by-layer path (wide.h): shapes without a fused kernel - n_hidden > 130 or more than two hidden layers
+// ---------------------------------------------------------------------------------------------------------------------
+static bool use_wide(const InrModelDesc* m) { return find_entry(m) == nullptr && wide_shape_ok(m); }
+
+static int wide_prepare(const InrModelDesc* model, const InrGridDesc* grid, int n_images, void* workspace, int64_t workspace_bytes,
+                        WideMap* m, WideWs* w, float** coef_all, hipStream_t s) {
+    if (!workspace || !grid || grid->n_points <= 0 || grid->n_points > 0x7fffffffLL / WIDE_MAX_HIDDEN * 64 || n_images <= 0) return INR_EINVAL;
+    if (grid->mode == INR_GRID_SEPARABLE) {
+        if (!grid->xs || !grid->ys || (long long)grid->width * grid->height != grid->n_points) return INR_EINVAL;
+    } else if (grid->mode != INR_GRID_EXPLICIT || !grid->coords) {
+        return INR_EINVAL;
+    }
+    if (model->act0 < INR_ACT_RELU || model->act0 > INR_ACT_SIN) return INR_EINVAL;
+    if (!wide_blas().ok) return INR_EUNSUPPORTED;   // rocBLAS could not be opened: this shape has no path on this box
+    *m = make_wide_map(model->n_hidden, model->in_features, model->n_layers);
+    const bool pre0 = model->act0 != INR_ACT_RELU;
+    if (workspace_bytes < wide_total_bytes(*m, grid->n_points, pre0, n_images)) return INR_EWORKSPACE;
+    *w = carve_wide(*m, grid->n_points, pre0, workspace);
+    *coef_all = (float*)((char*)workspace + w->bytes);
+    (void)s;
+    return INR_OK;
+}
+
+static int wide_forward_all(const InrModelDesc* model, const float* params, const InrGridDesc* grid, int n_images, float* logits,
+                            void* workspace, int64_t workspace_bytes, hipStream_t s) {
+    WideMap m;
+    WideWs w;
+    float* coef;
+    int rc = wide_prepare(model, grid, n_images, workspace, workspace_bytes, &m, &w, &coef, s);
+    if (rc) return rc;
+    for (int img = 0; img < n_images; ++img)
+        if ((rc = wide_forward(m, w, model, params + (size_t)img * m.P, grid, img, nullptr, 0, false, logits + (size_t)img * grid->n_points, s)))
+            return rc;
+    return INR_OK;
+}
+
+// loss + gradients (loss->kind may be INR_LOSS_EXTERNAL: `targets` = dL/dlogits) of every image into grads_out / loss_out
+static int wide_loss_grad_all(const InrModelDesc* model, const float* params, const InrGridDesc* grid, const float* targets,
+                              const InrLossDesc* loss, int n_images, float* loss_out, float* grads_out, void* workspace,
+                              int64_t workspace_bytes, hipStream_t s) {
+    WideMap m;
+    WideWs w;
+    float* coef;
+    int rc = wide_prepare(model, grid, n_images, workspace, workspace_bytes, &m, &w, &coef, s);
+    if (rc) return rc;
+    const long long N = grid->n_points;
+    if (loss->kind != INR_LOSS_EXTERNAL)
+        hipLaunchKernelGGL(loss_coef_kernel, dim3(n_images), dim3(256), 0, s, targets, N, *loss, coef);
+    for (int img = 0; img < n_images; ++img) {
+        w.coef = coef + 2 * img;
+        const float* p = params + (size_t)img * m.P;
+        if ((rc = wide_forward(m, w, model, p, grid, img, targets + (size_t)img * N, loss->kind, true, nullptr, s))) return rc;
+        if ((rc = wide_backward(m, w, model, p, N, s))) return rc;
+        if (hipMemcpyAsync(grads_out + (size_t)img * m.P, w.grads, sizeof(float) * m.P, hipMemcpyDeviceToDevice, s) != hipSuccess) return INR_ELAUNCH;
+        if (loss_out && hipMemcpyAsync(loss_out + img, w.grads + m.P, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return INR_ELAUNCH;
+    }
+    return INR_OK;
+}
+
+static int wide_fit(const InrModelDesc* model, float* params, float* opt_state, const InrGridDesc* grid, const float* targets,
+                    const InrLossDesc* loss, const InrOptDesc* opt, int n_images, int steps, int step0, float* loss_hist,
+                    float* final_logits, int32_t* status, void* workspace, int64_t workspace_bytes, hipStream_t s) {
+    WideMap m;
+    WideWs w;
+    float* coef;
+    int rc = wide_prepare(model, grid, n_images, workspace, workspace_bytes, &m, &w, &coef, s);
+    if (rc) return rc;
+    const long long N = grid->n_points;
+    hipLaunchKernelGGL(loss_coef_kernel, dim3(n_images), dim3(256), 0, s, targets, N, *loss, coef);
+    hipLaunchKernelGGL(opt_init_kernel, dim3(n_images), dim3(64), 0, s, opt_state, m.P, *opt, step0);
+    if (status && hipMemsetAsync(status, 0, sizeof(int32_t) * n_images, s) != hipSuccess) return INR_ELAUNCH;
+    // the optimizer step = icnn_update_kernel on a one-"slab" view of the gradient vector (column = parameter, column P = the loss)
+    UpdArgs u{};
+    u.img.identity = 1;
+    u.img.H = m.h; u.img.C = m.C; u.img.L = m.L; u.img.P = m.P; u.img.sl_cols = m.P + 1;
+    u.opt = *opt;
+    u.P = u.Pu = m.P;
+    u.hu = m.h;
+    u.PS = (m.P + 1 + 31) / 32 * 32;
+    u.wgs = 1;
+    u.n_images = 1;
+    u.hist_stride = steps;
+    u.one_minus_b1 = (float)(1.0 - (double)opt->beta1);
+    u.one_minus_b2 = (float)(1.0 - (double)opt->beta2);
+    u.slabs = w.grads;
+    for (int k = 0; k < UPD_RANGES; ++k) u.clamp_lo[k] = u.clamp_hi[k] = u.freeze_lo[k] = u.freeze_hi[k] = 0;
+    for (int k = 0; k < m.L; ++k) {
+        u.clamp_lo[k] = m.p_w(k); u.clamp_hi[k] = m.p_w(k) + m.h * m.h;
+        u.freeze_lo[k] = m.p_s(k); u.freeze_hi[k] = m.p_s(k) + m.h * m.C;
+    }
+    u.clamp_lo[UPD_RANGES - 1] = m.p_wo(); u.clamp_hi[UPD_RANGES - 1] = m.p_wo() + m.h;
+    u.freeze_lo[UPD_RANGES - 1] = m.p_so(); u.freeze_hi[UPD_RANGES - 1] = m.p_so() + m.C;
+    u.input_hi = m.p_w(0);
+    const dim3 ugrid = upd_grid(m.P + 1, 1), ublock = upd_block(m.P + 1);
+    const bool gate_logits = final_logits && opt->logits_at_last_forward && steps > 0;
+    for (int it = 0; it < steps; ++it) {
+        u.t = step0 + it + 1;
+        u.bc1 = 1.0 - pow((double)opt->beta1, (double)u.t);
+        u.bc2_sqrt = (float)sqrt(1.0 - pow((double)opt->beta2, (double)u.t));
+        u.hist_idx = it;
+        for (int img = 0; img < n_images; ++img) {
+            float* p = params + (size_t)img * m.P;
+            w.coef = coef + 2 * img;
+            if ((rc = wide_forward(m, w, model, p, grid, img, targets + (size_t)img * N, loss->kind, true,
+                                   gate_logits && it == steps - 1 ? final_logits + (size_t)img * N : nullptr, s))) return rc;
+            if ((rc = wide_backward(m, w, model, p, N, s))) return rc;
+            u.params = p;
+            u.opt_state = opt_state + (size_t)img * (2 * (size_t)m.P + INR_OPT_HEADER_FLOATS);
+            u.loss_hist = loss_hist ? loss_hist + (size_t)img * steps : nullptr;
+            u.status = status ? status + img : nullptr;
+            hipLaunchKernelGGL(icnn_update_kernel, ugrid, ublock, 0, s, u);
+        }
+    }
+    if (hipGetLastError() != hipSuccess) return INR_ELAUNCH;
+    if (final_logits && !gate_logits)
+        for (int img = 0; img < n_images; ++img)
+            if ((rc = wide_forward(m, w, model, params + (size_t)img * m.P, grid, img, nullptr, 0, false, final_logits + (size_t)img * N, s))) return rc;
+    return INR_OK;
+}
+
 int inrfit_forward(const InrModelDesc* model, const float* params, const InrGridDesc* grid, int n_images, float* logits,
                    void* workspace, int64_t workspace_bytes, void* stream) {
     const KernelEntry* e;
     Workspace w;
     if (!params || !logits) return INR_EINVAL;
+    if (use_wide(model)) return wide_forward_all(model, params, grid, n_images, logits, workspace, workspace_bytes, (hipStream_t)stream);
     int rc = prepare(model, grid, n_images, workspace, workspace_bytes, &e, &w);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -804,6 +934,8 @@ int inrfit_loss_grad(const InrModelDesc* model, const float* params, const InrGr
     if (!params || !targets || !loss_out || !grads) return INR_EINVAL;
     int rc = check_loss(loss);
     if (rc) return rc;
+    if (use_wide(model))
+        return wide_loss_grad_all(model, params, grid, targets, loss, n_images, loss_out, grads, workspace, workspace_bytes, (hipStream_t)stream);
     if ((rc = prepare(model, grid, n_images, workspace, workspace_bytes, &e, &w))) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(loss_coef_kernel, dim3(n_images), dim3(256), 0, s, targets, (long long)grid->n_points, *loss, w.coef);
@@ -818,6 +950,11 @@ int inrfit_backward(const InrModelDesc* model, const float* params, const InrGri
     const KernelEntry* e;
     Workspace w;
     if (!params || !dlogits || !grads) return INR_EINVAL;
+    if (use_wide(model)) {
+        if (dcoords) return INR_EUNSUPPORTED;   // coordinate gradients (ICNN behind a deformation): fused shapes only
+        const InrLossDesc ext{INR_LOSS_EXTERNAL, INR_WEIGHT_NONE, 1.f, 0.f, 0.f};
+        return wide_loss_grad_all(model, params, grid, dlogits, &ext, n_images, nullptr, grads, workspace, workspace_bytes, (hipStream_t)stream);
+    }
     int rc = prepare(model, grid, n_images, workspace, workspace_bytes, &e, &w);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -901,6 +1038,9 @@ int inrfit_fit(const InrModelDesc* model, float* params, float* opt_state, const
     int rc = check_loss(loss);
     if (rc) return rc;
     if (loss->kind == INR_LOSS_EXTERNAL) return INR_EINVAL;
+    if (use_wide(model))
+        return wide_fit(model, params, opt_state, grid, targets, loss, opt, n_images, steps, step0, loss_hist, final_logits, status,
+                        workspace, workspace_bytes, (hipStream_t)stream);
     if ((rc = prepare(model, grid, n_images, workspace, workspace_bytes, &e, &w))) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(loss_coef_kernel, dim3(n_images), dim3(256), 0, s, targets, (long long)grid->n_points, *loss, w.coef);

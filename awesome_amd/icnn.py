@@ -176,9 +176,8 @@ def _check_dev(t: Tensor, name: str) -> Tensor:
 
 def _check_spec(spec: IcnnSpec) -> None:
     if not spec.supported():
-        raise L.InrfitError(f"no compiled kernel for {spec} (any n_hidden <= 130 runs - zero-padded on the next compiled width of "
-                            f"{{32, 64, 130}} (L = 1) / {{64, 130}} (L = 2); in_features in {{2, 3}}; wider hidden layers do not fit the LDS-resident "
-                            f"weight image of the fused kernel)")
+        raise L.InrfitError(f"no kernel path for {spec}: n_hidden <= 1024, in_features in {{2, 3}}, 1..8 hidden layers (fused MFMA kernels "
+                            f"for n_hidden <= 130 and L <= 2, zero-padded to the next compiled width; the layer-by-layer path beyond)")
 
 
 def _workspace(spec: IcnnSpec, grid: Grid, n_images: int) -> Tensor:

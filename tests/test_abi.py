@@ -43,8 +43,11 @@ def test_binding_matches_header_and_abi_version():
         md2 = _lib.InrModelDesc(_lib.INR_MODEL_ICNN, h, 2, 1)
         assert lib.inrfit_supported(ctypes.byref(md2)) == 1
         assert lib.inrfit_param_count(ctypes.byref(md2)) == h * 2 + h + (h * h + h + h * 2) + h + 1 + 2
-    for h, l in ((131, 1), (256, 1), (350, 2)):   # wider than the LDS-resident weight image allows
+    for h, l in ((131, 1), (256, 1), (350, 3), (64, 4)):   # wider / deeper than the fused kernels hold: the layer-by-layer path (wide.h)
         md2 = _lib.InrModelDesc(_lib.INR_MODEL_ICNN, h, 2, l)
+        assert lib.inrfit_supported(ctypes.byref(md2)) == 1
+    for h, c, l in ((2000, 2, 1), (64, 5, 1), (64, 2, 0), (64, 2, 9)):
+        md2 = _lib.InrModelDesc(_lib.INR_MODEL_ICNN, h, c, l)
         assert lib.inrfit_supported(ctypes.byref(md2)) == 0
     assert lib.inrfit_strerror(-2).decode().startswith("model shape")
 
@@ -53,7 +56,7 @@ def test_argument_errors_are_reported_not_crashed():
     """Null pointers / unsupported shapes return negative codes before anything touches a device."""
     from awesome_amd import _lib
     lib = _lib.load()
-    md = _lib.InrModelDesc(_lib.INR_MODEL_ICNN, 177, 2, 1)
+    md = _lib.InrModelDesc(_lib.INR_MODEL_ICNN, 1777, 2, 1)
     gd = _lib.InrGridDesc(0, 4, 4, 16, None, None, None, None, 0)
     assert lib.inrfit_workspace_bytes(ctypes.byref(md), ctypes.byref(gd), 1) == -2  # unsupported shape
     md = _lib.InrModelDesc(_lib.INR_MODEL_ICNN, 130, 2, 1)

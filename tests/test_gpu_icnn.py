@@ -448,3 +448,47 @@ def test_any_hidden_width_up_to_130_runs_zero_padded(amd, h, C, L):
     gotp = A.unpack_params(spec, res.params[0].cpu())
     for k in pf:
         np.testing.assert_allclose(gotp[k].numpy(), pf[k].numpy(), rtol=5e-4, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("h,C,L,act0", [(256, 2, 1, "relu"), (350, 2, 3, "relu"), (160, 3, 2, "relu"), (64, 2, 4, "relu"), (200, 2, 2, "cos")])
+def test_wide_and_deep_shapes_on_the_layer_by_layer_path(amd, h, C, L, act0):
+    """n_hidden > 130 (and more than two hidden layers) have no fused kernel - the weight image of such a layer does
+    not fit the LDS - and run layer by layer (awesome_amd/csrc/wide.h: activations in HBM, plain GEMMs, the same update kernel).  Forward,
+    loss, every gradient and a 12-step Adam + clamp trajectory against the oracle; 350 x 3 is the relu stack of
+    notebooks/imageRepresentationTest.ipynb cell 5."""
+    A, dev = amd, torch.device("cuda:0")
+    torch.manual_seed(h + L)
+    spec = A.IcnnSpec(n_hidden=h, in_features=C, n_layers=L, act0=act0) if act0 != "relu" else A.IcnnSpec(n_hidden=h, in_features=C, n_layers=L)
+    assert spec.supported()
+    p = {k: (torch.rand(shp) - 0.45) * (0.6 / np.sqrt(h)) for k, shp in spec.keys_shapes()}
+    H, W = 20, 24
+    grid_t = O.positional_grid(W, H) if C == 2 else O.positional_grid(W, H, 2.0, 5.0)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    un = (((yy - 9) ** 2 + (xx - 11) ** 2) > 30).float()
+    flat = A.pack_state_dict(spec, p, dev)[None].contiguous()
+    grid = A.Grid.from_image_grid(grid_t[None].to(dev)) if C == 3 else A.Grid.linspace(W, H, dev)
+    logits = A.forward(spec, flat, grid)
+    ref = O.icnn_forward_image(p, grid_t[None], act0=act0)
+    np.testing.assert_allclose(logits[0].cpu().numpy(), ref.reshape(-1).numpy(), atol=2e-5, rtol=2e-5)
+    if act0 != "relu":
+        return
+    loss, grads = A.loss_grad(spec, flat, grid, un.reshape(1, -1).to(dev), loss="se")
+    lo, go = O.loss_and_grads(p, grid_t[None], un[None, None], "se")
+    assert float(loss[0]) == pytest.approx(lo, rel=2e-5)
+    got = A.unpack_params(spec, grads[0].cpu())
+    for k in go:
+        np.testing.assert_allclose(got[k].numpy(), go[k].numpy(), rtol=5e-4, atol=5e-6 * float(go[k].abs().max()) + 1e-10, err_msg=k)
+    dl = torch.randn(1, H * W)
+    gb = A.icnn.backward(spec, flat, grid, dl.to(dev))
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    (O.icnn_forward_image(pr, grid_t[None]).reshape(-1) * dl[0]).sum().backward()
+    gotb = A.unpack_params(spec, gb[0].cpu())
+    for k in pr:
+        np.testing.assert_allclose(gotb[k].numpy(), pr[k].grad.numpy(), rtol=5e-4, atol=5e-6 * float(pr[k].grad.abs().max()) + 1e-10, err_msg=k)
+    pf, losses, _ = O.fit_icnn(p, grid_t[None], un[None, None], 12, lr=2e-3)
+    res = A.fit(spec, flat.clone(), grid, un.reshape(1, -1).to(dev), 12, lr=2e-3)
+    np.testing.assert_allclose(res.loss_hist[0].cpu().numpy(), np.asarray(losses, np.float32), rtol=3e-4)
+    gotp = A.unpack_params(spec, res.params[0].cpu())
+    for k in pf:
+        np.testing.assert_allclose(gotp[k].numpy(), pf[k].numpy(), rtol=1e-3, atol=5e-6, err_msg=k)
+    np.testing.assert_allclose(res.logits[0].cpu().numpy(), O.icnn_forward_image(pf, grid_t[None]).reshape(-1).numpy(), atol=1e-4, rtol=1e-4)
