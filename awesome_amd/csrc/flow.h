@@ -90,13 +90,15 @@ __device__ __forceinline__ f32x2 step01(f32x2 pre) {
 }
 
 // ---- tanh / exp of the coupling outputs ---------------------------------------------------------------------------------------
-// libm's tanhf / expf cost ~35 / ~12 VALU instructions each (denormal / overflow handling, an IEEE division); the coupling needs
-// 2 tanh + 1 exp per point, flow and output channel, a third of the forward's instructions.  The forms below keep
-// libm's accuracy class - RELATIVE error, so tiny outputs of the zero-initialised nets stay exact to rounding - at ~19 / 5:
+// The coupling needs 2 tanh + 1 exp per point, flow and output channel.  libm's tanhf / expf are ~35 / ~12 VALU instructions with
+// data-dependent branches (cheap when a whole wave takes the same one, e.g. all arguments small; both sides when it does not); the
+// forms below are branch-free at ~19 / 5 and keep libm's accuracy class - RELATIVE error, so tiny outputs of the zero-initialised nets
+// stay exact to rounding.  They did not change the kernels' time (profiles/NOTES.md); what they buy is a run time that does not depend
+// on the data and error bounds that are asserted on the device:
 //   exp:  e^x = 2^hi (1 + lo ln 2) with x log2(e) = hi + lo split exactly by one fma (v_exp_f32: 1 ulp), |x| <~ 80;
-//         measured max rel. error 1.3e-7 on [-10, 10] (tests/test_gpu_rnvp.py::test_fast_tanh_exp_error_bounds asserts 2.5e-7)
+//         measured max rel. error 1.27e-7 on [-10, 10] (tests/test_gpu_rnvp.py::test_fast_tanh_exp_error_bounds asserts 2.5e-7)
 //   tanh: |x| < 0.625: odd minimax polynomial x + x^3 P(x^2) (the Cephes tanhf coefficients); else 1 - 2 / (e^{2|x|} + 1) with the exp
-//         above and v_rcp_f32 (1 ulp); measured max rel. error 2.4e-7 (asserted: 5e-7; libm: 1.2e-7).
+//         above and v_rcp_f32 (1 ulp); measured max rel. error 1.61e-7 (asserted: 5e-7; libm: 1.2e-7).
 // A first attempt in round 1 (tanh x = 1 - 2/(1 + e^2x) for ALL x, plain v_exp_f32 of x log2e) had ABSOLUTE error 2e-7, i.e. large
 // relative error near 0 where the couplings start: "3x noisier" gradients.  The relative-error forms do not have that problem
 // (test_accuracy_against_float64 holds with the same x4 bar as libm).
@@ -124,8 +126,9 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // The weights are WAVE-UNIFORM (every lane evaluates the same nets on its own point) and are read from an LDS copy of the image with
 // broadcast ds_read_b128, 2 per hidden unit.  Round 3 took round 2's "VALU-issue bound at 0.6 busy" apart with four experiments
 // (rocprofv3 kernel stats of tools/kbench_{pcn,cdn}.py in profiles/r03_*; the table is in profiles/NOTES.md):
-//   * a fifth fewer VALU instructions (mask-specialised bodies, tanh / exp at ~19 / 5 instructions instead of libm's ~35 / ~12): the
-//     forward kernels did not move (55.7 vs 53.2 us at configs[3], 18.2 vs 18.3 at 256x256): not VALU issue;
+//   * mask-specialised bodies (no scratch, no select chains) and branch-free tanh / exp (~19 / 5 instructions; libm's are longer but
+//     skip whole branches when a wave agrees): the forward kernels did not move (55.7 vs 53.2 us at configs[3], 18.2 vs 18.3 at
+//     256x256) - and by SQ_INSTS_VALU the instruction count did not fall either (270 vs 246 per wave and flow);
 //   * the scalar data path (image read from HBM through a constant-address-space pointer -> s_load_dwordx4/x8 into SGPRs, RecK below;
 //     no LDS traffic at all): 2-3x SLOWER (coupling-flow forward 64 vs 21.5 us): the scalar cache cannot feed the loop;
 //   * Q = 2 / 4 points per lane (a record read serves Q points; 64-thread blocks so the fewer waves still spread over all CUs):
@@ -206,16 +209,24 @@ __device__ __forceinline__ void nb_pair_forward(const Rec e, int W, const float 
         unit(r[6], r[7]);
     };
     int j = 0;
-    if (W >= 8) {
-        f32x4 ra[8], rb[8];
-        load4(ra, 0);
-        for (; j + 8 <= W; j += 8) {
-            load4(rb, j + 4);
-            __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the arithmetic
-            eval4(ra);
-            load4(ra, j + 8);
-            __builtin_amdgcn_sched_barrier(0);
-            eval4(rb);
+    if constexpr (DU) {   // backward: pipelined (27.6 -> 25.4 us); the forward keeps hipcc's own order (21.5 vs 22.7 us pipelined)
+        if (W >= 8) {
+            f32x4 ra[8], rb[8];
+            load4(ra, 0);
+            for (; j + 8 <= W; j += 8) {
+                load4(rb, j + 4);
+                __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the arithmetic
+                eval4(ra);
+                load4(ra, j + 8);
+                __builtin_amdgcn_sched_barrier(0);
+                eval4(rb);
+            }
+        }
+    } else {
+        for (; j + 4 <= W; j += 4) {
+            f32x4 r[8];
+            load4(r, j);
+            eval4(r);
         }
     }
     for (; j < W; ++j) unit(e.v4(8 * j), e.v4(8 * j + 4));

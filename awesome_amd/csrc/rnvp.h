@@ -251,17 +251,24 @@ __device__ __forceinline__ void rnvp_nets(const Rec rec, int HID, const float (&
         unit(r[6], r[7]);
     };
     int j = 0;
-    if (HID >= 8) {
-        f32x4 ra[8], rb[8];
-        load4(ra, 0);
-        for (; j + 8 <= HID; j += 8) {
-            load4(rb, j + 4);
-            __builtin_amdgcn_sched_barrier(0);
-            eval4(ra);
-            load4(ra, j + 8);
-            __builtin_amdgcn_sched_barrier(0);
-            eval4(rb);
+    if constexpr (DU && NIN + NOUT == 2) {   // the backward's longer arithmetic covers the next batch's LDS latency: pipelined (38.1 -> 28.9 us
+                                             // at 256x256, C = 2).  Not at C = 3: configs[3] runs 4 waves per SIMD and the second register set costs one
+                                             // of them (144 registers; 107.5 vs 106.8 us)
+        if (HID >= 8) {
+            f32x4 ra[8], rb[8];
+            load4(ra, 0);
+            for (; j + 8 <= HID; j += 8) {
+                load4(rb, j + 4);
+                __builtin_amdgcn_sched_barrier(0);
+                eval4(ra);
+                load4(ra, j + 8);
+                __builtin_amdgcn_sched_barrier(0);
+                eval4(rb);
+            }
         }
+    } else {   // hipcc's own order (it also narrows the record reads to what is used): the forward kernels are faster with it
+#pragma unroll 4
+        for (; j < HID; ++j) unit(rec.v4(RNVP_REC * j), rec.v4(RNVP_REC * j + 4));
     }
     for (; j < HID; ++j) unit(rec.v4(RNVP_REC * j), rec.v4(RNVP_REC * j + 4));
 }

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Turn the on-box summaries of tools/profile_r02.sh (gpurun_out/r02_prof/) into the committed profiles/r02_<tag>_* files."""
+"""Turn the on-box summaries of tools/profile_r02.sh / profile_r03.sh (gpurun_out/rNN_prof*/) into the committed profiles/rNN_<tag>_* files.
+
+    python tools/make_profile_summary.py <tag> [<source dir under gpurun_out> [<round>]]      e.g.  ... e r03_prof_e 3"""
 import csv
 import json
 import os
@@ -36,11 +38,20 @@ def stats(path):
 
 
 def main():
+    global SRC
     tag = sys.argv[1] if len(sys.argv) > 1 else "a"
-    shutil.copy(os.path.join(SRC, "bench_line.json"), os.path.join(DST, f"r02_{tag}_bench_line.json"))
+    if len(sys.argv) > 2:
+        SRC = os.path.join(ROOT, "gpurun_out", sys.argv[2])
+    rnd = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    R = f"r{rnd:02d}"
+    if os.path.exists(os.path.join(SRC, "bench_line.json")):
+        shutil.copy(os.path.join(SRC, "bench_line.json"), os.path.join(DST, f"{R}_{tag}_bench_line.json"))
     for src, name, cmd in (("bench", "bench", "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants --throughput-images 0"),
-                           ("pcn", "pcn_fit", "python3 tools/kbench_pcn.py --steps 200"), ("cdn", "cdn_fit", "python3 tools/kbench_cdn.py")):
-        with open(os.path.join(DST, f"r02_{tag}_kernel_stats_{name}.csv"), "w") as f:
+                           ("pcn", "pcn_fit", "python3 tools/kbench_pcn.py --steps 200"), ("cdn", "cdn_fit", "python3 tools/kbench_cdn.py"),
+                           ("joint", "joint_step", "python3 tools/kbench_joint.py")):
+        if not os.path.exists(os.path.join(SRC, f"{src}_kernel_stats.csv")):
+            continue
+        with open(os.path.join(DST, f"{R}_{tag}_kernel_stats_{name}.csv"), "w") as f:
             f.write(f"# rocprofv3 --kernel-trace --stats -- {cmd}   (table from the rocpd file by tools/rocpd_stats.py)\n")
             f.write(open(os.path.join(SRC, f"{src}_kernel_stats.csv")).read())
     # ---- step kernel: traffic + SQ counters
@@ -56,7 +67,7 @@ def main():
     rec = {
         "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_* (three separate passes, no trace domain besides the counters) -- "
                    "python3 bench.py --steps 1 --warmup 0 --epochs 50 --kernel-iters 20 --no-cpu-baseline --throughput-images 0 --no-variants",
-        "round": 2, "kernel": "icnn_step_kernel<130,2,train,relu>", "workload": "1 x 256x256, 256 workgroups x 4 waves",
+        "round": rnd, "kernel": "icnn_step_kernel<130,2,train,relu>", "workload": "1 x 256x256, 256 workgroups x 4 waves",
         "kernel_avg_us_rocprofv3_kernel_trace": round(avg_ns / 1e3, 2),
         "FETCH_SIZE_KB_mean": f_kb, "WRITE_SIZE_KB_mean": w_kb,
         "correction": "MI355X_MICROARCH.md HBM: FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads -> x2; WRITE_SIZE exact",
@@ -77,7 +88,10 @@ def main():
                     "issue stalls = waiting for the matrix pipe, expected when MFMA-bound",
         },
     }
-    json.dump(rec, open(os.path.join(DST, f"r02_{tag}_pmc_step_kernel.json"), "w"), indent=1)
+    json.dump(rec, open(os.path.join(DST, f"{R}_{tag}_pmc_step_kernel.json"), "w"), indent=1)
+    if not os.path.exists(os.path.join(SRC, "pcn_pmc_sq.txt")):
+        print(json.dumps(rec["derived"], indent=1))
+        return
     # ---- RealNVP kernels at configs[3]
     fs, ws, sq = (pmc(os.path.join(SRC, f"pcn_pmc_{c}.txt")) for c in ("FETCH_SIZE", "WRITE_SIZE", "sq"))
     st = stats(os.path.join(SRC, "pcn_kernel_stats.csv"))
@@ -89,7 +103,7 @@ def main():
         "rnvp_bwd_units_kernel<3": (F * HID * 2 * (1 + 1 + 2) * 2, 4 * (F * 3 + F * 1.5)),           # moment sums; ps + the active zs channels in
     }
     out = {"command": "rocprofv3 --kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_* (separate passes) -- python3 tools/kbench_pcn.py --case xyt",
-           "round": 2, "workload": "BASELINE configs[3]: PathConnectedNet C=3, 18 flows x 32 hidden units, 128x128x16 = 262144 points, one optimizer step",
+           "round": rnd, "workload": "BASELINE configs[3]: PathConnectedNet C=3, 18 flows x 32 hidden units, 128x128x16 = 262144 points, one optimizer step",
            "peaks": {"fp32_vector_TFLOPs": 157.3, "hbm_TBs": 8.0}, "kernels": {}}
     for kname, (flop_pt, bytes_pt) in alg.items():
         ns = float(next(v for kk, v in st.items() if kname in kk)["AverageNs"])
@@ -103,10 +117,14 @@ def main():
             "achieved_TBs": round((fb + wb) / ns / 1e3, 3), "frac_of_hbm_peak": round((fb + wb) / ns / 1e3 / 8.0, 4),
             "valu_busy_frac": round(4 * s["SQ_INSTS_VALU"] / 32 / s["SQ_BUSY_CYCLES"], 4),
             "valu_wave_instructions_per_simd": round(s["SQ_INSTS_VALU"] / 32, 1), "lds_wave_instructions_per_simd": round(s["SQ_INSTS_LDS"] / 32, 1),
+            "valu_instructions_per_wave_of_64_points_and_flow": round(s["SQ_INSTS_VALU"] * 32 / (N / 64.0) / F, 1),
+            "lds_instructions_per_wave_of_64_points_and_flow": round(s["SQ_INSTS_LDS"] * 32 / (N / 64.0) / F, 1),
             "waves_per_simd_resident_mean": round(4 * s["SQ_WAVE_CYCLES"] / 32 / s["SQ_BUSY_CYCLES"], 2),
-            "bound": "VALU issue (a wave64 VALU instruction occupies its SIMD for 4 cycles); neither the flop nor the HBM roof is near",
+            "bound": ("VALU issue (a wave64 VALU instruction occupies its SIMD for 4 cycles); neither the flop nor the HBM roof is near" if rnd < 3 else
+                      "latency: neither VALU issue, nor LDS return bandwidth, nor HBM (profiles/NOTES.md, round 3: fewer VALU instructions, the "
+                      "scalar data path and Q points per lane were each measured)"),
         }
-    json.dump(out, open(os.path.join(DST, f"r02_{tag}_pmc_rnvp_kernels.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(DST, f"{R}_{tag}_pmc_rnvp_kernels.json"), "w"), indent=1)
     print(json.dumps(rec["derived"], indent=1))
     print(json.dumps(out["kernels"], indent=1))
 
