@@ -50,6 +50,39 @@ def test_shard_and_gather_world2(n_images):
     assert t == 2.0                                                      # max over ranks
 
 
+def _failing_worker(rank, world, port, q):
+    """The pattern of scripts/run.py: rank-local work in a try block, ONE flag all-reduce before the data collectives, and every rank
+    leaves non-zero when any rank failed (a rank that raised used to strand the others in a collective)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from awesome_amd import parallel
+    r, w, _ = parallel.init(backend="gloo")
+    error = None
+    try:
+        if r == 1:
+            raise ValueError("Loss is nan or inf! (images [3])")
+    except Exception as err:   # noqa: BLE001
+        error = err
+    failed = parallel.any_rank_failed(error is not None)
+    q.put((r, failed))
+    parallel.shutdown()
+    raise SystemExit(1 if failed else 0)
+
+
+def test_a_failing_rank_is_agreed_on_before_the_collectives():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 1          # both ranks exit non-zero, neither hangs
+    assert got == [(0, True), (1, True)]
+
+
 def test_bench_launcher_starts_the_ranks_and_relays_one_line():
     """`python bench.py --gpus 2` with no torch.distributed environment must start 2 ranks itself (torch.distributed.run as a child,
     before any GPU call), run every collective of the bench (barrier, MAX of the time, all_gather of the per-image metric, SUM of
