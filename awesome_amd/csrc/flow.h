@@ -517,14 +517,52 @@ struct FlowUpdArgs {
     int mode;             // 0 = Adam step + effective weights, 1 = gradients only, 2 = effective weights only (prep)
     const int32_t* status;   // per image (mode 0): frozen by a non-finite loss -> no step, like the ICNN and RealNVP updates
     const float* gscale;     // [n_images] factor on every reduced gradient (the joint step's detached clip factor), or null
+    // set when the ICNN update of the same optimizer step runs in the SAME launch (cdn_update_kernel): the loss column of its slabs
+    const float* loss_slabs;   // slab entry "loss" of image 0, workgroup 0 (stride loss_PS per workgroup, loss_wgs * loss_PS per image)
+    int loss_wgs;
+    long long loss_PS;
 };
 
-__device__ __forceinline__ float block_sum256(float v, float* sm) {  // fixed-order sum over a 256-thread block
+// fixed-order sum over the first 256 threads of a block (tid = linear thread index; those 256 threads are waves 0-3)
+__device__ __forceinline__ float block_sum256(float v, float* sm, const int tid) {
     v = sum_over_groups(sum_over_points(v));
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    if ((tid & 63) == 0) sm[tid >> 6] = v;
     __syncthreads();
     return ((sm[0] + sm[1]) + sm[2]) + sm[3];
+}
+__device__ __forceinline__ float block_sum256(float v, float* sm) { return block_sum256(v, sm, threadIdx.x); }
+
+// The loss of one image = the sum of the loss column over its slabs, in the order icnn_update_kernel uses: 16 groups (group g takes the
+// workgroups g, g + 16, ...), then the groups in order.  One definition for every kernel that needs the "non-finite loss" decision.
+constexpr int LOSS_GROUPS = 16;
+__device__ __forceinline__ float loss_column_group_sum(const float* __restrict__ sl, const int wgs, const size_t PS, const int grp) {
+    float lp = 0.f;
+    int w = grp;
+    for (; w + 15 * LOSS_GROUPS < wgs; w += 16 * LOSS_GROUPS) {   // 256 slabs: one trip, 16 loads in flight
+        float q[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) q[k] = sl[(size_t)(w + k * LOSS_GROUPS) * PS];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lp += q[k];
+    }
+    for (; w < wgs; w += LOSS_GROUPS) lp += sl[(size_t)w * PS];
+    return lp;
+}
+
+// "this image takes no optimizer step" exactly as the ICNN update of the same launch decides it: frozen by an earlier step (the flag
+// the PREVIOUS launch wrote, hdr[6 + (t & 1)]) or a non-finite loss now.  Called by the first 256 threads of a block.
+__device__ __forceinline__ bool frozen_in_launch(const float* __restrict__ loss_slabs, const int wgs, const long long PS,
+                                                 const float* __restrict__ hdr0, const long long hdr_stride, const int t, const int img,
+                                                 const int tid) {
+    __shared__ float redl[LOSS_GROUPS];
+    if (tid < LOSS_GROUPS) redl[tid] = loss_column_group_sum(loss_slabs + (size_t)img * wgs * PS, wgs, (size_t)PS, tid);
+    __syncthreads();
+    float loss_now = 0.f;
+#pragma unroll
+    for (int k = 0; k < LOSS_GROUPS; ++k) loss_now += redl[k];
+    const bool bad_before = hdr0 != nullptr && hdr0[(size_t)img * hdr_stride + 6 + (t & 1)] != 0.f;
+    return bad_before || !isfinite(loss_now);
 }
 
 __device__ __forceinline__ float adam_apply(const FlowUpdArgs& u, float gmul, float p, float g, float lr, float wd, float* m_, float* v_) {
@@ -540,17 +578,21 @@ __device__ __forceinline__ float adam_apply(const FlowUpdArgs& u, float gmul, fl
     return __fadd_rn(p, __fdiv_rn(__fmul_rn(-step_size, m), denom));
 }
 
-// grid: x = K*2 coupling nets + 1 (block K*2: scales + linear), y = image; 256 threads
-__global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
+// block nb of image img: coupling net nb (nb < 2K) or the scales + linear (nb == 2K); the first 256 threads of the block
+// (tid = linear thread index).  BATCH = chunk partials requested before the first add (64 needs 192 registers).
+template <int BATCH>
+__device__ __forceinline__ void flow_update_body(const FlowUpdArgs& u, const int nb, const int img, const int tid) {
     __shared__ float sm[4];
-    const int img = blockIdx.y, nb = blockIdx.x, tid = threadIdx.x;
     const float gmul = u.gscale != nullptr ? u.gscale[img] : 1.f;
     const FlowMap& m = u.m;
     // an image the ICNN update of this step has frozen (non-finite loss) takes no optimizer step: its effective weights are rebuilt
-    // from the unchanged parameters.  ONE source of truth with the ICNN update: the "frozen" flag it has just written for step t
-    // into the header's double buffer (hdr[6 + ((t + 1) & 1)], one launch earlier on this stream) - `status` may be NULL.
-    const bool frozen = (u.lr_hdr != nullptr && u.lr_hdr[(size_t)img * u.hdr_stride + 6 + ((u.t + 1) & 1)] != 0.f) ||
-                        (u.status != nullptr && u.status[img] != INR_STATUS_OK);
+    // from the unchanged parameters.  ONE source of truth with the ICNN update: the "frozen" flag it has written for step t
+    // into the header's double buffer (hdr[6 + ((t + 1) & 1)], one launch earlier on this stream; `status` may be NULL) - or, when
+    // that update runs in THIS launch (cdn_update_kernel), the same decision from the same numbers (frozen_in_launch).
+    const bool frozen = (u.mode == 0 && u.loss_slabs != nullptr)
+                            ? frozen_in_launch(u.loss_slabs, u.loss_wgs, u.loss_PS, u.lr_hdr, u.hdr_stride, u.t, img, tid)
+                            : ((u.lr_hdr != nullptr && u.lr_hdr[(size_t)img * u.hdr_stride + 6 + ((u.t + 1) & 1)] != 0.f) ||
+                               (u.status != nullptr && u.status[img] != INR_STATUS_OK));
     const int mode = (u.mode == 0 && frozen) ? 2 : u.mode;
     const int W = m.W, K = m.K;
     float* __restrict__ fp = u.FP + (size_t)img * m.FP;
@@ -573,19 +615,22 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
                 const float* s2 = u.slab2 + (((size_t)img * u.chunks * (K * 2) + nb) * 3) * u.Wp + tid;
                 const size_t cs = (size_t)(K * 2) * 3 * u.Wp;
                 if (u.chunks == 64) {   // the usual count: all partials requested before the first add (a latency chain on 2K + 1 blocks)
-                    float q0[64], q1[64], q2[64];
 #pragma unroll
-                    for (int c = 0; c < 64; ++c) {
-                        const float* q = s2 + c * cs;
-                        q0[c] = q[0];
-                        q1[c] = q[u.Wp];
-                        q2[c] = q[2 * u.Wp];
-                    }
+                    for (int c0 = 0; c0 < 64; c0 += BATCH) {
+                        float q0[BATCH], q1[BATCH], q2[BATCH];
 #pragma unroll
-                    for (int c = 0; c < 64; ++c) {
-                        dw1 += q0[c];
-                        db1 += q1[c];
-                        dw2 += q2[c];
+                        for (int c = 0; c < BATCH; ++c) {
+                            const float* q = s2 + (c0 + c) * cs;
+                            q0[c] = q[0];
+                            q1[c] = q[u.Wp];
+                            q2[c] = q[2 * u.Wp];
+                        }
+#pragma unroll
+                        for (int c = 0; c < BATCH; ++c) {
+                            dw1 += q0[c];
+                            db1 += q1[c];
+                            dw2 += q2[c];
+                        }
                     }
                 } else {
 #pragma unroll 16
@@ -601,11 +646,11 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
             {
                 float part = 0.f;
                 for (int b = tid; b < u.blocks1; b += 256) part += u.slab1[((size_t)img * u.blocks1 + b) * u.S1 + (1 + net) * K + i];
-                db2 = block_sum256(part, sm);
+                db2 = block_sum256(part, sm, tid);
             }
             // weight norm (dim=None): w = g v / n  =>  dg = <dw, v> / n ;  dv = g/n (dw - v <dw, v> / n^2)
-            const float n1 = sqrtf(block_sum256(v1 * v1, sm)), n2 = sqrtf(block_sum256(v2 * v2, sm));
-            const float dot1 = block_sum256(dw1 * v1, sm), dot2 = block_sum256(dw2 * v2, sm);
+            const float n1 = sqrtf(block_sum256(v1 * v1, sm, tid)), n2 = sqrtf(block_sum256(v2 * v2, sm, tid));
+            const float dot1 = block_sum256(dw1 * v1, sm, tid), dot2 = block_sum256(dw2 * v2, sm, tid);
             const float dg1 = dot1 / n1, dg2 = dot2 / n2;
             const float dv1 = g1 / n1 * (dw1 - v1 * dot1 / (n1 * n1)), dv2 = g2 / n2 * (dw2 - v2 * dot2 / (n2 * n2));
             if (mode == 1) {
@@ -645,9 +690,9 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
             }
         }
         // effective weights for the next forward
-        const float n1 = sqrtf(block_sum256(v1 * v1, sm)), n2 = sqrtf(block_sum256(v2 * v2, sm));
+        const float n1 = sqrtf(block_sum256(v1 * v1, sm, tid)), n2 = sqrtf(block_sum256(v2 * v2, sm, tid));
         const float w1e = v1 * (g1 / n1), w2e = v2 * (g2 / n2);   // 0 for the threads past W
-        const float sa = block_sum256(w2e * w1e, sm), sb = block_sum256(w2e * b1, sm);
+        const float sa = block_sum256(w2e * w1e, sm, tid), sb = block_sum256(w2e * b1, sm, tid);
         if (on) {
             const float w2p = (1.f - m.slope) * w2e;
             fe[eb + 8 * tid] = w1e;
@@ -668,7 +713,7 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
             if (k >= K && k < 3 * K) continue;   // db2 sums belong to the coupling-net blocks
             float part = 0.f;
             for (int b = tid; b < u.blocks1; b += 256) part += u.slab1[((size_t)img * u.blocks1 + b) * u.S1 + k];
-            const float t = block_sum256(part, sm);
+            const float t = block_sum256(part, sm, tid);
             if (tid == 0) tot[k] = t;
         }
         __syncthreads();
@@ -705,5 +750,8 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) {
         if (mode != 1) fe[k] = p;
     }
 }
+
+// grid: x = K*2 coupling nets + 1 (block K*2: scales + linear), y = image; 256 threads
+__global__ __launch_bounds__(256) void flow_update_kernel(const FlowUpdArgs u) { flow_update_body<64>(u, blockIdx.x, blockIdx.y, threadIdx.x); }
 
 }  // namespace

@@ -108,35 +108,40 @@ constexpr int UPD_GROUPS = 16;       // slab groups summed in parallel, then com
 // Parameters per block: a CU pulls ~10 B/clock from memory whatever runs on it, so the reduction is as fast as its busiest
 // CU: one block per CU, all equally long (17 814 parameters -> 248 blocks of 72), instead of 279 blocks of 64 with 23 CUs
 // doing double duty.  Multiple of 4 (float4 loads), x n_images blocks when there are many images.
-inline int upd_params_per_block(int cols) {   // cols = slab columns in use (P + 1 in the parameter-ordered layout)
-    int ppb = ((cols + 255) / 256 + 3) / 4 * 4;
+// `reserve` = CUs left to other blocks of the same launch (the deformation's update in cdn_/pcn_update_kernel).
+inline int upd_params_per_block(int cols, int reserve = 0) {   // cols = slab columns in use (P + 1 in the parameter-ordered layout)
+    const int cus = 256 - reserve;
+    int ppb = ((cols + cus - 1) / cus + 3) / 4 * 4;
     if (ppb < 16) ppb = 16;
     if (ppb > UPD_MAX_PARAMS) ppb = UPD_MAX_PARAMS;
     return ppb;
 }
-inline dim3 upd_grid(int cols, int n_images) { const int ppb = upd_params_per_block(cols); return dim3((cols + ppb - 1) / ppb, n_images); }
-inline dim3 upd_block(int cols) { return dim3(upd_params_per_block(cols) / 4, UPD_GROUPS); }
+inline dim3 upd_grid(int cols, int n_images, int reserve = 0) {
+    const int ppb = upd_params_per_block(cols, reserve);
+    return dim3((cols + ppb - 1) / ppb, n_images);
+}
+inline dim3 upd_block(int cols, int reserve = 0) { return dim3(upd_params_per_block(cols, reserve) / 4, UPD_GROUPS); }
 
 #if INR_STAMPS
 __device__ unsigned long long g_updtimes[512][4];   // per block of the LAST update launch, s_memrealtime (100 MHz): entry, slab loads back, reduced, stores done
 #define UPD_STAMP(k)                                                                                          \
-    if (threadIdx.x == 0 && threadIdx.y == 0 && blockIdx.y == 0 && blockIdx.x < 512) {                        \
+    if (threadIdx.x == 0 && threadIdx.y == 0 && img == 0 && bx < 512) {                                       \
         __builtin_amdgcn_s_waitcnt(0);                                                                        \
-        g_updtimes[blockIdx.x][k] = __builtin_amdgcn_s_memrealtime();                                         \
+        g_updtimes[bx][k] = __builtin_amdgcn_s_memrealtime();                                                 \
     }
 #else
 #define UPD_STAMP(k)
 #endif
-// block = (blockDim.x lanes x float4 = ppb parameters) x 16 slab groups
-__global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_kernel(const UpdArgs u) {
-    const int img = blockIdx.y;
+// block = (blockDim.x lanes x float4 = ppb parameters) x 16 slab groups; bx = the block's index along the slab columns
+static_assert(UPD_GROUPS == LOSS_GROUPS, "the loss column is summed in the update's group order");
+__device__ __forceinline__ void icnn_update_body(const UpdArgs& u, const int bx, const int img) {
     const int tx = threadIdx.x, grp = threadIdx.y;
     const int ppb = 4 * blockDim.x;
     __shared__ float red[UPD_GROUPS][UPD_MAX_PARAMS];
     __shared__ float redl[UPD_GROUPS];     // this step's loss partials (every block sums them: see `frozen` below)
     UPD_STAMP(0);
     const int jl = grp * blockDim.x + tx;  // the first ppb threads finish one slab column = one parameter each
-    const int j = jl < ppb ? slab_param_of_col(u.img, blockIdx.x * ppb + jl) : -1;   // flat parameter index (kernel shape), P = loss, -1 = none
+    const int j = jl < ppb ? slab_param_of_col(u.img, bx * ppb + jl) : -1;   // flat parameter index (kernel shape), P = loss, -1 = none
     const int ju = (j >= 0 && j < u.P) ? user_param_index(u.img, u.hu, j) : -1;       // ... in the caller's layout; -1: padding (gradient exactly 0)
     // The kernel is one dependent chain (slabs -> LDS -> optimizer -> stores) and at one image it is latency, not bandwidth,
     // that it pays for: everything the tail needs is requested up front, and all slab rows of a thread are in flight at once.
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
         }
     }
     {
-        const int j4 = blockIdx.x * ppb + 4 * tx;
+        const int j4 = bx * ppb + 4 * tx;
         f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
         if (j4 < u.PS && slab_param_of_col(u.img, j4) >= 0) {   // (a lane's 4 tile registers are parameters or padding together)
             const float* __restrict__ sl = u.slabs + (size_t)img * u.wgs * u.PS + j4;
@@ -170,18 +175,7 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
         }
         *(f32x4*)&red[grp][4 * tx] = part;
         if (u.mode == 0 && tx == 0) {   // the loss column (slab entry P), summed in the same order as any parameter column
-            const float* __restrict__ sl = u.slabs + (size_t)img * u.wgs * u.PS + (u.img.sl_cols - 1);
-            float lp = 0.f;
-            int w = grp;
-            for (; w + 15 * UPD_GROUPS < u.wgs; w += 16 * UPD_GROUPS) {
-                float q[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) q[k] = sl[(size_t)(w + k * UPD_GROUPS) * u.PS];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) lp += q[k];
-            }
-            for (; w < u.wgs; w += UPD_GROUPS) lp += sl[(size_t)w * u.PS];
-            redl[grp] = lp;
+            redl[grp] = loss_column_group_sum(u.slabs + (size_t)img * u.wgs * u.PS + (u.img.sl_cols - 1), u.wgs, (size_t)u.PS, grp);
         }
     }
     UPD_STAMP(1);
@@ -282,6 +276,42 @@ __global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_k
     st[ju] = m;
     st[u.Pu + ju] = v;
     UPD_STAMP(3);
+}
+
+__global__ __launch_bounds__(UPD_MAX_PARAMS / 4 * UPD_GROUPS) void icnn_update_kernel(const UpdArgs u) { icnn_update_body(u, blockIdx.x, blockIdx.y); }
+
+// Both optimizer updates of a composite step (ICNN + its deformation) in ONE launch.  They are independent - the ICNN update reads the
+// step kernel's slabs, the deformation's update the unit / point slabs of its backward kernels - and each alone is a latency chain that
+// leaves most of the chip idle (the flow / RealNVP update has 2K + 1 / F + 1 blocks): blocks [0, nbi) of a grid row are the ICNN
+// update's, the rest the deformation's (its 256 threads = the first four waves of the block; the other waves leave at once, which
+// s_barrier allows).  A CU holds one of these blocks (12 waves at up to 168 registers), so the ICNN update leaves the deformation's
+// blocks their own CUs (`reserve` of upd_params_per_block): measured with 248 + 13 blocks the two parts ran one after the other.  Same arithmetic in the same order as the two separate kernels; the deformation's blocks take the "frozen by a
+// non-finite loss" decision from the slabs themselves (frozen_in_launch) instead of the flag the ICNN update writes.
+constexpr int UPD_UNION_MAX_THREADS = 768;   // 12 waves: three per SIMD, 168 registers each
+__global__ __launch_bounds__(UPD_UNION_MAX_THREADS) void cdn_update_kernel(const UpdArgs ui, const FlowUpdArgs uf, const int nbi) {
+    if ((int)blockIdx.x < nbi) {
+        icnn_update_body(ui, blockIdx.x, blockIdx.y);
+        return;
+    }
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    if (tid >= 256) return;
+    flow_update_body<32>(uf, (int)blockIdx.x - nbi, blockIdx.y, tid);
+}
+template <int C>
+__global__ __launch_bounds__(UPD_UNION_MAX_THREADS) void pcn_update_kernel(const UpdArgs ui, const RnvpUpdArgs ur, const int nbi) {
+    if ((int)blockIdx.x < nbi) {
+        icnn_update_body(ui, blockIdx.x, blockIdx.y);
+        return;
+    }
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    if (tid >= 256) return;
+    rnvp_update_body<C>(ur, (int)blockIdx.x - nbi, blockIdx.y, tid);
+}
+inline bool upd_union_ok(int cols, int reserve) {   // the ICNN update's block must hold the deformation update's 256 threads
+    const dim3 b = upd_block(cols, reserve);
+    const int n = (int)(b.x * b.y);
+    static const bool off = getenv("INRFIT_SPLIT_UPDATES") != nullptr;   // measurement switch: the two launches of round 2
+    return !off && n >= 256 && n <= UPD_UNION_MAX_THREADS;
 }
 
 // params -> parameter image: constant background (zeros, ext-input constants), then every parameter into its slot(s)
@@ -1134,9 +1164,8 @@ CdnWs carve_cdn(const KernelEntry* e, const InrFlowDesc* f, const InrGridDesc* g
     return w;
 }
 
-void launch_flow_update(const CdnWs& w, const InrFlowDesc* f, int n_images, int mode, float* FP, float* opt, float* grads_out,
-                        const InrOptDesc* od, float wd_g, int t, const float* lr_hdr, long long hdr_stride, hipStream_t s,
-                        const int32_t* status = nullptr, const float* gscale = nullptr) {
+FlowUpdArgs make_flow_upd_args(const CdnWs& w, int mode, float* FP, float* opt, float* grads_out, const InrOptDesc* od, float wd_g, int t,
+                               const float* lr_hdr, long long hdr_stride, const int32_t* status = nullptr, const float* gscale = nullptr) {
     FlowUpdArgs u{};
     u.status = status;
     u.gscale = gscale;
@@ -1163,7 +1192,25 @@ void launch_flow_update(const CdnWs& w, const InrFlowDesc* f, int n_images, int 
     }
     u.wd_g = wd_g;
     u.mode = mode;
+    return u;
+}
+
+void launch_flow_update(const CdnWs& w, const InrFlowDesc* f, int n_images, int mode, float* FP, float* opt, float* grads_out,
+                        const InrOptDesc* od, float wd_g, int t, const float* lr_hdr, long long hdr_stride, hipStream_t s,
+                        const int32_t* status = nullptr, const float* gscale = nullptr) {
+    const FlowUpdArgs u = make_flow_upd_args(w, mode, FP, opt, grads_out, od, wd_g, t, lr_hdr, hdr_stride, status, gscale);
     hipLaunchKernelGGL(flow_update_kernel, dim3(2 * f->num_coupling + 1, n_images), dim3(256), 0, s, u);
+}
+
+// the ICNN update `ui` and the flow's optimizer step in one launch (cdn_update_kernel)
+void launch_cdn_update(const KernelEntry* e, const UpdArgs& ui, FlowUpdArgs uf, const InrFlowDesc* f, int n_images, hipStream_t s) {
+    const int nbf = 2 * f->num_coupling + 1;
+    const dim3 gi = upd_grid(e->img.sl_cols, n_images, nbf);
+    uf.status = nullptr;
+    uf.loss_slabs = ui.slabs + (e->img.sl_cols - 1);
+    uf.loss_wgs = ui.wgs;
+    uf.loss_PS = ui.PS;
+    hipLaunchKernelGGL(cdn_update_kernel, dim3(gi.x + nbf, n_images), upd_block(e->img.sl_cols, nbf), 0, s, ui, uf, (int)gi.x);
 }
 
 void launch_flow_fwd(const CdnWs& w, const InrGridDesc* grid, int n_images, float* out, hipStream_t s) {
@@ -1362,11 +1409,17 @@ int inrfit_cdn_fit(const InrModelDesc* model, const InrFlowDesc* flow, float* ic
         u.bc1 = 1.0 - pow((double)opt->beta1, (double)u.t);
         u.bc2_sqrt = (float)sqrt(1.0 - pow((double)opt->beta2, (double)u.t));
         u.hist_idx = it;
-        hipLaunchKernelGGL(icnn_update_kernel, ugrid, ublock, 0, s, u);
-        launch_flow_bwd(w, flow, grid, n_images, s);
-        // the learning rate of THIS step sits in header[t & 1] (the plateau thread wrote the next one into the other slot)
-        launch_flow_update(w, flow, n_images, 0, flow_params, flow_opt_state, nullptr, opt, wd_on_weight_g, u.t,
-                           icnn_opt_state + 2 * (size_t)w.icnn.Pu, hdr_stride, s, status);
+        // the learning rate of THIS step sits in header[t & 1] (the plateau thread writes the next one into the other slot)
+        if (upd_union_ok(e->img.sl_cols, 2 * flow->num_coupling + 1)) {
+            launch_flow_bwd(w, flow, grid, n_images, s);
+            launch_cdn_update(e, u, make_flow_upd_args(w, 0, flow_params, flow_opt_state, nullptr, opt, wd_on_weight_g, u.t,
+                                                       icnn_opt_state + 2 * (size_t)w.icnn.Pu, hdr_stride), flow, n_images, s);
+        } else {
+            hipLaunchKernelGGL(icnn_update_kernel, ugrid, ublock, 0, s, u);
+            launch_flow_bwd(w, flow, grid, n_images, s);
+            launch_flow_update(w, flow, n_images, 0, flow_params, flow_opt_state, nullptr, opt, wd_on_weight_g, u.t,
+                               icnn_opt_state + 2 * (size_t)w.icnn.Pu, hdr_stride, s, status);
+        }
     }
     if (hipGetLastError() != hipSuccess) return INR_ELAUNCH;
     if (final_logits && !gate_logits) {
@@ -1602,6 +1655,18 @@ RnvpUpdArgs make_rnvp_upd_args(const PcnWs& w, int n_images, int mode, float* rp
     return u;
 }
 
+// the ICNN update `ui` and the RealNVP's optimizer step in one launch (pcn_update_kernel)
+void launch_pcn_update(const KernelEntry* e, const PcnWs& w, const UpdArgs& ui, RnvpUpdArgs ur, int n_images, hipStream_t s) {
+    const int nbf = w.rm.F + 1;
+    const dim3 gi = upd_grid(e->img.sl_cols, n_images, nbf), g(gi.x + nbf, n_images), b = upd_block(e->img.sl_cols, nbf);
+    ur.status = nullptr;
+    ur.loss_slabs = ui.slabs + (e->img.sl_cols - 1);
+    ur.loss_wgs = ui.wgs;
+    ur.loss_PS = ui.PS;
+    if (w.rm.C == 2) hipLaunchKernelGGL(pcn_update_kernel<2>, g, b, 0, s, ui, ur, (int)gi.x);
+    else hipLaunchKernelGGL(pcn_update_kernel<3>, g, b, 0, s, ui, ur, (int)gi.x);
+}
+
 void launch_rnvp_update_args(const PcnWs& w, int n_images, const RnvpUpdArgs& u, hipStream_t s) {
     const dim3 g(w.rm.F + 1, n_images);
     if (w.rm.C == 2) hipLaunchKernelGGL(rnvp_update_kernel<2>, g, dim3(256), 0, s, u);
@@ -1815,13 +1880,18 @@ int inrfit_pcn_fit(const InrModelDesc* model, const InrRnvpDesc* rnvp, float* ic
         u.bc1 = 1.0 - pow((double)opt->beta1, (double)u.t);
         u.bc2_sqrt = (float)sqrt(1.0 - pow((double)opt->beta2, (double)u.t));
         u.hist_idx = it;
-        hipLaunchKernelGGL(icnn_update_kernel, ugrid, ublock, 0, s, u);
-        launch_rnvp_bwd(w, flow_params, grid, n_images, s);
-        // the learning rate of THIS step sits in header[t & 1] (the plateau thread wrote the next one into the other slot)
+        // the learning rate of THIS step sits in header[t & 1] (the plateau thread writes the next one into the other slot)
         RnvpUpdArgs ru = make_rnvp_upd_args(w, n_images, 0, flow_params, flow_opt_state, nullptr, opt, flow_weight_decay, u.t,
                                             icnn_opt_state + 2 * (size_t)w.icnn.Pu, hdr_stride, status);
         ru.RE = w.RE;
-        launch_rnvp_update_args(w, n_images, ru, s);
+        if (upd_union_ok(e->img.sl_cols, w.rm.F + 1)) {
+            launch_rnvp_bwd(w, flow_params, grid, n_images, s);
+            launch_pcn_update(e, w, u, ru, n_images, s);
+        } else {
+            hipLaunchKernelGGL(icnn_update_kernel, ugrid, ublock, 0, s, u);
+            launch_rnvp_bwd(w, flow_params, grid, n_images, s);
+            launch_rnvp_update_args(w, n_images, ru, s);
+        }
     }
     if (hipGetLastError() != hipSuccess) return INR_ELAUNCH;
     if (final_logits && !gate_logits) {
@@ -2096,12 +2166,17 @@ int inrfit_pcn_joint_step(const InrModelDesc* model, const InrRnvpDesc* rnvp, fl
     u.slabs = w.icnn.slabs;
     u.gscale = c.gscale;
     set_step_consts(u, &o, step);
-    hipLaunchKernelGGL(icnn_update_kernel, upd_grid(e->img.sl_cols, 1), upd_block(e->img.sl_cols), 0, s, u);
-    launch_rnvp_bwd(w, flow_params, grid, 1, s);
     RnvpUpdArgs ru = make_rnvp_upd_args(w, 1, 0, flow_params, flow_opt_state, nullptr, &o, flow_weight_decay, step, hdr,
                                         2 * (long long)w.icnn.Pu + INR_OPT_HEADER_FLOATS, status);
     ru.gscale = c.gscale;
-    launch_rnvp_update_args(w, 1, ru, s);
+    if (upd_union_ok(e->img.sl_cols, w.rm.F + 1)) {
+        launch_rnvp_bwd(w, flow_params, grid, 1, s);
+        launch_pcn_update(e, w, u, ru, 1, s);
+    } else {
+        hipLaunchKernelGGL(icnn_update_kernel, upd_grid(e->img.sl_cols, 1), upd_block(e->img.sl_cols), 0, s, u);
+        launch_rnvp_bwd(w, flow_params, grid, 1, s);
+        launch_rnvp_update_args(w, 1, ru, s);
+    }
     joint_dseg(c, dseg, s);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
@@ -2138,10 +2213,17 @@ int inrfit_cdn_joint_step(const InrModelDesc* model, const InrFlowDesc* flow, fl
     u.slabs = w.icnn.slabs;
     u.gscale = c.gscale;
     set_step_consts(u, &o, step);
-    hipLaunchKernelGGL(icnn_update_kernel, upd_grid(e->img.sl_cols, 1), upd_block(e->img.sl_cols), 0, s, u);
-    launch_flow_bwd(w, flow, grid, 1, s);
-    launch_flow_update(w, flow, 1, 0, flow_params, flow_opt_state, nullptr, &o, wd_on_weight_g, step, hdr,
-                       2 * (long long)w.icnn.Pu + INR_OPT_HEADER_FLOATS, s, status, c.gscale);
+    const long long hdr_stride = 2 * (long long)w.icnn.Pu + INR_OPT_HEADER_FLOATS;
+    if (upd_union_ok(e->img.sl_cols, 2 * flow->num_coupling + 1)) {
+        launch_flow_bwd(w, flow, grid, 1, s);
+        launch_cdn_update(e, u, make_flow_upd_args(w, 0, flow_params, flow_opt_state, nullptr, &o, wd_on_weight_g, step, hdr, hdr_stride,
+                                                   nullptr, c.gscale), flow, 1, s);
+    } else {
+        hipLaunchKernelGGL(icnn_update_kernel, upd_grid(e->img.sl_cols, 1), upd_block(e->img.sl_cols), 0, s, u);
+        launch_flow_bwd(w, flow, grid, 1, s);
+        launch_flow_update(w, flow, 1, 0, flow_params, flow_opt_state, nullptr, &o, wd_on_weight_g, step, hdr, hdr_stride, s, status,
+                           c.gscale);
+    }
     joint_dseg(c, dseg, s);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }

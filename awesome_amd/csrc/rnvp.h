@@ -117,15 +117,15 @@ __device__ __forceinline__ float minmax_fwd(float v, float lo, float hi, float n
 // flat parameters of one image -> the image the kernels read from LDS (records by flow; only the active rows/columns of
 // every flow's MLPs): header, then one block of `fl` floats per flow
 template <int C>
-__device__ __forceinline__ void rnvp_header_image(const float* __restrict__ rp, float* dst) {
-    for (int i = threadIdx.x; i < RNVP_HDR; i += blockDim.x) dst[i] = i < 3 ? (i < C ? rp[i] : 0.f) : (i < 6 ? (i - 3 < C ? rp[C + i - 3] : 0.f) : 0.f);
+__device__ __forceinline__ void rnvp_header_image(const float* __restrict__ rp, float* dst, int tid, int nt) {
+    for (int i = tid; i < RNVP_HDR; i += nt) dst[i] = i < 3 ? (i < C ? rp[i] : 0.f) : (i < 6 ? (i - 3 < C ? rp[C + i - 3] : 0.f) : 0.f);
 }
 
 template <int C>
-__device__ __forceinline__ void rnvp_flow_image(const float* __restrict__ rp, float* dst, const RnvpMap& m, int f) {
+__device__ __forceinline__ void rnvp_flow_image(const float* __restrict__ rp, float* dst, const RnvpMap& m, int f, int tid, int nt) {
     const FlowIdx x = flow_idx<C>(m.masks[f]);
     const float* __restrict__ pf = rp + 2 * C + (size_t)f * m.pf;
-    for (int i = threadIdx.x; i < m.HID * RNVP_REC; i += blockDim.x) {
+    for (int i = tid; i < m.HID * RNVP_REC; i += nt) {
         const int j = i >> 3, slot = i & 7, q = slot >> 1;
         const float* __restrict__ pn = pf + (slot & 1) * m.net;
         float v = 0.f;
@@ -134,7 +134,7 @@ __device__ __forceinline__ void rnvp_flow_image(const float* __restrict__ rp, fl
         else if (q < x.nin + 1 + x.nout) v = pn[m.HID * C + m.HID + x.out(q - x.nin - 1) * m.HID + j];
         dst[i] = v;
     }
-    for (int i = threadIdx.x; i < RNVP_TAIL; i += blockDim.x) {
+    for (int i = tid; i < RNVP_TAIL; i += nt) {
         float v = 0.f;
         if (i < 4) {
             const int k = i >> 1;
@@ -146,6 +146,13 @@ __device__ __forceinline__ void rnvp_flow_image(const float* __restrict__ rp, fl
         }
         dst[m.HID * RNVP_REC + i] = v;
     }
+}
+
+template <int C>
+__device__ __forceinline__ void rnvp_header_image(const float* __restrict__ rp, float* dst) { rnvp_header_image<C>(rp, dst, threadIdx.x, blockDim.x); }
+template <int C>
+__device__ __forceinline__ void rnvp_flow_image(const float* __restrict__ rp, float* dst, const RnvpMap& m, int f) {
+    rnvp_flow_image<C>(rp, dst, m, f, threadIdx.x, blockDim.x);
 }
 
 // header + flows [f0, f1) into LDS
@@ -822,6 +829,10 @@ struct RnvpUpdArgs {
     float* RE;            // [n_images][LDSF] packed image to refresh after the step (mode 0), or null
     int unit_linear;      // header of RE with a = 1, b = 0 (learn_flow_identity)
     const float* gscale;  // [n_images] factor on every reduced gradient (the joint step's detached clip factor), or null
+    // set when the ICNN update of the same optimizer step runs in the SAME launch (pcn_update_kernel): the loss column of its slabs
+    const float* loss_slabs;   // slab entry "loss" of image 0, workgroup 0 (stride loss_PS per workgroup, loss_wgs * loss_PS per image)
+    int loss_wgs;
+    long long loss_PS;
 };
 
 __device__ __forceinline__ float opt_apply(const RnvpUpdArgs& u, float gmul, float p, float g, float lr, float wd, float* m_, float* v_) {
@@ -843,18 +854,20 @@ __device__ __forceinline__ float opt_apply(const RnvpUpdArgs& u, float gmul, flo
     return p;
 }
 
-// grid: x = F flows + 1 (the linear), y = image; 256 threads
+// block f of image img: flow f (f < F) or the linear (f == F); the first 256 threads of the block (tid = linear thread index)
 template <int C>
-__global__ __launch_bounds__(256) void rnvp_update_kernel(const RnvpUpdArgs u) {
+__device__ __forceinline__ void rnvp_update_body(const RnvpUpdArgs& u, const int f, const int img, const int tid) {
     __shared__ float sm[4];
     __shared__ float tot[4 * 3 + 2 * 3];
-    const int img = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
     const float gmul = u.gscale != nullptr ? u.gscale[img] : 1.f;
     const RnvpMap& m = u.m;
     const int F = m.F, HID = m.HID;
-    // one source of truth with the ICNN update: the flag it has just written for step t (hdr[6 + ((t + 1) & 1)]); `status` may be NULL
-    const bool frozen = (u.lr_hdr != nullptr && u.lr_hdr[(size_t)img * u.hdr_stride + 6 + ((u.t + 1) & 1)] != 0.f) ||
-                        (u.status != nullptr && u.status[img] != INR_STATUS_OK);
+    // one source of truth with the ICNN update: the flag it has written for step t (hdr[6 + ((t + 1) & 1)]; `status` may be NULL) -
+    // or, when that update runs in THIS launch (pcn_update_kernel), the same decision from the same numbers (frozen_in_launch)
+    const bool frozen = u.loss_slabs != nullptr
+                            ? frozen_in_launch(u.loss_slabs, u.loss_wgs, u.loss_PS, u.lr_hdr, u.hdr_stride, u.t, img, tid)
+                            : ((u.lr_hdr != nullptr && u.lr_hdr[(size_t)img * u.hdr_stride + 6 + ((u.t + 1) & 1)] != 0.f) ||
+                               (u.status != nullptr && u.status[img] != INR_STATUS_OK));
     float* __restrict__ rp = u.RP + (size_t)img * m.RP;
     float* __restrict__ om = u.opt ? u.opt + (size_t)img * 2 * m.RP : nullptr;
     float* __restrict__ ov = om ? om + m.RP : nullptr;
@@ -868,7 +881,22 @@ __global__ __launch_bounds__(256) void rnvp_update_kernel(const RnvpUpdArgs u) {
         float part[4 * C];
 #pragma unroll
         for (int k = 0; k < 4 * C; ++k) part[k] = 0.f;
-        for (int b = tid; b < u.blocks1; b += 256) {
+        int b = tid;
+        for (; b + 768 < u.blocks1; b += 1024) {   // four rows in flight (262 144 points = 1024 point blocks = one trip); same order of adds
+            float v[4][4 * C];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* __restrict__ row = u.slab1 + ((size_t)img * u.blocks1 + b + 256 * r) * u.S1 + k0;
+#pragma unroll
+                for (int k = 0; k < 4 * C; ++k) v[r][k] = k < nk ? row[k] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 4 * C; ++k)
+                    if (k < nk) part[k] += v[r][k];
+        }
+        for (; b < u.blocks1; b += 256) {
             const float* __restrict__ row = u.slab1 + ((size_t)img * u.blocks1 + b) * u.S1 + k0;
 #pragma unroll
             for (int k = 0; k < 4 * C; ++k)
@@ -886,21 +914,24 @@ __global__ __launch_bounds__(256) void rnvp_update_kernel(const RnvpUpdArgs u) {
     if (f == F && u.lossp != nullptr) {
         float part = 0.f;
         for (int b = tid; b < u.lossp_blocks; b += 256) part += u.lossp[(size_t)img * u.lossp_blocks + b];
-        const float t = block_sum256(part, sm);
+        const float t = block_sum256(part, sm, tid);
         if (tid == 0 && u.loss_hist) u.loss_hist[(size_t)img * u.hist_stride + u.hist_idx] = t * u.loss_scale;
     }
     if (f == F && u.skip_linear) {
         if (u.mode == 0 && u.RE != nullptr) {
             float* re = u.RE + (size_t)img * m.LDSF;
-            rnvp_header_image<C>(rp, re);
+            rnvp_header_image<C>(rp, re, tid, 256);
             if (u.unit_linear && tid < 6) re[tid] = tid < 3 ? (tid < C ? 1.f : 0.f) : 0.f;
         }
         return;
     }
     const int base = f < F ? 2 * C + f * m.pf : 0;
     const int count = f < F ? m.pf : 2 * C;
-    for (int i = tid; i < count; i += 256) {
-        float g;
+    // where parameter i's gradient comes from: the sum of its unit-slab partials over the chunks (s2), or a point-scalar total (g)
+    const size_t cs = (size_t)(F * 2) * (2 * C + 1) * m.HIDp;
+    auto source = [&](const int i, const float*& s2, float& g) {
+        s2 = nullptr;
+        g = 0.f;
         if (f == F) {
             g = tot[i];   // a[C] | b[C]
         } else if (i >= 2 * m.net) {
@@ -912,41 +943,74 @@ __global__ __launch_bounds__(256) void rnvp_update_kernel(const RnvpUpdArgs u) {
             else if (r < HID * C + HID) { j = r - HID * C; row = C; }                 // b1[j]
             else if (r < 2 * HID * C + HID) { const int q = r - HID * C - HID; row = C + 1 + q / HID; j = q - (q / HID) * HID; }   // W2[c][j]
             else { row = -1; j = r - (2 * HID * C + HID); }                           // b2[c]
-            if (row < 0) {
-                g = tot[net * C + j];
-            } else {
-                g = 0.f;
-                const float* s2 = u.slab2 + ((((size_t)img * u.chunks) * (F * 2) + f * 2 + net) * (2 * C + 1) + row) * m.HIDp + j;
-                const size_t cs = (size_t)(F * 2) * (2 * C + 1) * m.HIDp;
-                if (u.chunks == 64) {   // the usual count: every chunk's partial requested before the first add (this kernel is a
-                    float q[64];        // latency chain on F + 1 blocks; `#pragma unroll 64` on the runtime bound falls back to a scalar loop)
-#pragma unroll
-                    for (int c = 0; c < 64; ++c) q[c] = s2[c * cs];
-#pragma unroll
-                    for (int c = 0; c < 64; ++c) g += q[c];
-                } else {
-#pragma unroll 8
-                    for (int c = 0; c < u.chunks; ++c) g += s2[c * cs];
-                }
-            }
+            if (row < 0) g = tot[net * C + j];
+            else s2 = u.slab2 + ((((size_t)img * u.chunks) * (F * 2) + f * 2 + net) * (2 * C + 1) + row) * m.HIDp + j;
         }
+    };
+    auto apply = [&](const int i, const float g) {
         if (u.mode == 1) {
             go[base + i] = g;
         } else if (!frozen && isfinite(g)) {
             rp[base + i] = opt_apply(u, gmul, rp[base + i], g, lr, f < F ? u.wd_flow : 0.f, &om[base + i], &ov[base + i]);
         }
+    };
+    // This kernel is a latency chain on F + 1 blocks: a thread's (up to) two parameters are fetched together, and with the usual 64
+    // chunks every partial is requested before the first add (`#pragma unroll 64` on the runtime bound falls back to a scalar loop).
+    for (int i0 = tid; i0 < count; i0 += 512) {
+        const int i1 = i0 + 256;
+        const bool has1 = i1 < count;
+        const float *sa, *sb = nullptr;
+        float ga, gb = 0.f;
+        source(i0, sa, ga);
+        if (has1) source(i1, sb, gb);
+        if (u.chunks == 64) {
+            float qa[64], qb[64];
+            if (sa != nullptr) {
+#pragma unroll
+                for (int c = 0; c < 64; ++c) qa[c] = sa[c * cs];
+            }
+            if (sb != nullptr) {
+#pragma unroll
+                for (int c = 0; c < 64; ++c) qb[c] = sb[c * cs];
+            }
+            if (sa != nullptr) {
+#pragma unroll
+                for (int c = 0; c < 64; ++c) ga += qa[c];
+            }
+            if (sb != nullptr) {
+#pragma unroll
+                for (int c = 0; c < 64; ++c) gb += qb[c];
+            }
+        } else {
+            if (sa != nullptr) {
+#pragma unroll 8
+                for (int c = 0; c < u.chunks; ++c) ga += sa[c * cs];
+            }
+            if (sb != nullptr) {
+#pragma unroll 8
+                for (int c = 0; c < u.chunks; ++c) gb += sb[c * cs];
+            }
+        }
+        apply(i0, ga);
+        if (has1) apply(i1, gb);
     }
     if (u.mode == 0 && u.RE != nullptr) {
         // the next forward's packed image, straight from the parameters this block has just written (one launch less per step)
         __syncthreads();
         float* re = u.RE + (size_t)img * m.LDSF;
         if (f < F) {
-            rnvp_flow_image<C>(rp, re + RNVP_HDR + f * m.fl, m, f);
+            rnvp_flow_image<C>(rp, re + RNVP_HDR + f * m.fl, m, f, tid, 256);
         } else {
-            rnvp_header_image<C>(rp, re);
+            rnvp_header_image<C>(rp, re, tid, 256);
             if (u.unit_linear && tid < 6) re[tid] = tid < 3 ? (tid < C ? 1.f : 0.f) : 0.f;
         }
     }
+}
+
+// grid: x = F flows + 1 (the linear), y = image; 256 threads
+template <int C>
+__global__ __launch_bounds__(256) void rnvp_update_kernel(const RnvpUpdArgs u) {
+    rnvp_update_body<C>(u, blockIdx.x, blockIdx.y, threadIdx.x);
 }
 
 // ---- ActNorm data-dependent initialisation (nf.flows.ActNorm: first forward sets s = -log(std + 1e-6), t = -mean exp(s),

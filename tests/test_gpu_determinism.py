@@ -6,6 +6,8 @@ that last-bit difference into masks 4 pixels apart (fg-IoU 0.99866 vs 0.99799, b
 built with -ffp-contract=off (arithmetic = what the source says) and reports its flags; these tests pin the rest: no kernel
 reads a byte nobody wrote, repeated fits are bit-identical, and the one remaining source of rounding differences - how many
 gradient slabs an image is split into - moves the result by a bounded amount."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -96,6 +98,49 @@ def test_flow_priors_bitwise_with_poisoned_workspaces(amd, poison):
             outs.append(sd)
         for k_ in outs[0]:
             assert torch.equal(outs[0][k_], outs[1][k_]), k_
+
+
+_UNION_SNIPPET = r"""
+import hashlib, sys, torch
+sys.path.insert(0, %r)
+import awesome_amd as amd
+from awesome_amd.dataset import convex_blob_unaries
+from awesome_amd.model import ConvexDiffeomorphismNet, real_nvp_path_connected_net
+dev = torch.device("cuda:0")
+un = (convex_blob_unaries(256, 3).reshape(256, 256)[::4, ::4] > 0.5).float().reshape(1, -1).to(dev)
+bad = un.clone(); bad[0, 7] = float("nan")
+grid = amd.Grid.linspace(64, 64, dev)
+for make in (lambda: ConvexDiffeomorphismNet(n_hidden=130, n_hidden_layers=2, nf_layers=6, nf_hidden=130, diffeo_args=dict(backbone="normal_block")),
+             lambda: real_nvp_path_connected_net(channels=2, hidden_units=32, flow_n_flows=12, flow_output_fn="tanh"),
+             lambda: real_nvp_path_connected_net(channels=2, hidden_units=32, flow_n_flows=12, flow_output_fn="tanh", convex_net_hidden_layers=1)):
+    for targets in (un, bad):
+        torch.manual_seed(5)
+        m = make().to(dev)
+        res = m.fit_images(grid, targets, num_epochs=40)
+        h = hashlib.sha1()
+        for t in (res.icnn_params, res.flow_params, res.icnn_opt_state, res.flow_opt_state, res.loss_hist, res.status):
+            h.update(t.detach().cpu().numpy().tobytes())
+        print("CK", h.hexdigest(), int(res.status[0]))
+"""
+
+
+def test_one_launch_for_both_updates_equals_the_two_launches(amd):
+    """cdn_update_kernel / pcn_update_kernel (ICNN update + the deformation's update in one launch, the deformation's blocks deriving the
+    non-finite-loss decision from the slabs themselves) against the two separate launches (INRFIT_SPLIT_UPDATES=1): parameters, both
+    optimizer states, loss curves and status bit for bit - on a healthy image and on one whose targets hold a NaN (frozen at step 1)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for split in (False, True):
+        env = dict(os.environ)
+        env.pop("INRFIT_SPLIT_UPDATES", None)
+        if split:
+            env["INRFIT_SPLIT_UPDATES"] = "1"
+        r = subprocess.run([sys.executable, "-c", _UNION_SNIPPET % root], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("CK")])
+    assert len(outs[0]) == 6 and outs[0] == outs[1], outs
+    assert [l.split()[2] for l in outs[0]] == ["0", "1"] * 3     # the NaN image is reported and frozen on both paths
 
 
 def test_slab_count_moves_the_result_by_rounding_only(amd):

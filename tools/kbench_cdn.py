@@ -31,5 +31,8 @@ res = FL.cdn_fit(ispec, fspec, ip.clone(), fp.clone(), grid, un, a.steps, lr=3e-
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 h = res.loss_hist[0].cpu()
+import hashlib
+ck = hashlib.sha1(b"".join(t.detach().cpu().numpy().tobytes() for t in (res.icnn_params, res.flow_params, res.flow_opt_state, res.loss_hist))).hexdigest()[:16]
+print(f"checksum {ck}")
 print(f"CDN fit {S}x{S} x{a.images} L={a.layers} K=6 W=130: {dt / a.steps * 1e6:.1f} us per optimizer step "
       f"({dt / a.steps / a.images * 1e6:.1f} per image); loss {float(h[0]):.4f} -> {float(h[-1]):.4f}")

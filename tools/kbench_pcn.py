@@ -26,6 +26,9 @@ def run(name, m, grid, un, steps):
     dt = time.perf_counter() - t0
     h = res.loss_hist[0].cpu()
     iou = float(A.miou(torch.sigmoid(res.logits), un)[0])
+    import hashlib
+    ck = hashlib.sha1(b"".join(t.detach().cpu().numpy().tobytes() for t in (res.icnn_params, res.flow_params, res.flow_opt_state, res.loss_hist))).hexdigest()[:16]
+    print(f"checksum {ck}")
     print(f"{name}: {dt / steps * 1e6:.1f} us per optimizer step; loss {float(h[0]):.4f} -> {float(h[-1]):.4f}; fg-IoU {iou:.4f}", flush=True)
 
 

@@ -34,6 +34,12 @@ echo "== kernel stats of the joint step $(date +%T)"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_joint -o joint -- python3 tools/kbench_joint.py > $O/stats_joint.log 2>&1 || exit 1
 summ_stats $O/stats_joint joint
 fi
+if [ "$MODE" = "flowstats" ]; then   # the two composite fits only
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_pcn -o pcn -- python3 tools/kbench_pcn.py --steps 200 > $O/stats_pcn.log 2>&1 || exit 1
+summ_stats $O/stats_pcn pcn
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_cdn -o cdn -- python3 tools/kbench_cdn.py > $O/stats_cdn.log 2>&1 || exit 1
+summ_stats $O/stats_cdn cdn
+fi
 if [ "$MODE" = "pmc" ] || [ "$MODE" = "all" ]; then
 S="python3 bench.py --steps 1 --warmup 0 --epochs 50 --kernel-iters 20 --no-cpu-baseline --throughput-images 0 --no-variants"
 for c in FETCH_SIZE WRITE_SIZE; do
