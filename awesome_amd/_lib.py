@@ -15,7 +15,7 @@ INR_LOSS_SE, INR_LOSS_BCE = 0, 1
 INR_WEIGHT_NONE, INR_WEIGHT_EQUAL, INR_WEIGHT_RATIO, INR_WEIGHT_SSSDMS, INR_WEIGHT_EXPLICIT = 0, 1, 2, 3, 4
 INR_OPT_ADAM, INR_OPT_ADAMAX = 0, 1
 INR_OPT_HEADER_FLOATS = 8
-INRFIT_ABI_VERSION = 5
+INRFIT_ABI_VERSION = 6
 INR_ACT_RELU, INR_ACT_COS, INR_ACT_SIN = 0, 1, 2
 ACT_KINDS = {"relu": INR_ACT_RELU, "cos": INR_ACT_COS, "sin": INR_ACT_SIN}
 INR_FLOW_NORMAL_BLOCK, INR_FLOW_SIMPLE = 0, 1
@@ -63,6 +63,10 @@ class InrJointLossDesc(C.Structure):
 
 
 JOINT_FBMS, JOINT_AWESOME_IMAGE, JOINT_AWESOME_PIXEL = 0, 1, 2
+
+
+class InrStarDesc(C.Structure):
+    _fields_ = [("n_hidden", C.c_int32)]
 
 
 class InrOptDesc(C.Structure):
@@ -147,6 +151,15 @@ EXPORTS = {
                                         C.POINTER(InrGridDesc), C.c_void_p, C.c_void_p, C.POINTER(InrJointLossDesc),
                                         C.POINTER(InrOptDesc), C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_star_param_count": (C.c_int64, [C.POINTER(InrStarDesc)]),
+    "inrfit_star_workspace_bytes": (C.c_int64, [C.POINTER(InrStarDesc), C.c_int64]),
+    "inrfit_star_forward": (C.c_int, [C.POINTER(InrStarDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_void_p]),
+    "inrfit_star_loss_grad": (C.c_int, [C.POINTER(InrStarDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "inrfit_star_fit": (C.c_int, [C.POINTER(InrStarDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                  C.c_int64, C.POINTER(InrOptDesc), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                  C.c_void_p]),
     "inrfit_debug_tanh_exp": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "inrfit_miou": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_void_p,
                               C.c_void_p]),

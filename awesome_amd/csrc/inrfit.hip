@@ -26,6 +26,7 @@
 #include "rnvp.h"
 #include "joint_loss.h"
 #include "wide.h"
+#include "star.h"
 
 #include <vector>
 
@@ -649,7 +650,7 @@ int inrfit_query(int* abi_version, int* max_hidden, int* lds_bytes) {
 #define INRFIT_BUILD_FLAGS "unknown (not built by awesome_amd/build.py)"
 #endif
 const char* inrfit_build_info(void) {
-    return "libinrfit abi " "5" "; gfx950; slab_base 256; " __VERSION__ "; flags: " INRFIT_BUILD_FLAGS;
+    return "libinrfit abi " "6" "; gfx950; slab_base 256; " __VERSION__ "; flags: " INRFIT_BUILD_FLAGS;
 }
 
 int inrfit_debug_set_slab_base(int slab_base) {
@@ -2225,6 +2226,110 @@ int inrfit_cdn_joint_step(const InrModelDesc* model, const InrFlowDesc* flow, fl
                            c.gscale);
     }
     joint_dseg(c, dseg, s);
+    return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// star-shape prior of the teaser (csrc/star.h)
+// ---------------------------------------------------------------------------------------------------------------------
+static int check_star(const InrStarDesc* star, int64_t n_points, void* workspace, int64_t workspace_bytes, StarMap* m, StarWs* w) {
+    if (!star || star->n_hidden < 1 || star->n_hidden > STAR_MAX_HIDDEN) return INR_EUNSUPPORTED;
+    if (n_points <= 0 || n_points * (int64_t)star->n_hidden > (int64_t)1 << 31) return INR_EINVAL;
+    if (!workspace) return INR_EINVAL;
+    *m = make_star_map(star->n_hidden);
+    *w = carve_star(star->n_hidden, n_points, workspace);
+    if (workspace_bytes < w->bytes) return INR_EWORKSPACE;
+    if (!wide_blas().ok) return INR_EUNSUPPORTED;   // rocBLAS could not be opened
+    return INR_OK;
+}
+
+int64_t inrfit_star_param_count(const InrStarDesc* star) {
+    if (!star || star->n_hidden < 1 || star->n_hidden > STAR_MAX_HIDDEN) return INR_EUNSUPPORTED;
+    return make_star_map(star->n_hidden).P;
+}
+
+int64_t inrfit_star_workspace_bytes(const InrStarDesc* star, int64_t n_points) {
+    if (!star || star->n_hidden < 1 || star->n_hidden > STAR_MAX_HIDDEN) return INR_EUNSUPPORTED;
+    if (n_points <= 0 || n_points * (int64_t)star->n_hidden > (int64_t)1 << 31) return INR_EINVAL;
+    return carve_star(star->n_hidden, n_points, nullptr).bytes;
+}
+
+int inrfit_star_forward(const InrStarDesc* star, const float* params, const float* coords, int64_t n_points, float* logits,
+                        void* workspace, int64_t workspace_bytes, void* stream) {
+    StarMap m;
+    StarWs w;
+    if (!params || !coords || !logits) return INR_EINVAL;
+    int rc = check_star(star, n_points, workspace, workspace_bytes, &m, &w);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = star_forward_pass(m, w, params, coords, nullptr, n_points, n_points, nullptr, logits, s))) return rc;
+    return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
+}
+
+static void star_upd_consts(StarUpdArgs& u, const InrOptDesc* opt, int t, int t_off) {
+    u.lr = opt->lr;
+    u.beta1 = opt->beta1;
+    u.beta2 = opt->beta2;
+    u.eps = opt->eps;
+    u.one_minus_b1 = (float)(1.0 - (double)opt->beta1);
+    u.one_minus_b2 = (float)(1.0 - (double)opt->beta2);
+    u.bc1 = 1.0 - pow((double)opt->beta1, (double)t);
+    u.bc2_sqrt = (float)sqrt(1.0 - pow((double)opt->beta2, (double)t));
+    u.offset_on = t_off > 0;
+    u.bc1_off = t_off > 0 ? 1.0 - pow((double)opt->beta1, (double)t_off) : 1.0;
+    u.bc2_sqrt_off = t_off > 0 ? (float)sqrt(1.0 - pow((double)opt->beta2, (double)t_off)) : 1.f;
+}
+
+int inrfit_star_loss_grad(const InrStarDesc* star, const float* params, const float* coords, const float* labels, int64_t n_pixels,
+                          const int32_t* index, int64_t batch, float* loss, float* grads, void* workspace, int64_t workspace_bytes,
+                          void* stream) {
+    StarMap m;
+    StarWs w;
+    if (!params || !coords || !labels || !grads || n_pixels <= 0 || batch > STAR_MAX_BATCH) return INR_EINVAL;
+    if (!index && batch > n_pixels) return INR_EINVAL;
+    int rc = check_star(star, batch, workspace, workspace_bytes, &m, &w);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = star_forward_pass(m, w, params, coords, index, n_pixels, batch, labels, nullptr, s))) return rc;
+    if ((rc = star_backward_pass(m, w, params, batch, loss, 0, s))) return rc;
+    StarUpdArgs u{};
+    u.prm = nullptr;
+    u.gW1 = w.gW1;
+    u.colp = w.colp;
+    u.scal = w.scal;
+    u.grads_out = grads;
+    u.m = m;
+    u.mode = 1;
+    hipLaunchKernelGGL(star_update_kernel, dim3((m.P + 255) / 256), dim3(256), 0, s, u);
+    return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
+}
+
+int inrfit_star_fit(const InrStarDesc* star, float* params, float* opt_state, const float* coords, const float* labels,
+                    int64_t n_pixels, const int32_t* batch_index, int64_t batch, const InrOptDesc* opt, int32_t steps, int32_t step0,
+                    int32_t offset_first_step, float* loss_hist, void* workspace, int64_t workspace_bytes, void* stream) {
+    StarMap m;
+    StarWs w;
+    if (!params || !opt_state || !coords || !labels || !batch_index || !opt || steps < 0 || step0 < 0 || n_pixels <= 0) return INR_EINVAL;
+    if (opt->kind != INR_OPT_ADAM || batch > STAR_MAX_BATCH) return INR_EINVAL;
+    int rc = check_star(star, batch, workspace, workspace_bytes, &m, &w);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    StarUpdArgs u{};
+    u.prm = params;
+    u.opt = opt_state;
+    u.gW1 = w.gW1;
+    u.colp = w.colp;
+    u.scal = w.scal;
+    u.m = m;
+    u.mode = 0;
+    for (int it = 0; it < steps; ++it) {
+        const int ep = step0 + it;
+        const int32_t* idx = batch_index + (size_t)it * batch;
+        if ((rc = star_forward_pass(m, w, params, coords, idx, n_pixels, batch, labels, nullptr, s))) return rc;
+        if ((rc = star_backward_pass(m, w, params, batch, loss_hist, it, s))) return rc;
+        star_upd_consts(u, opt, ep + 1, offset_first_step >= 0 && ep >= offset_first_step ? ep - offset_first_step + 1 : 0);
+        hipLaunchKernelGGL(star_update_kernel, dim3((m.P + 255) / 256), dim3(256), 0, s, u);
+    }
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 

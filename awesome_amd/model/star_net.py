@@ -17,16 +17,20 @@ same HIP network sharing W0:
 
 with the polar split, the product with r and the shared-parameter bookkeeping left to torch autograd on the device (a few
 elementwise operations per point).  Forward and backward of everything with a matrix in it run through `inrfit_forward` /
-`inrfit_backward`; `offset` receives its gradient through the kernels' coordinate gradient.  This is the module / autograd surface
-only: the notebook trains on random 1000-pixel minibatches with a torch optimizer, and that loop runs unchanged on this class.  There
-is no fused `inrfit_fit` for it (two chains with shared weights and a logit scaled per point are outside the fit kernel's loss).
-Widths: the kernels' (130; the notebook's 150 is not compiled)."""
+`inrfit_backward`; `offset` receives its gradient through the kernels' coordinate gradient.  That is the module / autograd surface:
+the notebook's loop (random 1000-pixel minibatches, a torch optimizer) runs unchanged on this class.
+
+The loop itself also exists on the device (`fit` -> `inrfit_star_fit`, csrc/star.h: the network evaluated layer by layer on the
+minibatch with its own read-out, MSE on the sigmoid, every gradient incl. the centre's, torch's Adam and the projection - no autograd,
+no torch optimizer, no host synchronisation), and `forward_fused` is the inference of cells 4 / 6 (`inrfit_star_forward`).  Any width
+up to 1024 (the notebook's 150 included); the autograd surface takes what `inrfit_supported` takes."""
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
 
 from .. import icnn as K
+from .. import star as S
 from .convex_net import _IcnnFunction
 
 
@@ -48,6 +52,50 @@ class StarShapedNet(nn.Module):
             self.W2_r.weight.clamp_(min=0.0)
 
     enforce_convexity = enforce_star_shape   # the prior-module contract name (WrapperModule calls it after each step)
+
+    # ---- the device-resident surface (awesome_amd/star.py) -----------------------------------------------------------------------
+    @property
+    def star_spec(self) -> "S.StarSpec":
+        return S.StarSpec(self.spec.n_hidden)
+
+    def flat_parameters(self) -> torch.Tensor:
+        """[P] float32 on the module's device, in the order of named_parameters() (= include/inrfit.h's layout)."""
+        return S.flatten_state_dict(self.star_spec, {k: v for k, v in self.named_parameters()}, self.W0.weight.device)
+
+    def load_flat(self, flat: torch.Tensor) -> None:
+        with torch.no_grad():
+            named = dict(self.named_parameters())
+            for k, v in S.unflatten(self.star_spec, flat).items():
+                named[k].copy_(v)
+
+    @torch.no_grad()
+    def forward_fused(self, x: torch.Tensor) -> torch.Tensor:
+        """Inference without autograd: (N, 2) -> (N, 1) through inrfit_star_forward (star.ipynb cells 4 / 6)."""
+        if not x.is_cuda:
+            raise RuntimeError("awesome_amd modules run on the MI355X only (no CPU fallback); move module and input to cuda")
+        return S.star_forward(self.star_spec, self.flat_parameters(), x.to(torch.float32).contiguous())[:, None]
+
+    def fit(self, pixel_info: torch.Tensor, labels: torch.Tensor, num_epochs: int = 10000, number: int = 500, lr: float = 1e-2,
+            offset_free_epoch: int = 1000, batch_index: torch.Tensor = None, generator: torch.Generator = None,
+            state: dict = None) -> "S.StarFitResult":
+        """star.ipynb cell 3 as one device-resident call: per epoch `number` random background + `number` random foreground pixels
+        (labels = 1 - likelihood, so background has label 1), sigmoid -> MSELoss -> Adam(lr) over every parameter -> W2_r.weight <-
+        relu(W2_r.weight); `offset` is freed after the forward pass of epoch `offset_free_epoch` (None: never), i.e. its first step is
+        the next epoch's.  `batch_index` ([epochs, batch] pixel numbers) replaces the random draw.  `state` (a dict this call fills:
+        opt_state, epoch) continues an earlier call.  The fitted parameters are loaded back into the module."""
+        dev = self.W0.weight.device
+        pixel_info = pixel_info.to(device=dev, dtype=torch.float32).contiguous()
+        labels = labels.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        if batch_index is None:
+            batch_index = S.notebook_minibatches(labels, num_epochs, number, generator)
+        state = {} if state is None else state
+        flat = self.flat_parameters()
+        res = S.star_fit(self.star_spec, flat, pixel_info, labels, batch_index, lr=lr, step0=int(state.get("epoch", 0)),
+                         offset_first_step=-1 if offset_free_epoch is None else int(offset_free_epoch) + 1,
+                         opt_state=state.get("opt_state"))
+        state["opt_state"], state["epoch"] = res.opt_state, int(state.get("epoch", 0)) + int(batch_index.shape[0])
+        self.load_flat(res.params)
+        return res
 
     def forward(self, x: torch.Tensor, *args, **kwargs) -> torch.Tensor:
         """(N, 2) -> (N, 1), or (B, 2, H, W) -> (B, 1, H, W)."""

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define INRFIT_ABI_VERSION 5
+#define INRFIT_ABI_VERSION 6
 
 enum {
     INR_OK = 0,
@@ -401,6 +401,40 @@ int inrfit_timing_end(float* avg_step_bracket_us, float* avg_update_bracket_us, 
  * fast_exp) evaluated on x [n] -> tanh_out [n], exp_out [n], so their error bounds are asserted against float64 on the device
  * that runs them. */
 int inrfit_debug_tanh_exp(const float* x, int64_t n, float* tanh_out, float* exp_out, void* stream);
+
+/* ---- star-shape prior of the teaser ----------------------------------------------------------------------
+ * Replaces: `myNet` of notebooks/icml_teaser_code/star_shaped/star.ipynb cell 2 (forward) and the training loop of cell 3 (minibatch of
+ * pixels -> sigmoid -> nn.MSELoss -> torch.optim.Adam(net.parameters(), lr) -> W2_r.weight <- relu(W2_r.weight); `offset` joins the
+ * optimizer at a given epoch).  out = r (W2 x_old + W2_r relu(W1 x_old + W1_r r)) - 1, x_old = relu(W0 x / (0.01 + r)), r = |x + offset|.
+ * params: ONE flat vector in the order of the class's named_parameters():
+ *   offset[2] | W0.weight[h][2] | W0.bias[h] | W1.weight[h][h] | W1.bias[h] | W2.weight[h] | W2.bias | W1_r.weight[h] | W1_r.bias[h] |
+ *   W2_r.weight[h] | W2_r.bias                                                      (inrfit_star_param_count = h^2 + 8 h + 4)
+ * coords: [n_pixels][2] row-major (the notebook's pixel_info), labels [n_pixels]; 1 <= n_hidden <= 1024.  Layer-by-layer kernels with
+ * rocBLAS for the h x h contractions (csrc/star.h); results reproducible run to run. */
+typedef struct InrStarDesc {
+    int32_t n_hidden;
+} InrStarDesc;
+
+int64_t inrfit_star_param_count(const InrStarDesc* star);
+/* workspace for n_points points evaluated at once (the minibatch size for _fit / _loss_grad, all pixels for _forward) */
+int64_t inrfit_star_workspace_bytes(const InrStarDesc* star, int64_t n_points);
+/* logits[n_points] = net(coords) (star.ipynb cell 4 / 6: inference on every pixel) */
+int inrfit_star_forward(const InrStarDesc* star, const float* params, const float* coords, int64_t n_points, float* logits,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+/* One minibatch (index[batch] pixel numbers, or NULL = the first `batch` pixels): loss[1] = MSE(sigmoid(net), labels) and its gradient
+ * with respect to every parameter, the centre included, in the parameter layout (grads[P]); batch <= 65536. */
+int inrfit_star_loss_grad(const InrStarDesc* star, const float* params, const float* coords, const float* labels, int64_t n_pixels,
+                          const int32_t* index, int64_t batch, float* loss, float* grads, void* workspace, int64_t workspace_bytes,
+                          void* stream);
+/* The training loop of cell 3 on the device: for epoch = step0 .. step0 + steps - 1: minibatch batch_index[epoch - step0][batch]
+ * (values clamped into [0, n_pixels)), forward, MSE, backward, Adam (opt->lr, beta1, beta2, eps; kind must be INR_OPT_ADAM) on params
+ * IN PLACE with opt_state [2 P] (exp_avg | exp_avg_sq; zero it before epoch 0), then W2_r.weight <- max(W2_r.weight, 0).  `offset`
+ * takes its first step at epoch `offset_first_step` with its own step count, as torch's Adam treats a parameter that starts to
+ * receive gradients (the notebook sets requires_grad after the forward pass of epoch 1000: offset_first_step = 1001; < 0: never).
+ * loss_hist [steps] or NULL.  Nothing synchronises with the host. */
+int inrfit_star_fit(const InrStarDesc* star, float* params, float* opt_state, const float* coords, const float* labels,
+                    int64_t n_pixels, const int32_t* batch_index, int64_t batch, const InrOptDesc* opt, int32_t steps, int32_t step0,
+                    int32_t offset_first_step, float* loss_hist, void* workspace, int64_t workspace_bytes, void* stream);
 
 const char* inrfit_strerror(int code);
 

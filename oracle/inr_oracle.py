@@ -147,6 +147,30 @@ def star_shaped_forward(sd: Dict[str, Tensor], x: Tensor) -> Tensor:
     return r * (F.linear(x_old, sd["W2.weight"], sd["W2.bias"]) + F.linear(r_aug, sd["W2_r.weight"], sd["W2_r.bias"])) - 1
 
 
+def star_shaped_fit(sd: Dict[str, Tensor], pixel_info: Tensor, labels: Tensor, batch_index: Tensor, lr: float = 1e-2,
+                    offset_free_epoch: Optional[int] = 1000, offset_trainable_from_start: bool = False):
+    """The training loop of star.ipynb cell 3 on given minibatches (batch_index [epochs, batch] replaces its two torch.randperm draws):
+    outputs = sigmoid(net(pixels)); loss = nn.MSELoss(); `if epoch == 1000: net.offset.requires_grad = True` AFTER the forward pass
+    (so the centre's first Adam step is the next epoch's); optimizer.step(); W2_r.weight <- relu(W2_r.weight).
+    Returns (state dict after the last epoch, losses)."""
+    p = {k: v.detach().clone().requires_grad_(k != "offset" or offset_trainable_from_start) for k, v in sd.items()}
+    opt = torch.optim.Adam(list(p.values()), lr=lr)
+    losses = []
+    for epoch in range(batch_index.shape[0]):
+        idx = batch_index[epoch].long()
+        outputs = torch.sigmoid(star_shaped_forward(p, pixel_info[idx])).squeeze()
+        loss = F.mse_loss(outputs, labels[idx])
+        if offset_free_epoch is not None and epoch == offset_free_epoch:
+            p["offset"].requires_grad = True
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            p["W2_r.weight"].data = F.relu(p["W2_r.weight"].data)
+        losses.append(float(loss.detach()))
+    return {k: v.detach().clone() for k, v in p.items()}, losses
+
+
 def icnn_forward(p: Dict[str, Tensor], x: Tensor, act0: str = "relu", omega: float = 1.0) -> Tensor:
     """ConvexNextNet.forward (convex_net.py:205-214) on (N,C) rows -> (N,1) logits; `act0`: layer 0's activation (encode_layer)."""
     x_in = x

@@ -222,3 +222,23 @@ def test_oracle_star_shaped_net_matches_the_notebook_class(golden_dir):
     np.testing.assert_allclose(losses, z["adam8.loss"], rtol=1e-4)
     for k, v in sd.items():
         np.testing.assert_allclose(v.detach().numpy(), z["adam8.sd." + k], rtol=1e-3, atol=1e-5, err_msg=k)
+
+
+def test_oracle_star_training_loop_matches_the_notebook_class(golden_dir):
+    """O.star_shaped_fit (star.ipynb cell 3 restated on given minibatches) against the recorded 8-step trajectory of the notebook's
+    class (full batch, the centre trainable from the start), and its `epoch == k` switch: the centre does not move before epoch k + 1."""
+    z = _z(golden_dir, "teaser_star_shaped.npz")
+    sd = {k[3:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith("sd.")}
+    x, labels = torch.from_numpy(z["x"]), torch.from_numpy(z["labels"])
+    full = torch.arange(x.shape[0])[None].repeat(8, 1)
+    out, losses = O.star_shaped_fit(sd, x, labels, full, lr=1e-2, offset_free_epoch=None, offset_trainable_from_start=True)
+    np.testing.assert_allclose(losses, z["adam8.loss"], rtol=1e-4)
+    for k, v in out.items():
+        np.testing.assert_allclose(v.numpy(), z["adam8.sd." + k], rtol=1e-3, atol=1e-5, err_msg=k)
+    g = torch.Generator().manual_seed(3)
+    idx = torch.stack([torch.randperm(x.shape[0], generator=g)[:100] for _ in range(6)])
+    out3, _ = O.star_shaped_fit(sd, x, labels, idx[:4], offset_free_epoch=2)     # epochs 0..3: the centre steps once (epoch 3)
+    out2, _ = O.star_shaped_fit(sd, x, labels, idx[:3], offset_free_epoch=2)     # epochs 0..2: not yet
+    assert torch.equal(out2["offset"], sd["offset"]) and not torch.equal(out3["offset"], sd["offset"])
+    # Adam's first step moves a parameter by lr whatever the gradient's size: the centre's own step count starts at its first gradient
+    np.testing.assert_allclose((out3["offset"] - sd["offset"]).abs().numpy(), 1e-2, rtol=1e-3)

@@ -208,3 +208,125 @@ def test_star_net_fits_a_non_convex_star_and_stays_star_shaped(dev):
         # (the architecture makes the bracket convex in r, W2_r >= 0; monotone only where W1_r >= 0, which the notebook does not
         # project - so this is a property of the trained network, checked with a small allowance)
         assert float(reenter) <= 0.05, f"{float(reenter):.3f} of the rays re-enter the region: not star-shaped"
+
+
+# ---- the star prior's device-resident entry points (awesome_amd/star.py, csrc/star.h) --------------------------------------------------
+def test_star_fused_forward_and_loss_grad_match_the_notebook_class(dev, zs):
+    """inrfit_star_forward / inrfit_star_loss_grad against the fixture of the notebook's own class: logits, and - through the chain rule
+    of the fixture's scalar sum(sigmoid(y)^2)/n, which is MSE against zero labels - every parameter gradient, the centre's included."""
+    from awesome_amd import star as S
+    m = _star(zs, dev)
+    spec = m.star_spec
+    assert spec.n_params == sum(p.numel() for p in m.parameters())
+    flat = m.flat_parameters()
+    x = torch.from_numpy(zs["x"]).to(dev)
+    y = S.star_forward(spec, flat, x)
+    np.testing.assert_allclose(y.cpu().numpy(), zs["y"][:, 0], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(m.forward_fused(x).cpu().numpy(), zs["y"], rtol=1e-5, atol=1e-5)
+    loss, grads = S.star_loss_grad(spec, flat, x, torch.zeros(x.shape[0], device=dev))
+    ref_loss = float((1.0 / (1.0 + np.exp(-zs["y"].astype(np.float64))) ** 2).mean())
+    assert abs(float(loss) - ref_loss) <= 1e-5 * ref_loss
+    g = S.unflatten(spec, grads)
+    for k in S.PARAM_ORDER:
+        ref = zs["grad." + k]
+        np.testing.assert_allclose(g[k].cpu().numpy(), ref, rtol=2e-4, atol=2e-4 * float(np.abs(ref).max()) + 1e-9, err_msg=k)
+    # a minibatch through the index path = the same pixels gathered by hand
+    idx = torch.tensor([5, 17, 300, 44, 44, 359, 0, 128], dtype=torch.int32, device=dev)
+    lab = torch.from_numpy(zs["labels"]).to(dev)
+    l1, g1 = S.star_loss_grad(spec, flat, x, lab, idx)
+    l2, g2 = S.star_loss_grad(spec, flat, x[idx.long()].contiguous(), lab[idx.long()].contiguous())
+    assert torch.equal(l1, l2) and torch.equal(g1, g2)
+
+
+def test_star_fused_fit_reproduces_the_notebook_trajectory(dev, zs):
+    """inrfit_star_fit on the fixture's problem: 8 full-batch epochs, the centre trainable from the first one - losses and every
+    parameter against the trajectory the notebook's class recorded (the same bars as the autograd loop above), run twice: same bits."""
+    from awesome_amd import star as S
+    m = _star(zs, dev)
+    spec = m.star_spec
+    x, labels = torch.from_numpy(zs["x"]).to(dev), torch.from_numpy(zs["labels"]).to(dev)
+    full = torch.arange(x.shape[0], dtype=torch.int32, device=dev)[None].repeat(8, 1)
+    runs = []
+    for _ in range(2):
+        res = S.star_fit(spec, m.flat_parameters(), x, labels, full, lr=1e-2, offset_first_step=0)
+        runs.append(res)
+    assert torch.equal(runs[0].params, runs[1].params) and torch.equal(runs[0].loss_hist, runs[1].loss_hist)
+    np.testing.assert_allclose(runs[0].loss_hist.cpu().numpy(), zs["adam8.loss"], rtol=2e-4)
+    out = S.unflatten(spec, runs[0].params)
+    assert float(out["W2_r.weight"].min()) >= 0.0
+    for k in S.PARAM_ORDER:
+        np.testing.assert_allclose(out[k].cpu().numpy(), zs["adam8.sd." + k], rtol=2e-3, atol=1e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("h", [150, 37])
+def test_star_fused_fit_against_the_oracle_loop_on_minibatches(dev, h):
+    """The notebook's width (150) and an odd one: 12 epochs of 200-pixel minibatches, the centre freed after the forward pass of epoch 4
+    (first step at epoch 5, its own Adam step count), continued in a second call - against oracle.star_shaped_fit on the CPU."""
+    from awesome_amd import star as S
+    from awesome_amd.model import StarShapedNet
+    from oracle import inr_oracle as O
+    torch.manual_seed(21 + h)
+    m = StarShapedNet(h)
+    with torch.no_grad():
+        m.offset.copy_(torch.tensor([[0.02, -0.04]]))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    n = 48
+    ii, jj = torch.meshgrid(torch.arange(n), torch.arange(n), indexing="ij")
+    x = torch.stack([ii.reshape(-1) / (n - 1) - 0.5, jj.reshape(-1) / (n - 1) - 0.5], 1).float()
+    rad, phi = ((x[:, 0] - 0.03) ** 2 + (x[:, 1] + 0.05) ** 2).sqrt(), torch.atan2(x[:, 1] + 0.05, x[:, 0] - 0.03)
+    labels = 1 - (rad < 0.22 + 0.12 * torch.cos(5 * phi)).float()
+    g = torch.Generator().manual_seed(1)
+    idx = torch.stack([torch.randperm(n * n, generator=g)[:200] for _ in range(12)]).to(torch.int32)
+    ref, ref_losses = O.star_shaped_fit(sd, x, labels, idx, lr=1e-2, offset_free_epoch=4)
+    m = m.to(dev)
+    state = {}
+    r1 = m.fit(x.to(dev), labels.to(dev), lr=1e-2, offset_free_epoch=4, batch_index=idx[:7].to(dev), state=state)
+    r2 = m.fit(x.to(dev), labels.to(dev), lr=1e-2, offset_free_epoch=4, batch_index=idx[7:].to(dev), state=state)
+    assert state["epoch"] == 12
+    losses = torch.cat([r1.loss_hist, r2.loss_hist]).cpu().numpy()
+    np.testing.assert_allclose(losses, ref_losses, rtol=5e-4)
+    assert not torch.equal(m.offset.detach().cpu(), sd["offset"])
+    for k, v in m.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), ref[k].numpy(), rtol=5e-3, atol=2e-4, err_msg=k)
+    # inference of the fitted module: the fused forward and the autograd surface agree
+    xs = x[::7].to(dev).contiguous()
+    np.testing.assert_allclose(m.forward_fused(xs).cpu().numpy(), m(xs).detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_star_fused_fit_of_the_notebook_loop_is_star_shaped(dev):
+    """star.ipynb cell 3 end to end on the device (random minibatches drawn like its randperm pairs, 600 epochs, the centre freed at
+    epoch 300): the five-armed star is covered, the region stays star-shaped along rays from the learned centre, and the call is
+    faster than the same epochs through autograd + torch.optim by a wide margin (printed)."""
+    import time
+    from awesome_amd.model import StarShapedNet
+    torch.manual_seed(9)
+    S_ = 96
+    ii, jj = torch.meshgrid(torch.arange(S_), torch.arange(S_), indexing="ij")
+    x = torch.stack([ii.reshape(-1) / (S_ - 1) - 0.5, jj.reshape(-1) / (S_ - 1) - 0.5], 1).float().to(dev)
+    rad, phi = ((x[:, 0] - 0.04) ** 2 + (x[:, 1] + 0.03) ** 2).sqrt(), torch.atan2(x[:, 1] + 0.03, x[:, 0] - 0.04)
+    inside = (rad < 0.24 + 0.11 * torch.cos(5 * phi)).float()
+    labels = 1 - inside
+    m = StarShapedNet(150).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(4)
+    m.fit(x, labels, num_epochs=10, generator=gen)                      # warm-up (rocBLAS handle, workspaces)
+    m = StarShapedNet(150).to(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = m.fit(x, labels, num_epochs=600, number=500, lr=1e-2, offset_free_epoch=300, generator=gen)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    h = res.loss_hist.cpu().numpy()
+    assert np.isfinite(h).all() and h[-50:].mean() < 0.35 * h[:5].mean(), (h[:5], h[-5:])
+    print(f"\nstar fused fit: 600 epochs x 1000 pixels, h = 150: {dt * 1e3:.0f} ms ({dt / 600 * 1e6:.0f} us per epoch incl. the minibatch draw)")
+    with torch.no_grad():
+        pred_in = (m.forward_fused(x)[:, 0] < 0).float()
+        iou = float((pred_in * inside).sum() / ((pred_in + inside) > 0).float().sum())
+        assert iou > 0.8, iou
+        c = -m.offset.detach()[0]
+        t = torch.linspace(0.01, 0.7, 200, device=dev)
+        ang = torch.linspace(0, 2 * np.pi, 91, device=dev)[:-1]
+        pts = torch.stack((c[0] + t[None, :] * torch.cos(ang)[:, None], c[1] + t[None, :] * torch.sin(ang)[:, None]), -1).reshape(-1, 2)
+        out = m.forward_fused(pts.contiguous())[:, 0].reshape(90, 200)
+        outside = (out >= 0).int()
+        reenter = ((outside[:, 1:] - outside[:, :-1]).min(1).values < 0).float().mean()
+        assert float(reenter) <= 0.05, f"{float(reenter):.3f} of the rays re-enter the region: not star-shaped"
