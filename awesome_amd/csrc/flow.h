@@ -65,10 +65,17 @@ __device__ __forceinline__ void load_coords2(const InrGridDesc& gd, int img, lon
 
 // The effective weights of one image (<= 25 KB) are copied into LDS once per block; inside the unit loops every lane reads
 // the same 16-byte record (w1, b1, w2, w1*w2) of unit j: one broadcast ds_read_b128 per unit, pipelined by unrolling.
+// The copy is LDS-DMA (global_load_lds_dwordx4: a wave moves 1 KB per instruction straight into LDS, no registers, every piece in
+// flight at once); the register-staged loop it replaces waited for each of its ~7 loads per thread before issuing the next one.
 __device__ __forceinline__ void flow_weights_to_lds(const float* __restrict__ src, float* dst, int n_floats) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int pieces = n_floats / 256;
+    for (int pc = wave; pc < pieces; pc += nw)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(dst + pc * 256), 16, 0, 0);
     const f32x4* __restrict__ s4 = (const f32x4*)src;
-    for (int i = threadIdx.x; i < n_floats / 4; i += blockDim.x) ((f32x4*)dst)[i] = s4[i];
-    __syncthreads();
+    for (int i = pieces * 64 + threadIdx.x; i < n_floats / 4; i += blockDim.x) ((f32x4*)dst)[i] = s4[i];
+    __syncthreads();   // (its fence waits for vmcnt(0): the DMA pieces have landed)
 }
 
 
@@ -156,16 +163,86 @@ struct RecL {   // image in LDS
 };
 __device__ __forceinline__ RecK rec_global(const float* image) { return RecK{(const kfloat*)image}; }
 
-// Launch shape of the point kernels: points per lane Q and threads per block.  Fixed at Q = 1 and 256 threads: Q = 2 / 4 and
-// 64-thread blocks were measured slower at every size, before AND after the unit loops were software-pipelined (see above and
-// profiles/NOTES.md); the kernels keep Q and blockDim.x general.
-struct FlowShape { int Q, threads, blocks; };
-inline FlowShape flow_launch_shape(long long n_points, int /*n_images*/, int /*cv*/, int /*max_q*/) {
+// Launch shape of the point kernels: U lanes per point, Q points per lane, 256 threads.  A launch with at least two waves per SIMD
+// runs at (1, 1): more points per lane were measured slower at every size (profiles/NOTES.md).  A small launch (one image of 256x256:
+// ONE wave per SIMD at (1, 1)) cuts the unit loop over U lanes - forward U = 4 with every record read serving Q = 2 points, backward
+// U = 2 (it carries 7 saved values per coupling and point: fewer registers, fewer partial-sum blocks).
+// Measured (us, 256x256, K = 6, W = 130; tools/experiments/expq.sh; (U, Q)):
+//   forward            (1,1) 20.3 | (2,1) 16.5 | (4,1) 17.5 | (2,2) 18.5 | (4,2) 15.6 | (4,4) 18.3 | (8,2) 19.0 | (8,4) 19.4
+//   backward, points   (1,1) 23.8 | (2,1) 20.3 | (4,1) 22.4 | (4,2) 21.1
+//   Q alone (one lane per point, 256 / Q threads), forward: Q = 2 30.6, Q = 4 46.3
+struct FlowShape { int Q, U, threads, blocks; };
+inline FlowShape flow_launch_shape(long long n_points, int n_images, bool backward) {
     FlowShape s;
-    s.Q = 1;
+    const char* fe = getenv("INR_FLOW_SHAPE");   // measurement / test switch: 10 U + Q for both kernels (read per call)
+    const int force = fe ? atoi(fe) : 0;
+    const bool small = n_points * n_images <= 98304;
+    s.U = force ? force / 10 : (small ? (backward ? 2 : 4) : 1);
+    s.Q = force ? force % 10 : (small ? (backward ? 1 : 2) : 1);
+    if (!((s.U == 1 && s.Q == 1) || (s.U == 4 && s.Q == 2) || (s.U == 4 && s.Q == 1) || (s.U == 2 && s.Q == 1))) s.U = s.Q = 1;
     s.threads = 256;
-    s.blocks = (int)((n_points + 255) / 256);
+    s.blocks = (int)((n_points * s.U + 256 * s.Q - 1) / (256 * s.Q));
     return s;
+}
+
+inline FlowShape plain_launch_shape(long long n_points) { return FlowShape{1, 1, 256, (int)((n_points + 255) / 256)}; }
+
+// sum over the U adjacent lanes that share a point (U = 2, 4: inside a DPP quad); every lane ends with the same bits
+template <int U>
+__device__ __forceinline__ float lanes_sum(float v) {
+    if constexpr (U >= 2) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm(1,0,3,2)
+    if constexpr (U >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm(2,3,0,1)
+    if constexpr (U >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror: the other quad
+    return v;
+}
+
+// U LANES PER POINT (small launches).  One 256x256 image is one point per lane of the chip: one wave per SIMD, and nothing covers the
+// latency of a wave's dependent chain through the W = 130 units of a coupling (flow.h header: 66 clocks per unit for 16 of issue; more
+// points per lane made it worse).  The sum over the units is a reduction, so it can be cut the other way: the U lanes of a point take
+// the units s, s + U, s + 2U, ... (their records are U consecutive 32-byte records: one conflict-free ds_read_b128 per wave), add their
+// partial (acc, d) pairs through DPP, and evaluate the rest of the coupling redundantly.  The chain per wave is ~U times shorter and U
+// waves per SIMD cover each other.  The order of the sum over the units changes (per-lane partials, then lanes): results differ from
+// U = 1 by rounding; which U a launch uses depends only on its size, so a given problem is reproducible.
+template <bool DU, int U, int Q, class Rec>
+__device__ __forceinline__ void nb_pair_forward_split(const Rec e, int W, const int s, const float (&u)[Q], f32x2 (&st)[Q], f32x2 (&dpre_du)[Q]) {
+    const f32x4 tail = e.v4(8 * W);
+    f32x2 acc[Q], d[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = d[q] = f32x2{0.f, 0.f};
+    auto unit = [&](const f32x4& lo, const f32x4& hi) {   // lo = (w1s, w1t, b1s, b1t), hi = (w2's, w2't, w1s w2's, w1t w2't)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const f32x2 pre = pk_fma(f32x2{lo[0], lo[1]}, splat2(u[q]), f32x2{lo[2], lo[3]});
+            if (DU) {
+                const f32x2 sp = step01(pre);
+                acc[q] = pk_fma(f32x2{hi[0], hi[1]}, pre * sp, acc[q]);
+                d[q] = pk_fma(f32x2{hi[2], hi[3]}, sp, d[q]);
+            } else {
+                acc[q] = pk_fma(f32x2{hi[0], hi[1]}, f32x2{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f)}, acc[q]);
+            }
+        }
+    };
+    const int steps = W / U;
+    int t = 0;
+    for (; t + 4 <= steps; t += 4) {
+        f32x4 r[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            r[2 * k] = e.v4(8 * ((t + k) * U + s));
+            r[2 * k + 1] = e.v4(8 * ((t + k) * U + s) + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) unit(r[2 * k], r[2 * k + 1]);
+    }
+    for (; t < steps; ++t) unit(e.v4(8 * (t * U + s)), e.v4(8 * (t * U + s) + 4));
+    if (steps * U + s < W) unit(e.v4(8 * (steps * U + s)), e.v4(8 * (steps * U + s) + 4));   // the W mod U last units
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        f32x2 a2 = f32x2{lanes_sum<U>(acc[q][0]), lanes_sum<U>(acc[q][1])};
+        a2 += pk_fma(f32x2{tail[2], tail[3]}, splat2(u[q]), f32x2{tail[0], tail[1]});
+        st[q] = f32x2{fast_tanh(a2[0]), fast_tanh(a2[1])};
+        if (DU) dpre_du[q] = f32x2{lanes_sum<U>(d[q][0]), lanes_sum<U>(d[q][1])} + f32x2{tail[2], tail[3]};
+    }
 }
 
 // (NB_s(u), NB_t(u)) of one coupling for both nets at once on packed f32 pairs (v_pk_fma_f32: half the VALU
@@ -245,19 +322,21 @@ struct FlowFwdArgs {
     FlowMap m;
 };
 
-// grid: x = blocks of blockDim.x * Q points (lane t of the block owns points base + q * blockDim.x + t), y = image
-template <int Q>
+// grid: x = blocks of Q * blockDim.x / U points, y = image.  U lanes per point (adjacent lanes), Q points per lane: lane t of the block
+// owns points base + q * (blockDim.x / U) + t / U and the units (t mod U), (t mod U) + U, ... of every coupling (nb_pair_forward_split).
+template <int Q, int U>
 __global__ __launch_bounds__(256) void flow_fwd_kernel(const FlowFwdArgs a) {
     const int img = blockIdx.y;
-    const int N = (int)a.N, BS = blockDim.x;
+    const int N = (int)a.N, PB = blockDim.x / U;
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     flow_weights_to_lds(a.FE + (size_t)img * a.m.FE, fsm, a.m.FE);
     const RecL e{fsm};
+    const int sl = threadIdx.x & (U - 1);
     int p[Q];
     float x1[Q], x2[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        p[q] = (blockIdx.x * Q + q) * BS + threadIdx.x;
+        p[q] = (blockIdx.x * Q + q) * PB + threadIdx.x / U;
         float xin[2];
         load_coords2(a.grid, img, a.N, p[q] < N ? p[q] : N - 1, xin);
         x1[q] = fmaf(e.f(0), xin[0], fmaf(e.f(1), xin[1], e.f(4)));
@@ -268,7 +347,8 @@ __global__ __launch_bounds__(256) void flow_fwd_kernel(const FlowFwdArgs a) {
         f32x2 st[Q], dd[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) u[q] = (i & 1) ? x2[q] : x1[q];
-        nb_pair_forward<false, Q>(e.at(a.m.e_nb + i * a.m.e_cp_stride), a.m.W, u, st, dd);
+        if constexpr (U == 1) nb_pair_forward<false, Q>(e.at(a.m.e_nb + i * a.m.e_cp_stride), a.m.W, u, st, dd);
+        else nb_pair_forward_split<false, U, Q>(e.at(a.m.e_nb + i * a.m.e_cp_stride), a.m.W, sl, u, st, dd);
         const float sc = e.f(a.m.e_scale + i);
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
@@ -279,7 +359,7 @@ __global__ __launch_bounds__(256) void flow_fwd_kernel(const FlowFwdArgs a) {
     }
 #pragma unroll
     for (int q = 0; q < Q; ++q)
-        if (p[q] < N) {
+        if (p[q] < N && sl == 0) {
             a.xd[((size_t)img * 2) * N + p[q]] = x1[q];
             a.xd[((size_t)img * 2 + 1) * N + p[q]] = x2[q];
         }
@@ -297,10 +377,11 @@ struct FlowBwdArgs {
     int S1;             // K (dscale) + 2K (db2 s,t) + 6 (dA, db)
 };
 
-template <int K, int Q>
+template <int K, int Q, int U>
 __global__ __launch_bounds__(256) void flow_bwd_points_kernel(const FlowBwdArgs a) {
     const int img = blockIdx.y;
-    const int N = (int)a.N, W = a.m.W, BS = blockDim.x;
+    const int N = (int)a.N, W = a.m.W, BS = blockDim.x, PB = BS / U;
+    const int sl = threadIdx.x & (U - 1);   // U lanes per point (flow_fwd_kernel): lane 0 of a point owns its outputs and sums
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     flow_weights_to_lds(a.FE + (size_t)img * a.m.FE, fsm, a.m.FE);
     const RecL e{fsm};
@@ -312,9 +393,9 @@ __global__ __launch_bounds__(256) void flow_bwd_points_kernel(const FlowBwdArgs 
     float x1[Q], x2[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        p[q] = (blockIdx.x * Q + q) * BS + threadIdx.x;
-        valid[q] = p[q] < N;
-        load_coords2(a.grid, img, a.N, valid[q] ? p[q] : N - 1, xin[q]);
+        p[q] = (blockIdx.x * Q + q) * PB + threadIdx.x / U;
+        valid[q] = p[q] < N && sl == 0;
+        load_coords2(a.grid, img, a.N, p[q] < N ? p[q] : N - 1, xin[q]);
         x1[q] = fmaf(e.f(0), xin[q][0], fmaf(e.f(1), xin[q][1], e.f(4)));
         x2[q] = fmaf(e.f(2), xin[q][0], fmaf(e.f(3), xin[q][1], e.f(5)));
     }
@@ -328,7 +409,8 @@ __global__ __launch_bounds__(256) void flow_bwd_points_kernel(const FlowBwdArgs 
             x2s[i][q] = x2[q];
             u[q] = (i & 1) ? x2[q] : x1[q];
         }
-        nb_pair_forward<true, Q>(e.at(a.m.e_nb + i * a.m.e_cp_stride), W, u, st, dd);
+        if constexpr (U == 1) nb_pair_forward<true, Q>(e.at(a.m.e_nb + i * a.m.e_cp_stride), W, u, st, dd);
+        else nb_pair_forward_split<true, U, Q>(e.at(a.m.e_nb + i * a.m.e_cp_stride), W, sl, u, st, dd);
         const float sc = e.f(a.m.e_scale + i);
 #pragma unroll
         for (int q = 0; q < Q; ++q) {

@@ -1137,8 +1137,8 @@ CdnWs carve_cdn(const KernelEntry* e, const InrFlowDesc* f, const InrGridDesc* g
     CdnWs w;
     const long long N = grid->n_points;
     w.fm = make_flow_map(f->width, f->num_coupling, f->backbone == INR_FLOW_SIMPLE ? 0.f : LEAKY_SLOPE);
-    w.sf = flow_launch_shape(N, n_images, 20, 4);
-    w.sb = flow_launch_shape(N, n_images, 40, 2);
+    w.sf = flow_launch_shape(N, n_images, false);
+    w.sb = flow_launch_shape(N, n_images, true);
     w.blocks1 = w.sb.blocks;
     w.Wp = (f->width + 63) / 64 * 64;
     w.chunks = 64;   // x 2K nets x 4 waves: enough waves for 1024 SIMDs at one image
@@ -1223,13 +1223,22 @@ void launch_flow_fwd(const CdnWs& w, const InrGridDesc* grid, int n_images, floa
     a.m = w.fm;
     const dim3 g(w.sf.blocks, n_images), b(w.sf.threads);
     const size_t lds = (w.fm.FE + 64) * sizeof(float);   // + slack: the pipelined unit loop reads one batch ahead
-    hipLaunchKernelGGL(flow_fwd_kernel<1>, g, b, lds, s, a);   // (Q > 1: measured slower, flow.h)
+    if (w.sf.U == 4 && w.sf.Q == 2) hipLaunchKernelGGL((flow_fwd_kernel<2, 4>), g, b, lds, s, a);
+    else if (w.sf.U == 4) hipLaunchKernelGGL((flow_fwd_kernel<1, 4>), g, b, lds, s, a);
+    else if (w.sf.U == 2) hipLaunchKernelGGL((flow_fwd_kernel<1, 2>), g, b, lds, s, a);
+    else hipLaunchKernelGGL((flow_fwd_kernel<1, 1>), g, b, lds, s, a);
 }
 
 void launch_flow_bwd_points(const CdnWs& w, int K, int n_images, const FlowBwdArgs& a, hipStream_t s) {
     const dim3 g1(w.sb.blocks, n_images), b1(w.sb.threads);
     const size_t lds = (w.fm.FE + 64) * sizeof(float);
-#define INR_FLOW_BWD(KK) hipLaunchKernelGGL((flow_bwd_points_kernel<KK, 1>), g1, b1, lds, s, a)
+#define INR_FLOW_BWD(KK)                                                                                 \
+    do {                                                                                                 \
+        if (w.sb.U == 4 && w.sb.Q == 2) hipLaunchKernelGGL((flow_bwd_points_kernel<KK, 2, 4>), g1, b1, lds, s, a); \
+        else if (w.sb.U == 4) hipLaunchKernelGGL((flow_bwd_points_kernel<KK, 1, 4>), g1, b1, lds, s, a);     \
+        else if (w.sb.U == 2) hipLaunchKernelGGL((flow_bwd_points_kernel<KK, 1, 2>), g1, b1, lds, s, a);     \
+        else hipLaunchKernelGGL((flow_bwd_points_kernel<KK, 1, 1>), g1, b1, lds, s, a);                     \
+    } while (0)
     switch (K) {
         case 2: INR_FLOW_BWD(2); break;
         case 4: INR_FLOW_BWD(4); break;
@@ -1488,8 +1497,8 @@ PcnWs carve_pcn(const KernelEntry* e, const InrRnvpDesc* r, const InrGridDesc* g
     const long long N = grid->n_points;
     w.rm = make_rnvp_map(r);
     const int C = w.rm.C, F = w.rm.F;
-    w.sf = flow_launch_shape(N, n_images, 20, 4);
-    w.sb = flow_launch_shape(N, n_images, 40, 2);
+    w.sf = plain_launch_shape(N);   // the RealNVP point kernels: one lane per point (32 hidden units per flow: nothing to split)
+    w.sb = plain_launch_shape(N);
     w.blocks1 = w.sb.blocks;
     w.chunks = 64;   // x F flows x 4 waves: enough waves for the 1024 SIMDs
     while (w.chunks > 1 && N / w.chunks < 1024) w.chunks /= 2;

@@ -100,8 +100,23 @@ def _cdn_case(layers, width, K, h=130, seed=5):
     return m, {k: v.clone() for k, v in m.state_dict().items()}
 
 
+@pytest.fixture
+def flow_shape(request):
+    """Launch shape of the coupling-flow point kernels (csrc/flow.h: U lanes per point, Q points per lane); None = what the library picks
+    for the launch's size (small launches: forward (4, 2), backward (2, 1))."""
+    import os
+    old = os.environ.pop("INR_FLOW_SHAPE", None)
+    if request.param is not None:
+        os.environ["INR_FLOW_SHAPE"] = request.param
+    yield request.param
+    os.environ.pop("INR_FLOW_SHAPE", None)
+    if old is not None:
+        os.environ["INR_FLOW_SHAPE"] = old
+
+
+@pytest.mark.parametrize("flow_shape", [None, "11", "21", "41", "42"], indirect=True)
 @pytest.mark.parametrize("layers,width,K", [(1, 130, 6), (2, 24, 4), (1, 70, 2), (1, 200, 8), (2, 256, 2)])
-def test_hip_flow_forward_and_cdn_gradients(dev, layers, width, K):
+def test_hip_flow_forward_and_cdn_gradients(dev, layers, width, K, flow_shape):
     import awesome_amd as A
     from awesome_amd import flow as FL
     m, sd = _cdn_case(layers, width, K)
