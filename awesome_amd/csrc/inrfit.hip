@@ -1268,6 +1268,19 @@ void launch_flow_bwd(const CdnWs& w, const InrFlowDesc* f, const InrGridDesc* gr
     ua.chunks = w.chunks;
     ua.Wp = w.Wp;
     const dim3 g2(w.chunks, 2 * f->num_coupling, n_images);
+    const int W = w.fm.W, rem = W % 64, full = W / 64;
+    if (full >= 1 && full <= 3 && rem >= 1 && rem <= 4) {   // a few units past a multiple of 64 (W = 130): lane = point for those
+#define INR_UNITS_REM(UU)                                                                                     \
+    switch (rem) {                                                                                            \
+        case 1: hipLaunchKernelGGL((flow_bwd_units_kernel<UU, 1>), g2, dim3(256), 0, s, ua); break;           \
+        case 2: hipLaunchKernelGGL((flow_bwd_units_kernel<UU, 2>), g2, dim3(256), 0, s, ua); break;           \
+        case 3: hipLaunchKernelGGL((flow_bwd_units_kernel<UU, 3>), g2, dim3(256), 0, s, ua); break;           \
+        default: hipLaunchKernelGGL((flow_bwd_units_kernel<UU, 4>), g2, dim3(256), 0, s, ua); break;          \
+    }
+        if (full == 1) { INR_UNITS_REM(1) } else if (full == 2) { INR_UNITS_REM(2) } else { INR_UNITS_REM(3) }
+#undef INR_UNITS_REM
+        return;
+    }
     switch (w.Wp / 64) {
         case 1: hipLaunchKernelGGL(flow_bwd_units_kernel<1>, g2, dim3(256), 0, s, ua); break;
         case 2: hipLaunchKernelGGL(flow_bwd_units_kernel<2>, g2, dim3(256), 0, s, ua); break;
