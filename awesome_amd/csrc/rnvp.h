@@ -468,15 +468,13 @@ struct RnvpBwdArgs {
 template <int C, unsigned MASK, bool TANH, int Q>
 __device__ __forceinline__ void rnvp_flow_backward_m(const RnvpBwdArgs& a, const RecL rec, const RecL tl, int img, int f, int N,
                                                      const int (&p)[Q], const int (&pc)[Q], const bool (&valid)[Q], float (&g)[Q][C],
-                                                     float (&acc)[4 * C]) {
+                                                     float (&acc)[4 * C], const float (&z)[Q][C]) {
     using M = MaskT<C, MASK>;
     constexpr int NIN = M::NIN, NOUT = M::NOUT;
     const int F = a.m.F;
-    float z[Q][C], zin[Q][NIN];
+    float zin[Q][NIN];   // z = the state in front of this flow (zs), loaded by the caller one flow ahead
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) z[q][c] = a.zs[(((size_t)img * F + f) * C + c) * N + pc[q]];
         zin[q][0] = z[q][M::in0];
         if constexpr (NIN > 1) zin[q][NIN - 1] = z[q][M::in1 < C ? M::in1 : 0];
     }
@@ -566,15 +564,31 @@ __global__ __launch_bounds__(256) void rnvp_bwd_points_kernel(const RnvpBwdArgs 
             g[q][c] = d * (a.m.vmax[c] - a.m.vmin[c]) / (a.m.nmax - a.m.nmin);
         }
     }
+    // The state in front of flow f (saved by the forward kernel) is requested one flow AHEAD: loaded where it is used, every flow of the
+    // walk began with a trip to memory that nothing covered at one wave per SIMD (12 flows: ~8 of the kernel's 29 us at 256x256).
+    auto load_state = [&](int f, float (&z)[Q][C]) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int c = 0; c < C; ++c) z[q][c] = a.zs[(((size_t)img * F + f) * C + c) * N + pc[q]];
+    };
+    float znext[Q][C];
+    load_state(F - 1, znext);
     for (int f = F - 1; f >= 0; --f) {
         const RecL rec = img_rec.at(RNVP_HDR + f * a.m.fl);
         const RecL tl = rec.at(a.m.HID * RNVP_REC);
         float acc[4 * C];   // db2s[C] | db2t[C] | das[C] | dat[C]
 #pragma unroll
         for (int k = 0; k < 4 * C; ++k) acc[k] = 0.f;
+        float zcur[Q][C];
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int c = 0; c < C; ++c) zcur[q][c] = znext[q][c];
+        if (f > 0) load_state(f - 1, znext);
         with_mask<C>(a.m.masks[f], [&](auto mk) {
-            if (a.m.out_fn) rnvp_flow_backward_m<C, decltype(mk)::value, true, Q>(a, rec, tl, img, f, N, p, pc, valid, g, acc);
-            else rnvp_flow_backward_m<C, decltype(mk)::value, false, Q>(a, rec, tl, img, f, N, p, pc, valid, g, acc);
+            if (a.m.out_fn) rnvp_flow_backward_m<C, decltype(mk)::value, true, Q>(a, rec, tl, img, f, N, p, pc, valid, g, acc, zcur);
+            else rnvp_flow_backward_m<C, decltype(mk)::value, false, Q>(a, rec, tl, img, f, N, p, pc, valid, g, acc, zcur);
         });
 #pragma unroll
         for (int k = 0; k < 4 * C; ++k) {
