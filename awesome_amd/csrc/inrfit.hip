@@ -1510,8 +1510,19 @@ PcnWs carve_pcn(const KernelEntry* e, const InrRnvpDesc* r, const InrGridDesc* g
     const long long N = grid->n_points;
     w.rm = make_rnvp_map(r);
     const int C = w.rm.C, F = w.rm.F;
-    w.sf = plain_launch_shape(N);   // the RealNVP point kernels: one lane per point (32 hidden units per flow: nothing to split)
-    w.sb = plain_launch_shape(N);
+    // The RealNVP point kernels (32 hidden units per flow: the per-flow scalar work, evaluated by every lane of a point, is as large as
+    // the unit loop).  Small launches at C = 2: the FORWARD cuts the unit loop over 2 lanes (flow.h: U lanes per point; 16.8 -> 14.7 us at
+    // 256x256, U = 4: 15.9); the backward stays at one lane per point (U = 2: 26.8 vs 26.3 us, U = 4: 30.5, and twice / four times the
+    // partial-sum blocks for the update).  INR_RNVP_SHAPE = U forces both (measurement / test switch).
+    {
+        const char* fe = getenv("INR_RNVP_SHAPE");
+        const bool small = C == 2 && N * n_images <= 98304;
+        int uf = fe ? atoi(fe) : (small ? 2 : 1), ub = fe ? atoi(fe) : 1;
+        if ((uf != 1 && uf != 2 && uf != 4) || C != 2) uf = 1;
+        if ((ub != 1 && ub != 2 && ub != 4) || C != 2) ub = 1;
+        w.sf = FlowShape{1, uf, 256, (int)((N * uf + 255) / 256)};
+        w.sb = FlowShape{1, ub, 256, (int)((N * ub + 255) / 256)};
+    }
     w.blocks1 = w.sb.blocks;
     w.chunks = 64;   // x F flows x 4 waves: enough waves for the 1024 SIMDs
     while (w.chunks > 1 && N / w.chunks < 1024) w.chunks /= 2;
@@ -1550,6 +1561,10 @@ int rnvp_set_lds() {
     ok &= hipFuncSetAttribute((const void*)rnvp_fwd_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
     ok &= hipFuncSetAttribute((const void*)rnvp_bwd_points_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
     ok &= hipFuncSetAttribute((const void*)rnvp_bwd_points_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)rnvp_fwd_kernel<2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)rnvp_fwd_kernel<2, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)rnvp_bwd_points_kernel<2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)rnvp_bwd_points_kernel<2, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
     ok &= hipFuncSetAttribute((const void*)rnvp_inverse_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
     ok &= hipFuncSetAttribute((const void*)rnvp_inverse_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
     rc = ok ? INR_OK : INR_ENODEVICE;
@@ -1610,8 +1625,13 @@ void launch_rnvp_fwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, i
     a.m = w.rm;
     const dim3 g(w.sf.blocks, n_images), b(w.sf.threads);
     const size_t lds = (size_t)(w.rm.LDSF + 64) * sizeof(float);   // + slack: the pipelined unit loop reads one batch ahead
-    if (w.rm.C == 2) hipLaunchKernelGGL((rnvp_fwd_kernel<2, 1>), g, b, lds, s, a);   // (Q > 1: measured slower, flow.h)
-    else hipLaunchKernelGGL((rnvp_fwd_kernel<3, 1>), g, b, lds, s, a);
+    if (w.rm.C == 2) {
+        if (w.sf.U == 2) hipLaunchKernelGGL((rnvp_fwd_kernel<2, 1, 2>), g, b, lds, s, a);
+        else if (w.sf.U == 4) hipLaunchKernelGGL((rnvp_fwd_kernel<2, 1, 4>), g, b, lds, s, a);
+        else hipLaunchKernelGGL((rnvp_fwd_kernel<2, 1>), g, b, lds, s, a);   // (Q > 1: measured slower, flow.h)
+    } else {
+        hipLaunchKernelGGL((rnvp_fwd_kernel<3, 1>), g, b, lds, s, a);
+    }
 }
 
 void launch_rnvp_bwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, int n_images, hipStream_t s) {
@@ -1627,8 +1647,13 @@ void launch_rnvp_bwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, i
     a.S1 = w.S1;
     const dim3 g1(w.sb.blocks, n_images), b1(w.sb.threads);
     const size_t lds = (size_t)(w.rm.LDSF + 4 * w.S1) * sizeof(float);
-    if (w.rm.C == 2) hipLaunchKernelGGL((rnvp_bwd_points_kernel<2, 1>), g1, b1, lds, s, a);
-    else hipLaunchKernelGGL((rnvp_bwd_points_kernel<3, 1>), g1, b1, lds, s, a);
+    if (w.rm.C == 2) {
+        if (w.sb.U == 2) hipLaunchKernelGGL((rnvp_bwd_points_kernel<2, 1, 2>), g1, b1, lds, s, a);
+        else if (w.sb.U == 4) hipLaunchKernelGGL((rnvp_bwd_points_kernel<2, 1, 4>), g1, b1, lds, s, a);
+        else hipLaunchKernelGGL((rnvp_bwd_points_kernel<2, 1>), g1, b1, lds, s, a);
+    } else {
+        hipLaunchKernelGGL((rnvp_bwd_points_kernel<3, 1>), g1, b1, lds, s, a);
+    }
     RnvpUnitsArgs ua{};
     ua.RP = rp;
     ua.zs = w.zs;

@@ -197,10 +197,67 @@ __global__ __launch_bounds__(256) void rnvp_pack_kernel(const RnvpPackArgs a) {
 
 // pre-activation outputs o[q][k] = (o_s, o_t) of the two MLPs of one flow for the NOUT active output channels of Q points
 // per lane (a record read from LDS serves all Q); DU: also J[q][k][m] = d o[k] / d zin[m] (packed for both nets).
-template <int NIN, int NOUT, bool DU, int Q, class Rec>
+// U > 1: the U adjacent lanes of a point share the unit loop (flow.h, nb_pair_forward_split): lane sl takes the units sl, sl + U, ...,
+// the partial (o, J) sums are added over the lanes with DPP, every lane ends with the same values.
+template <int NIN, int NOUT, bool DU, int Q, class Rec, int U = 1>
 __device__ __forceinline__ void rnvp_nets(const Rec rec, int HID, const float (&zin)[Q][NIN], f32x2 (&o)[Q][NOUT],
-                                          f32x2 (&J)[Q][NOUT][NIN]) {
+                                          f32x2 (&J)[Q][NOUT][NIN], const int sl = 0) {
     const f32x4 tl = rec.v4(HID * RNVP_REC);
+    if constexpr (U > 1) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) {
+                o[q][k] = f32x2{0.f, 0.f};
+#pragma unroll
+                for (int mm = 0; mm < NIN; ++mm) J[q][k][mm] = f32x2{0.f, 0.f};
+            }
+        auto unit = [&](const f32x4& r0, const f32x4& r1) {
+            const float v[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                f32x2 pre = f32x2{v[2 * NIN], v[2 * NIN + 1]};
+#pragma unroll
+                for (int mm = 0; mm < NIN; ++mm) pre = pk_fma(f32x2{v[2 * mm], v[2 * mm + 1]}, splat2(zin[q][mm]), pre);
+                if (DU) {
+                    const f32x2 st = step01(pre);
+                    const f32x2 h = pre * st;
+                    f32x2 t[NIN];
+#pragma unroll
+                    for (int mm = 0; mm < NIN; ++mm) t[mm] = st * f32x2{v[2 * mm], v[2 * mm + 1]};
+#pragma unroll
+                    for (int k = 0; k < NOUT; ++k) {
+                        const f32x2 w2 = f32x2{v[2 * (NIN + 1 + k)], v[2 * (NIN + 1 + k) + 1]};
+                        o[q][k] = pk_fma(w2, h, o[q][k]);
+#pragma unroll
+                        for (int mm = 0; mm < NIN; ++mm) J[q][k][mm] = pk_fma(w2, t[mm], J[q][k][mm]);
+                    }
+                } else {
+                    const f32x2 h = f32x2{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f)};
+#pragma unroll
+                    for (int k = 0; k < NOUT; ++k) o[q][k] = pk_fma(f32x2{v[2 * (NIN + 1 + k)], v[2 * (NIN + 1 + k) + 1]}, h, o[q][k]);
+                }
+            }
+        };
+        const int steps = HID / U;
+#pragma unroll 4
+        for (int t = 0; t < steps; ++t) unit(rec.v4(RNVP_REC * (t * U + sl)), rec.v4(RNVP_REC * (t * U + sl) + 4));
+        if (steps * U + sl < HID) unit(rec.v4(RNVP_REC * (steps * U + sl)), rec.v4(RNVP_REC * (steps * U + sl) + 4));
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) {
+                o[q][k] = f32x2{lanes_sum<U>(o[q][k][0]), lanes_sum<U>(o[q][k][1])};
+                if (DU) {
+#pragma unroll
+                    for (int mm = 0; mm < NIN; ++mm) J[q][k][mm] = f32x2{lanes_sum<U>(J[q][k][mm][0]), lanes_sum<U>(J[q][k][mm][1])};
+                }
+            }
+            o[q][0] += f32x2{tl[0], tl[1]};
+            if (NOUT > 1) o[q][NOUT - 1] += f32x2{tl[2], tl[3]};
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         o[q][0] = f32x2{tl[0], tl[1]};
@@ -281,8 +338,8 @@ __device__ __forceinline__ void rnvp_nets(const Rec rec, int HID, const float (&
 }
 
 // one flow on z (MaskedAffineFlow, then ActNorm unless !ACTNORM), channel roles fixed at compile time
-template <int C, unsigned MASK, bool ACTNORM, bool TANH, int Q, class Rec>
-__device__ __forceinline__ void rnvp_flow_forward_m(const Rec rec, const RnvpMap& m, float (&z)[Q][C]) {
+template <int C, unsigned MASK, bool ACTNORM, bool TANH, int Q, class Rec, int U = 1>
+__device__ __forceinline__ void rnvp_flow_forward_m(const Rec rec, const RnvpMap& m, float (&z)[Q][C], const int sl = 0) {
     using M = MaskT<C, MASK>;
     constexpr int NIN = M::NIN, NOUT = M::NOUT;
     float zin[Q][NIN];
@@ -292,7 +349,7 @@ __device__ __forceinline__ void rnvp_flow_forward_m(const Rec rec, const RnvpMap
         zin[q][0] = z[q][M::in0];
         if constexpr (NIN > 1) zin[q][NIN - 1] = z[q][M::in1];
     }
-    rnvp_nets<NIN, NOUT, false, Q>(rec, m.HID, zin, o, J);
+    rnvp_nets<NIN, NOUT, false, Q, Rec, U>(rec, m.HID, zin, o, J, sl);
     const Rec tl = rec.at(m.HID * RNVP_REC);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
@@ -316,12 +373,12 @@ __device__ __forceinline__ void rnvp_flow_forward_m(const Rec rec, const RnvpMap
 }
 
 // run-time mask (wave-uniform) and output function -> the specialised body
-template <int C, bool ACTNORM, int Q, class Rec>
-__device__ __forceinline__ void rnvp_flow_forward(const Rec rec, const RnvpMap& m, unsigned mask, float (&z)[Q][C]) {
+template <int C, bool ACTNORM, int Q, class Rec, int U = 1>
+__device__ __forceinline__ void rnvp_flow_forward(const Rec rec, const RnvpMap& m, unsigned mask, float (&z)[Q][C], const int sl = 0) {
     with_mask<C>(mask, [&](auto mk) {
         constexpr unsigned MASK = decltype(mk)::value;
-        if (m.out_fn) rnvp_flow_forward_m<C, MASK, ACTNORM, true, Q>(rec, m, z);
-        else rnvp_flow_forward_m<C, MASK, ACTNORM, false, Q>(rec, m, z);
+        if (m.out_fn) rnvp_flow_forward_m<C, MASK, ACTNORM, true, Q, Rec, U>(rec, m, z, sl);
+        else rnvp_flow_forward_m<C, MASK, ACTNORM, false, Q, Rec, U>(rec, m, z, sl);
     });
 }
 
@@ -350,19 +407,21 @@ struct RnvpFwdArgs {
 
 // grid: x = blocks of 256 Q points (lane t of the block owns points base + q 256 + t), y = image.  Q = 2 when there are
 // enough points to keep every SIMD busy with half the waves: the broadcast record reads are the bottleneck of the unit loops.
-template <int C, int Q>
+template <int C, int Q, int U = 1>
 __global__ __launch_bounds__(256) void rnvp_fwd_kernel(const RnvpFwdArgs a) {
     const int img = blockIdx.y;
     const int N = (int)a.N;
     extern __shared__ __attribute__((aligned(16))) float rsm[];
     flow_weights_to_lds(a.RE + (size_t)img * a.m.LDSF, rsm, a.m.LDSF);
-    const RecL img_rec{rsm};   // (flow.h: why LDS and why Q points per lane)
-    const int BS = blockDim.x;
+    const RecL img_rec{rsm};   // (flow.h: why LDS, and U lanes per point for small launches)
+    const int BS = blockDim.x / U;
+    const int sl = threadIdx.x & (U - 1);
+    const bool own = sl == 0;   // lane 0 of a point stores its values
     int p[Q];
     float z[Q][C];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        p[q] = (blockIdx.x * Q + q) * BS + threadIdx.x;
+        p[q] = (blockIdx.x * Q + q) * BS + threadIdx.x / U;
         float x[C];
         load_coords<C>(a.grid, img, a.N, p[q] < N ? p[q] : N - 1, x);
 #pragma unroll
@@ -372,16 +431,16 @@ __global__ __launch_bounds__(256) void rnvp_fwd_kernel(const RnvpFwdArgs a) {
         if (a.zs != nullptr) {
 #pragma unroll
             for (int q = 0; q < Q; ++q)
-                if (p[q] < N) {
+                if (p[q] < N && own) {
 #pragma unroll
                     for (int c = 0; c < C; ++c) a.zs[(((size_t)img * a.m.F + f) * C + c) * N + p[q]] = z[q][c];
                 }
         }
-        rnvp_flow_forward<C, true, Q>(img_rec.at(RNVP_HDR + f * a.m.fl), a.m, a.m.masks[f], z);
+        rnvp_flow_forward<C, true, Q, RecL, U>(img_rec.at(RNVP_HDR + f * a.m.fl), a.m, a.m.masks[f], z, sl);
     }
 #pragma unroll
     for (int q = 0; q < Q; ++q)
-        if (p[q] < N) {
+        if (p[q] < N && own) {
 #pragma unroll
             for (int c = 0; c < C; ++c)
                 a.xd[((size_t)img * C + c) * N + p[q]] = minmax_fwd(z[q][c], a.m.nmin, a.m.nmax, a.m.vmin[c], a.m.vmax[c]);
@@ -465,10 +524,10 @@ struct RnvpBwdArgs {
 // One flow of the backward walk for Q points per lane, channel roles fixed at compile time.  In: g = d loss / d (state behind this
 // flow's ActNorm); out: g = d loss / d (state in front of the flow), per-lane partial sums of the per-point-scalar gradients in
 // acc (db2s [C] | db2t [C] | das [C] | dat [C]), and per point the gradients at the MLP outputs in ps (do_s [NOUT] | do_t [NOUT]).
-template <int C, unsigned MASK, bool TANH, int Q>
+template <int C, unsigned MASK, bool TANH, int Q, int U = 1>
 __device__ __forceinline__ void rnvp_flow_backward_m(const RnvpBwdArgs& a, const RecL rec, const RecL tl, int img, int f, int N,
                                                      const int (&p)[Q], const int (&pc)[Q], const bool (&valid)[Q], float (&g)[Q][C],
-                                                     float (&acc)[4 * C], const float (&z)[Q][C]) {
+                                                     float (&acc)[4 * C], const float (&z)[Q][C], const int sl = 0) {
     using M = MaskT<C, MASK>;
     constexpr int NIN = M::NIN, NOUT = M::NOUT;
     const int F = a.m.F;
@@ -479,7 +538,7 @@ __device__ __forceinline__ void rnvp_flow_backward_m(const RnvpBwdArgs& a, const
         if constexpr (NIN > 1) zin[q][NIN - 1] = z[q][M::in1 < C ? M::in1 : 0];
     }
     f32x2 o[Q][NOUT], J[Q][NOUT][NIN];
-    rnvp_nets<NIN, NOUT, true, Q>(rec, a.m.HID, zin, o, J);
+    rnvp_nets<NIN, NOUT, true, Q, RecL, U>(rec, a.m.HID, zin, o, J, sl);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         // post-coupling state and the outputs of the nets
@@ -539,7 +598,7 @@ __device__ __forceinline__ void rnvp_flow_backward_m(const RnvpBwdArgs& a, const
     }
 }
 
-template <int C, int Q>
+template <int C, int Q, int U = 1>
 __global__ __launch_bounds__(256) void rnvp_bwd_points_kernel(const RnvpBwdArgs a) {
     const int img = blockIdx.y;
     const int N = (int)a.N, F = a.m.F;
@@ -548,16 +607,17 @@ __global__ __launch_bounds__(256) void rnvp_bwd_points_kernel(const RnvpBwdArgs 
     float* red = rsm + a.m.LDSF;   // [waves][S1]
     flow_weights_to_lds(a.RE + (size_t)img * a.m.LDSF, rsm, a.m.LDSF);
     const RecL img_rec{rsm};
-    const int BS = blockDim.x;
-    int p[Q], pc[Q];
+    const int BS = blockDim.x, PB = BS / U;
+    const int sl = threadIdx.x & (U - 1);   // U lanes per point (rnvp_fwd_kernel): lane 0 of a point owns its outputs and sums;
+    int p[Q], pc[Q];                        // the others start from a zero gradient, so everything they add is zero
     bool valid[Q];
     // gradient at the flow output: through MinMax.inverse_transform
     float g[Q][C];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        p[q] = (blockIdx.x * Q + q) * BS + threadIdx.x;
-        valid[q] = p[q] < N;
-        pc[q] = valid[q] ? p[q] : N - 1;
+        p[q] = (blockIdx.x * Q + q) * PB + threadIdx.x / U;
+        valid[q] = p[q] < N && sl == 0;
+        pc[q] = p[q] < N ? p[q] : N - 1;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float d = valid[q] ? a.dxd[((size_t)img * C + c) * N + pc[q]] : 0.f;
@@ -587,8 +647,8 @@ __global__ __launch_bounds__(256) void rnvp_bwd_points_kernel(const RnvpBwdArgs 
             for (int c = 0; c < C; ++c) zcur[q][c] = znext[q][c];
         if (f > 0) load_state(f - 1, znext);
         with_mask<C>(a.m.masks[f], [&](auto mk) {
-            if (a.m.out_fn) rnvp_flow_backward_m<C, decltype(mk)::value, true, Q>(a, rec, tl, img, f, N, p, pc, valid, g, acc, zcur);
-            else rnvp_flow_backward_m<C, decltype(mk)::value, false, Q>(a, rec, tl, img, f, N, p, pc, valid, g, acc, zcur);
+            if (a.m.out_fn) rnvp_flow_backward_m<C, decltype(mk)::value, true, Q, U>(a, rec, tl, img, f, N, p, pc, valid, g, acc, zcur, sl);
+            else rnvp_flow_backward_m<C, decltype(mk)::value, false, Q, U>(a, rec, tl, img, f, N, p, pc, valid, g, acc, zcur, sl);
         });
 #pragma unroll
         for (int k = 0; k < 4 * C; ++k) {

@@ -82,12 +82,27 @@ def test_masks_match_reference_factory():
         assert [int(sum(int(ref[f, c]) << c for c in range(C))) for f in range(F)] == got
 
 
+@pytest.fixture
+def rnvp_shape(request):
+    """Lanes per point of the RealNVP point kernels (csrc/inrfit.hip carve_pcn; C = 2 only): None = what the library picks for the
+    launch's size (small launches: forward 2, backward 1), "1" / "2" / "4" force both kernels."""
+    import os
+    old = os.environ.pop("INR_RNVP_SHAPE", None)
+    if request.param is not None:
+        os.environ["INR_RNVP_SHAPE"] = request.param
+    yield request.param
+    os.environ.pop("INR_RNVP_SHAPE", None)
+    if old is not None:
+        os.environ["INR_RNVP_SHAPE"] = old
+
+
+@pytest.mark.parametrize("rnvp_shape", [None, "1", "2", "4"], indirect=True)
 @pytest.mark.parametrize("C,hid,F,layers,fn,scale", [(2, 32, 12, 2, "tanh", None), (3, 32, 18, 2, "tanh", None),
                                                       (3, 20, 5, 1, None, None), (2, 64, 3, 1, "tanh", 0.5),
                                                       (2, 130, 6, 2, "tanh", None),     # the factory defaults for the sizes
                                                       (3, 130, 18, 1, "tanh", None),    # 76 KB of flow records in LDS
                                                       (3, 70, 4, 1, "tanh", None)])
-def test_forward_and_gradients(dev, C, hid, F, layers, fn, scale):
+def test_forward_and_gradients(dev, C, hid, F, layers, fn, scale, rnvp_shape):
     from awesome_amd import rnvp as R
     import awesome_amd as A
     ispec, rspec, sd = _case(C, hid, F, layers, seed=C * 7 + F, output_fn=fn, output_scale=scale)
