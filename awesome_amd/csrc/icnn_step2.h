@@ -65,6 +65,10 @@ struct Cfg2 {
     static constexpr int SL_COLS = SL_LOSS + 1;
 };
 
+#if INR_STAMPS
+__device__ unsigned long long g_stamps2[16];   // per-phase cycle sums of workgroup 0 / wave 0 of the last L = 2 launch (tools/stamps2.py)
+#endif
+
 template <int H, int C, bool TRAIN, bool DX = false, int ACT0 = INR_ACT_RELU>
 __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArgs a) {
     static_assert(!DX || TRAIN, "coordinate gradients are a by-product of the backward pass");
@@ -346,7 +350,13 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
         return q;
     };
     PointIn nxt = load_point(wg);
+#if INR_STAMPS
+    unsigned long long st_sum[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+    const unsigned long long st_begin = st_prev;
+#endif
     for (int chunk = wg; chunk < n_chunks; chunk += a.wgs) {
+        STAMP(0);
         const int p = chunk * SP + wave * 16 + l15;
         const bool valid = p < (int)N;
         const PointIn cur = nxt;
@@ -415,7 +425,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
         // last k-group of z1ext: lane group 0 = leftover units, lane groups 1-2 = the same ext inputs as in z0ext
 #pragma unroll
         for (int r = 0; r < 4; ++r) z1[TM][r] = g == 0 ? (r < HR ? z1l[r < HRA ? r : 0] : 0.f) : z0last[r];
+        STAMP(1);
         __syncthreads();  // (A) W2 image complete in LDS (re-fetch waited for by every wave's vmcnt(0) at this barrier)
+        STAMP(2);
 
         // ---- layer 2 ---------------------------------------------------------------------------------------------------
         f32x4 acc2[TM];
@@ -445,6 +457,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
         for (int c = 0; c < C; ++c) y = fmaf(s_o[c], x[c], y);
         if (a.logits != nullptr && valid && g == 0) a.logits[(size_t)img * N + p] = y;
 
+        STAMP(3);
         if (TRAIN) {
             const float pr = 1.f / (1.f + expf(-y));
             const float cw = tg < 0.5f ? cfg_ : cbg_;
@@ -504,8 +517,11 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
                 const float d = sum_over_groups(dz1l[u]);
                 dz1l[u] = z1l[u] > 0.f ? d : 0.f;
             }
+            STAMP(4);
             __syncthreads();  // (B) every wave is done with the W2 image: its region becomes the stage
+            STAMP(5);
             stage(acc2, dz2l, z1);  // staged early so that dz2 and z1 leave the register file before the next product
+            STAMP(6);
             // ---- backward through layer 1 (W1 image), transposed output; layer-0 gradient wave-locally ----------------------
             {
                 f32x4 dz0[TM];
@@ -608,18 +624,25 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
                     }
                 }
             }
+            STAMP(7);
             __syncthreads();  // (C)
+            STAMP(8);
             dw_phase(dWb, dWlb);
+            STAMP(9);
             __syncthreads();  // (D)
+            STAMP(10);
             {
                 f32x4 z0[KG];
                 z0_main(z0);
                 z0[TM] = z0last;
                 stage(dz1, dz1l, z0);
             }
+            STAMP(11);
             __syncthreads();  // (E)
             dw_phase(dWa, dWla);
+            STAMP(12);
             __syncthreads();  // (F)
+            STAMP(13);
             if (G::ALIAS && chunk + a.wgs < n_chunks) {
                 // re-fetch the W2 image straight into LDS (LDS-DMA: wave-uniform LDS base + lane*16, no registers);
                 // completion is awaited at barrier (A) of the next chunk, after that chunk's layer-1 product.
@@ -633,6 +656,14 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
         }
     }
 
+#if INR_STAMPS
+    if (TRAIN && blockIdx.x == 0 && tid == 0) {
+        unsigned long long st_end;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_end)::"memory");
+        for (int k = 0; k < 14; ++k) g_stamps2[k] = st_sum[k];
+        g_stamps2[14] = st_end - st_begin;
+    }
+#endif
     if (TRAIN) {
         __syncthreads();
         float* __restrict__ slab = a.slabs + ((size_t)img * a.wgs + wg) * a.PS;

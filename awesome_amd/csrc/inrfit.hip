@@ -2417,6 +2417,9 @@ int inrfit_pack_masks(const float* values, int n_images, int64_t n_points, float
 int inrfit_debug_updtimes(unsigned long long* host_out) {   // [512][4] of the last update launch
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_updtimes), sizeof(unsigned long long) * 2048) == hipSuccess ? 0 : -4;
 }
+int inrfit_debug_stamps2(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps2), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -4;
+}
 int inrfit_debug_stamps(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -4;
 }
