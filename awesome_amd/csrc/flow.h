@@ -89,6 +89,18 @@ __device__ __forceinline__ void flow_weights_to_lds(const float* __restrict__ sr
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 
+// relu through the CLAMP modifier.  The records hold the first layer scaled by REC_DOWN = 2^-32 and w2' scaled by REC_UP = 2^32 (exact:
+// powers of two), so one `v_pk_fma_f32 ... clamp` gives relu(pre) 2^-32 for every pre <= 2^32 (clamp = [0, 1]; coordinates and weights
+// are O(1)), and the second fma multiplies the 2^32 back in: two instructions per unit instead of fma + 2 x v_max + fma (there is no
+// packed fp32 max), the same bits.  src1 broadcasts its low half to both lanes (op_sel_hi).
+constexpr float REC_DOWN = 0x1p-32f, REC_UP = 0x1p32f;
+__device__ __forceinline__ f32x2 pk_fma_clamp_bcast(f32x2 a, float u, f32x2 c) {   // clamp01(a * (u, u) + c)
+    f32x2 r;
+    const f32x2 uu = f32x2{u, u};
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(uu), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ f32x2 step01(f32x2 pre) {
     f32x2 r;
     const f32x2 big = f32x2{0x1p126f, 0x1p126f};
@@ -167,10 +179,10 @@ __device__ __forceinline__ RecK rec_global(const float* image) { return RecK{(co
 // runs at (1, 1): more points per lane were measured slower at every size (profiles/NOTES.md).  A small launch (one image of 256x256:
 // ONE wave per SIMD at (1, 1)) cuts the unit loop over U lanes - forward U = 4 with every record read serving Q = 2 points, backward
 // U = 2 (it carries 7 saved values per coupling and point: fewer registers, fewer partial-sum blocks).
-// Measured (us, 256x256, K = 6, W = 130; tools/experiments/expq.sh; (U, Q)):
-//   forward            (1,1) 20.3 | (2,1) 16.5 | (4,1) 17.5 | (2,2) 18.5 | (4,2) 15.6 | (4,4) 18.3 | (8,2) 19.0 | (8,4) 19.4
-//   backward, points   (1,1) 23.8 | (2,1) 20.3 | (4,1) 22.4 | (4,2) 21.1
-//   Q alone (one lane per point, 256 / Q threads), forward: Q = 2 30.6, Q = 4 46.3
+// Measured (us, 256x256, K = 6, W = 130; tools/experiments/expq.sh; (U, Q); with the clamp-form unit evaluation):
+//   forward            (1,1) 19.9 | (2,1) 15.6 | (4,1) 16.7 | (2,2) 13.9 | (4,2) 13.0 | (4,4) 14.2      [before the clamp form: 20.3 .. 15.6]
+//   backward, points   (1,1) 22.3 | (2,1) 19.6 | (4,1) 21.7 | (4,2) 19.4
+//   Q alone (one lane per point, 256 / Q threads), forward, before the clamp form: Q = 2 30.6, Q = 4 46.3
 struct FlowShape { int Q, U, threads, blocks; };
 inline FlowShape flow_launch_shape(long long n_points, int n_images, bool backward) {
     FlowShape s;
@@ -179,7 +191,10 @@ inline FlowShape flow_launch_shape(long long n_points, int n_images, bool backwa
     const bool small = n_points * n_images <= 98304;
     s.U = force ? force / 10 : (small ? (backward ? 2 : 4) : 1);
     s.Q = force ? force % 10 : (small ? (backward ? 1 : 2) : 1);
-    if (!((s.U == 1 && s.Q == 1) || (s.U == 4 && s.Q == 2) || (s.U == 4 && s.Q == 1) || (s.U == 2 && s.Q == 1))) s.U = s.Q = 1;
+    const bool fwd_only = (s.U == 2 && s.Q == 2) || (s.U == 4 && s.Q == 4);   // forward instantiations without a backward twin
+    if (backward && fwd_only) s.Q = 1;
+    if (!((s.U == 1 && s.Q == 1) || (s.U == 4 && s.Q == 2) || (s.U == 4 && s.Q == 1) || (s.U == 2 && s.Q == 1) || (!backward && fwd_only)))
+        s.U = s.Q = 1;
     s.threads = 256;
     s.blocks = (int)((n_points * s.U + 256 * s.Q - 1) / (256 * s.Q));
     return s;
@@ -212,14 +227,9 @@ __device__ __forceinline__ void nb_pair_forward_split(const Rec e, int W, const 
     auto unit = [&](const f32x4& lo, const f32x4& hi) {   // lo = (w1s, w1t, b1s, b1t), hi = (w2's, w2't, w1s w2's, w1t w2't)
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            const f32x2 pre = pk_fma(f32x2{lo[0], lo[1]}, splat2(u[q]), f32x2{lo[2], lo[3]});
-            if (DU) {
-                const f32x2 sp = step01(pre);
-                acc[q] = pk_fma(f32x2{hi[0], hi[1]}, pre * sp, acc[q]);
-                d[q] = pk_fma(f32x2{hi[2], hi[3]}, sp, d[q]);
-            } else {
-                acc[q] = pk_fma(f32x2{hi[0], hi[1]}, f32x2{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f)}, acc[q]);
-            }
+            const f32x2 h = pk_fma_clamp_bcast(f32x2{lo[0], lo[1]}, u[q], f32x2{lo[2], lo[3]});   // relu(pre) 2^-32
+            acc[q] = pk_fma(f32x2{hi[0], hi[1]}, h, acc[q]);
+            if (DU) d[q] = pk_fma(f32x2{hi[2], hi[3]}, step01(h), d[q]);
         }
     };
     const int steps = W / U;
@@ -259,16 +269,15 @@ __device__ __forceinline__ void nb_pair_forward(const Rec e, int W, const float 
     auto unit = [&](const f32x4& lo, const f32x4& hi) {   // lo = (w1s, w1t, b1s, b1t), hi = (w2's, w2't, w1s w2's, w1t w2't)
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            f32x2 pre;
-            if constexpr (Rec::SCALAR) pre = f32x2{lo[0], lo[1]} * splat2(u[q]) + f32x2{lo[2], lo[3]};   // one SGPR pair per instruction
-            else pre = pk_fma(f32x2{lo[0], lo[1]}, splat2(u[q]), f32x2{lo[2], lo[3]});
-            if (DU) {
-                const f32x2 sp = step01(pre);
-                acc[q] = pk_fma(f32x2{hi[0], hi[1]}, pre * sp, acc[q]);
-                d[q] = pk_fma(f32x2{hi[2], hi[3]}, sp, d[q]);
+            f32x2 h;   // relu(pre) 2^-32 (pk_fma_clamp_bcast)
+            if constexpr (Rec::SCALAR) {   // (experiment path: one SGPR pair per instruction)
+                const f32x2 pre = f32x2{lo[0], lo[1]} * splat2(u[q]) + f32x2{lo[2], lo[3]};
+                h = f32x2{fminf(fmaxf(pre[0], 0.f), 1.f), fminf(fmaxf(pre[1], 0.f), 1.f)};
             } else {
-                acc[q] = pk_fma(f32x2{hi[0], hi[1]}, f32x2{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f)}, acc[q]);
+                h = pk_fma_clamp_bcast(f32x2{lo[0], lo[1]}, u[q], f32x2{lo[2], lo[3]});
             }
+            acc[q] = pk_fma(f32x2{hi[0], hi[1]}, h, acc[q]);
+            if (DU) d[q] = pk_fma(f32x2{hi[2], hi[3]}, step01(h), d[q]);
         }
     };
     // Software-pipelined over batches of 4 units (two register sets, ping-pong): the records of the NEXT batch are requested before the
@@ -518,9 +527,16 @@ __global__ __launch_bounds__(256) void flow_bwd_units_kernel(const FlowUnitsArgs
     for (int r = 0; r < UPL; ++r) {
         const int unit = r * 64 + lane;
         const bool on = unit < W;
-        w1[r] = on ? e[8 * unit] : 0.f;
-        b1[r] = on ? e[8 * unit + 2] : 0.f;
-        w2p[r] = on ? e[8 * unit + 4] : 0.f;
+        w1[r] = on ? e[8 * unit] * REC_UP : 0.f;          // the records are scaled (pk_fma_clamp_bcast): undo, exact
+        b1[r] = on ? e[8 * unit + 2] * REC_UP : 0.f;
+        w2p[r] = on ? e[8 * unit + 4] * REC_DOWN : 0.f;
+    }
+    // step(pre) in ONE instruction: the first layer scaled by 2^100, the fma clamped to [0, 1] (1 for every pre >= 2^-100, 0 for pre <= 0)
+    f32x2 w1s[UPL], b1s[UPL];
+#pragma unroll
+    for (int r = 0; r < UPL; ++r) {
+        w1s[r] = splat2(w1[r] * 0x1p100f);
+        b1s[r] = splat2(b1[r] * 0x1p100f);
     }
     const int per_chunk = (N + a.chunks - 1) / a.chunks;
     const int per_wave = (per_chunk + 3) / 4;
@@ -540,9 +556,9 @@ __global__ __launch_bounds__(256) void flow_bwd_units_kernel(const FlowUnitsArgs
     for (int m = 0; m < REMA; ++m) {
         const int unit = UPL * 64 + m;
         const bool on = REM > 0 && unit < W;
-        w1m[m] = on ? e[8 * unit] : 0.f;
-        b1m[m] = on ? e[8 * unit + 2] : 0.f;
-        w2pm[m] = on ? e[8 * unit + 4] : 0.f;
+        w1m[m] = on ? e[8 * unit] * REC_UP : 0.f;
+        b1m[m] = on ? e[8 * unit + 2] * REC_UP : 0.f;
+        w2pm[m] = on ? e[8 * unit + 4] * REC_DOWN : 0.f;
         a0m[m] = a1m[m] = 0.f;
     }
     float g0 = 0.f, g1 = 0.f;
@@ -578,7 +594,8 @@ __global__ __launch_bounds__(256) void flow_bwd_units_kernel(const FlowUnitsArgs
             const f32x2 gu2 = f32x2{bc(guc, k), bc(guc, k + 1)};
 #pragma unroll
             for (int r = 0; r < UPL; ++r) {
-                const f32x2 st = step01(pk_fma(splat2(w1[r]), u2, splat2(b1[r])));
+                f32x2 st;
+                asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(st) : "v"(w1s[r]), "s"(u2), "v"(b1s[r]));
                 A0[r] = pk_fma(gq2, st, A0[r]);
                 A1[r] = pk_fma(gu2, st, A1[r]);
             }
@@ -817,9 +834,9 @@ __device__ __forceinline__ void flow_update_body(const FlowUpdArgs& u, const int
         const float sa = block_sum256(w2e * w1e, sm, tid), sb = block_sum256(w2e * b1, sm, tid);
         if (on) {
             const float w2p = (1.f - m.slope) * w2e;
-            fe[eb + 8 * tid] = w1e;
-            fe[eb + 8 * tid + 2] = b1;
-            fe[eb + 8 * tid + 4] = w2p;
+            fe[eb + 8 * tid] = w1e * REC_DOWN;       // the first layer scaled down, w2' scaled up (pk_fma_clamp_bcast): exact
+            fe[eb + 8 * tid + 2] = b1 * REC_DOWN;
+            fe[eb + 8 * tid + 4] = w2p * REC_UP;
             fe[eb + 8 * tid + 6] = w1e * w2p;
         }
         if (tid == 0) {

@@ -1224,6 +1224,8 @@ void launch_flow_fwd(const CdnWs& w, const InrGridDesc* grid, int n_images, floa
     const dim3 g(w.sf.blocks, n_images), b(w.sf.threads);
     const size_t lds = (w.fm.FE + 64) * sizeof(float);   // + slack: the pipelined unit loop reads one batch ahead
     if (w.sf.U == 4 && w.sf.Q == 2) hipLaunchKernelGGL((flow_fwd_kernel<2, 4>), g, b, lds, s, a);
+    else if (w.sf.U == 4 && w.sf.Q == 4) hipLaunchKernelGGL((flow_fwd_kernel<4, 4>), g, b, lds, s, a);
+    else if (w.sf.U == 2 && w.sf.Q == 2) hipLaunchKernelGGL((flow_fwd_kernel<2, 2>), g, b, lds, s, a);
     else if (w.sf.U == 4) hipLaunchKernelGGL((flow_fwd_kernel<1, 4>), g, b, lds, s, a);
     else if (w.sf.U == 2) hipLaunchKernelGGL((flow_fwd_kernel<1, 2>), g, b, lds, s, a);
     else hipLaunchKernelGGL((flow_fwd_kernel<1, 1>), g, b, lds, s, a);

@@ -128,10 +128,10 @@ __device__ __forceinline__ void rnvp_flow_image(const float* __restrict__ rp, fl
     for (int i = tid; i < m.HID * RNVP_REC; i += nt) {
         const int j = i >> 3, slot = i & 7, q = slot >> 1;
         const float* __restrict__ pn = pf + (slot & 1) * m.net;
-        float v = 0.f;
-        if (q < x.nin) v = pn[j * C + x.in(q)];
-        else if (q == x.nin) v = pn[m.HID * C + j];
-        else if (q < x.nin + 1 + x.nout) v = pn[m.HID * C + m.HID + x.out(q - x.nin - 1) * m.HID + j];
+        float v = 0.f;   // first layer x 2^-32, second layer x 2^32: relu through the clamp modifier (flow.h, pk_fma_clamp_bcast); exact
+        if (q < x.nin) v = pn[j * C + x.in(q)] * REC_DOWN;
+        else if (q == x.nin) v = pn[m.HID * C + j] * REC_DOWN;
+        else if (q < x.nin + 1 + x.nout) v = pn[m.HID * C + m.HID + x.out(q - x.nin - 1) * m.HID + j] * REC_UP;
         dst[i] = v;
     }
     for (int i = tid; i < RNVP_TAIL; i += nt) {
@@ -218,10 +218,16 @@ __device__ __forceinline__ void rnvp_nets(const Rec rec, int HID, const float (&
             for (int q = 0; q < Q; ++q) {
                 f32x2 pre = f32x2{v[2 * NIN], v[2 * NIN + 1]};
 #pragma unroll
-                for (int mm = 0; mm < NIN; ++mm) pre = pk_fma(f32x2{v[2 * mm], v[2 * mm + 1]}, splat2(zin[q][mm]), pre);
+                for (int mm = 0; mm + 1 < NIN; ++mm) pre = pk_fma(f32x2{v[2 * mm], v[2 * mm + 1]}, splat2(zin[q][mm]), pre);
+                f32x2 h;   // relu(pre) 2^-32 (see the U = 1 body below for why the forward keeps v_max)
+                if constexpr (DU) {
+                    h = pk_fma_clamp_bcast(f32x2{v[2 * (NIN - 1)], v[2 * (NIN - 1) + 1]}, zin[q][NIN - 1], pre);
+                } else {
+                    pre = pk_fma(f32x2{v[2 * (NIN - 1)], v[2 * (NIN - 1) + 1]}, splat2(zin[q][NIN - 1]), pre);
+                    h = f32x2{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f)};
+                }
                 if (DU) {
-                    const f32x2 st = step01(pre);
-                    const f32x2 h = pre * st;
+                    const f32x2 st = step01(h);
                     f32x2 t[NIN];
 #pragma unroll
                     for (int mm = 0; mm < NIN; ++mm) t[mm] = st * f32x2{v[2 * mm], v[2 * mm + 1]};
@@ -233,7 +239,6 @@ __device__ __forceinline__ void rnvp_nets(const Rec rec, int HID, const float (&
                         for (int mm = 0; mm < NIN; ++mm) J[q][k][mm] = pk_fma(w2, t[mm], J[q][k][mm]);
                     }
                 } else {
-                    const f32x2 h = f32x2{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f)};
 #pragma unroll
                     for (int k = 0; k < NOUT; ++k) o[q][k] = pk_fma(f32x2{v[2 * (NIN + 1 + k)], v[2 * (NIN + 1 + k) + 1]}, h, o[q][k]);
                 }
@@ -271,20 +276,29 @@ __device__ __forceinline__ void rnvp_nets(const Rec rec, int HID, const float (&
         const float v[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            f32x2 pre;
-            if constexpr (Rec::SCALAR) {   // one SGPR pair per instruction: mul, (fma,) add
-                pre = f32x2{v[0], v[1]} * splat2(zin[q][0]);
+            f32x2 h;   // relu(pre) 2^-32: the last fma of the pre-activation carries the clamp (flow.h, pk_fma_clamp_bcast)
+            if constexpr (Rec::SCALAR) {   // (experiment path) one SGPR pair per instruction: mul, (fma,) add
+                f32x2 pre = f32x2{v[0], v[1]} * splat2(zin[q][0]);
 #pragma unroll
                 for (int mm = 1; mm < NIN; ++mm) pre = pk_fma(f32x2{v[2 * mm], v[2 * mm + 1]}, splat2(zin[q][mm]), pre);
                 pre = pre + f32x2{v[2 * NIN], v[2 * NIN + 1]};
+                h = f32x2{fminf(fmaxf(pre[0], 0.f), 1.f), fminf(fmaxf(pre[1], 0.f), 1.f)};
             } else {
-                pre = f32x2{v[2 * NIN], v[2 * NIN + 1]};
+                f32x2 pre = f32x2{v[2 * NIN], v[2 * NIN + 1]};
 #pragma unroll
-                for (int mm = 0; mm < NIN; ++mm) pre = pk_fma(f32x2{v[2 * mm], v[2 * mm + 1]}, splat2(zin[q][mm]), pre);
+                for (int mm = 0; mm + 1 < NIN; ++mm) pre = pk_fma(f32x2{v[2 * mm], v[2 * mm + 1]}, splat2(zin[q][mm]), pre);
+                if constexpr (DU) {
+                    h = pk_fma_clamp_bcast(f32x2{v[2 * (NIN - 1)], v[2 * (NIN - 1) + 1]}, zin[q][NIN - 1], pre);
+                } else {
+                    // The forward keeps fma + 2 x v_max on the (scaled) records: with the clamped asm form its kernels were SLOWER (256x256,
+                    // C = 2: 16.95 vs 14.7 us; configs[3]: 55.8 vs 53.9) - hipcc orders and narrows the record reads of the plain loop
+                    // better than around the asm statements; the backward kernels gain (26.3 -> 24.4, 104.4 -> 98.6 us).
+                    pre = pk_fma(f32x2{v[2 * (NIN - 1)], v[2 * (NIN - 1) + 1]}, splat2(zin[q][NIN - 1]), pre);
+                    h = f32x2{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f)};
+                }
             }
             if (DU) {
-                const f32x2 st = step01(pre);
-                const f32x2 h = pre * st;
+                const f32x2 st = step01(h);
                 f32x2 t[NIN];
 #pragma unroll
                 for (int mm = 0; mm < NIN; ++mm) t[mm] = st * f32x2{v[2 * mm], v[2 * mm + 1]};
@@ -296,7 +310,6 @@ __device__ __forceinline__ void rnvp_nets(const Rec rec, int HID, const float (&
                     for (int mm = 0; mm < NIN; ++mm) J[q][k][mm] = pk_fma(w2, t[mm], J[q][k][mm]);
                 }
             } else {
-                const f32x2 h = f32x2{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f)};
 #pragma unroll
                 for (int k = 0; k < NOUT; ++k) o[q][k] = pk_fma(f32x2{v[2 * (NIN + 1 + k)], v[2 * (NIN + 1 + k) + 1]}, h, o[q][k]);
             }

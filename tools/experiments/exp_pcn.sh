@@ -1,11 +1,11 @@
 #!/bin/bash
-# rocprofv3 kernel stats of the 256x256 PathConnectedNet fit (tools/kbench_pcn.py --case xy) per RealNVP launch shape (INR_RNVP_SHAPE = U)
+# rocprofv3 kernel stats of the PathConnectedNet fits (tools/kbench_pcn.py --case $CASE) per RealNVP launch shape (INR_RNVP_SHAPE = U; 0 = default)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
-for u in ${EXPU_LIST:-1 2 4}; do
-  export INR_RNVP_SHAPE=$u
+for u in ${EXPU_LIST:-0}; do
+  if [ "$u" = "0" ]; then unset INR_RNVP_SHAPE; else export INR_RNVP_SHAPE=$u; fi
   O=gpurun_out/exp_pcn_$u
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O -o pcn -- python3 tools/kbench_pcn.py --case xy > gpurun_out/exp_pcn_$u.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O -o pcn -- python3 tools/kbench_pcn.py --case ${CASE:-both} > gpurun_out/exp_pcn_$u.log 2>&1 || exit 1
   db=$(find $O -name "*.db" | head -1)
   python3 tools/rocpd_stats.py "$db" gpurun_out/exp_pcn_$u.csv
   rm -rf $O

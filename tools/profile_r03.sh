@@ -60,4 +60,15 @@ echo "== pmc SQ (pcn xyt) $(date +%T)"
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS -d $O/pcn_sq -o p -- $P > $O/pcn_sq.log 2>&1 || exit 1
 summ_pmc $O/pcn_sq pcn_pmc_sq
 fi
+if [ "$MODE" = "cdnpmc" ]; then   # coupling-flow point kernels at (1,1) and at the shipped split shapes: kernel stats + SQ counters
+for shp in 11 0; do
+  if [ "$shp" = "0" ]; then unset INR_FLOW_SHAPE; else export INR_FLOW_SHAPE=$shp; fi
+  echo "== cdn stats shape $shp $(date +%T)"
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/cdn_stats_$shp -o cdn -- python3 tools/kbench_cdn.py > $O/cdn_stats_$shp.log 2>&1 || exit 1
+  summ_stats $O/cdn_stats_$shp cdn_shape$shp
+  echo "== cdn pmc SQ shape $shp $(date +%T)"
+  timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS -d $O/cdn_sq_$shp -o p -- python3 tools/kbench_cdn.py --steps 30 > $O/cdn_sq_$shp.log 2>&1 || exit 1
+  summ_pmc $O/cdn_sq_$shp cdn_pmc_sq_shape$shp
+done
+fi
 rm -f $O/*.log.tmp; du -sh $O; ls -la $O
