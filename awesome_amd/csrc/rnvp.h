@@ -122,16 +122,17 @@ __device__ __forceinline__ void rnvp_header_image(const float* __restrict__ rp, 
 }
 
 template <int C>
-__device__ __forceinline__ void rnvp_flow_image(const float* __restrict__ rp, float* dst, const RnvpMap& m, int f, int tid, int nt) {
+__device__ __forceinline__ void rnvp_flow_image(const float* __restrict__ rp, float* dst, const RnvpMap& m, int f, int tid, int nt,
+                                                const float s1 = REC_DOWN, const float s2 = REC_UP) {
     const FlowIdx x = flow_idx<C>(m.masks[f]);
     const float* __restrict__ pf = rp + 2 * C + (size_t)f * m.pf;
     for (int i = tid; i < m.HID * RNVP_REC; i += nt) {
         const int j = i >> 3, slot = i & 7, q = slot >> 1;
         const float* __restrict__ pn = pf + (slot & 1) * m.net;
         float v = 0.f;   // first layer x 2^-32, second layer x 2^32: relu through the clamp modifier (flow.h, pk_fma_clamp_bcast); exact
-        if (q < x.nin) v = pn[j * C + x.in(q)] * REC_DOWN;
-        else if (q == x.nin) v = pn[m.HID * C + j] * REC_DOWN;
-        else if (q < x.nin + 1 + x.nout) v = pn[m.HID * C + m.HID + x.out(q - x.nin - 1) * m.HID + j] * REC_UP;
+        if (q < x.nin) v = pn[j * C + x.in(q)] * s1;
+        else if (q == x.nin) v = pn[m.HID * C + j] * s1;
+        else if (q < x.nin + 1 + x.nout) v = pn[m.HID * C + m.HID + x.out(q - x.nin - 1) * m.HID + j] * s2;
         dst[i] = v;
     }
     for (int i = tid; i < RNVP_TAIL; i += nt) {
@@ -728,7 +729,11 @@ __device__ __forceinline__ void rnvp_units_body(const RnvpUnitsArgs& a, const Fl
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = (int)a.N, HID = a.m.HID;
     const float* __restrict__ rp = a.RP + (size_t)img * a.m.RP;
-    rnvp_params_to_lds<C>(rp, lds, a.m, f, f + 1);
+    // this kernel's own image of flow f: the first layer scaled by 2^100, so that the LAST fma of a unit's pre-activation, clamped to
+    // [0, 1], IS step(pre) (1 for every pre >= 2^-100, 0 for pre <= 0): one instruction less per unit and point
+    rnvp_header_image<C>(rp, lds);
+    rnvp_flow_image<C>(rp, lds + RNVP_HDR, a.m, f, threadIdx.x, blockDim.x, 0x1p100f, 1.f);
+    __syncthreads();
     const float* rec = lds + RNVP_HDR;
     const int per_chunk = (N + a.chunks - 1) / a.chunks;
     const int p0 = chunk * per_chunk;
@@ -771,8 +776,8 @@ __device__ __forceinline__ void rnvp_units_body(const RnvpUnitsArgs& a, const Fl
                 for (int q = 0; q < PPL; ++q) {
                     f32x2 pre = f32x2{v[2 * NIN], v[2 * NIN + 1]};
 #pragma unroll
-                    for (int mm = 0; mm < NIN; ++mm) pre = pk_fma(f32x2{v[2 * mm], v[2 * mm + 1]}, splat2(zin[q][mm]), pre);
-                    const f32x2 st = step01(pre);
+                    for (int mm = 0; mm + 1 < NIN; ++mm) pre = pk_fma(f32x2{v[2 * mm], v[2 * mm + 1]}, splat2(zin[q][mm]), pre);
+                    const f32x2 st = pk_fma_clamp_bcast(f32x2{v[2 * (NIN - 1)], v[2 * (NIN - 1) + 1]}, zin[q][NIN - 1], pre);
 #pragma unroll
                     for (int k = 0; k < NOUT; ++k) {
                         S0[u][k] = pk_fma(dd[q][k], st, S0[u][k]);
