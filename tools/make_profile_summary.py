@@ -54,7 +54,17 @@ def main():
         with open(os.path.join(DST, f"{R}_{tag}_kernel_stats_{name}.csv"), "w") as f:
             f.write(f"# rocprofv3 --kernel-trace --stats -- {cmd}   (table from the rocpd file by tools/rocpd_stats.py)\n")
             f.write(open(os.path.join(SRC, f"{src}_kernel_stats.csv")).read())
-    # ---- step kernel: traffic + SQ counters
+    # ---- step kernel: traffic + SQ counters (skipped when this collection did not run the bench PMC passes)
+    rec = {"derived": {}}
+    if os.path.exists(os.path.join(SRC, "bench_pmc_sq.txt")):
+        rec = step_kernel_summary(tag, rnd, R)
+    if not os.path.exists(os.path.join(SRC, "pcn_pmc_sq.txt")):
+        print(json.dumps(rec["derived"], indent=1))
+        return
+    rnvp_summary(tag, rnd, R, rec)
+
+
+def step_kernel_summary(tag, rnd, R):
     fs, ws, sq = (pmc(os.path.join(SRC, f"bench_pmc_{c}.txt")) for c in ("FETCH_SIZE", "WRITE_SIZE", "sq"))
     k = "icnn_step_kernel<130, 2, true"
     f_kb, w_kb = find(fs, k)["FETCH_SIZE"][1], find(ws, k)["WRITE_SIZE"][1]
@@ -89,9 +99,10 @@ def main():
         },
     }
     json.dump(rec, open(os.path.join(DST, f"{R}_{tag}_pmc_step_kernel.json"), "w"), indent=1)
-    if not os.path.exists(os.path.join(SRC, "pcn_pmc_sq.txt")):
-        print(json.dumps(rec["derived"], indent=1))
-        return
+    return rec
+
+
+def rnvp_summary(tag, rnd, R, rec):
     # ---- RealNVP kernels at configs[3]
     fs, ws, sq = (pmc(os.path.join(SRC, f"pcn_pmc_{c}.txt")) for c in ("FETCH_SIZE", "WRITE_SIZE", "sq"))
     st = stats(os.path.join(SRC, "pcn_kernel_stats.csv"))
@@ -121,8 +132,9 @@ def main():
             "lds_instructions_per_wave_of_64_points_and_flow": round(s["SQ_INSTS_LDS"] * 32 / (N / 64.0) / F, 1),
             "waves_per_simd_resident_mean": round(4 * s["SQ_WAVE_CYCLES"] / 32 / s["SQ_BUSY_CYCLES"], 2),
             "bound": ("VALU issue (a wave64 VALU instruction occupies its SIMD for 4 cycles); neither the flop nor the HBM roof is near" if rnd < 3 else
-                      "latency: neither VALU issue, nor LDS return bandwidth, nor HBM (profiles/NOTES.md, round 3: fewer VALU instructions, the "
-                      "scalar data path and Q points per lane were each measured)"),
+                      "VALU issue at 3-4 waves per SIMD (0.6-0.7 busy) next to LDS / memory latency; neither the flop nor the HBM roof is near "
+                      "(profiles/NOTES.md, round 3: the scalar data path and Q points per lane were slower; fewer VALU instructions per unit - "
+                      "relu / step through the clamp modifier - made the backward kernels faster)"),
         }
     json.dump(out, open(os.path.join(DST, f"{R}_{tag}_pmc_rnvp_kernels.json"), "w"), indent=1)
     print(json.dumps(rec["derived"], indent=1))
