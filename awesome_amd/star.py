@@ -71,6 +71,8 @@ def _workspace(spec: StarSpec, n_points: int, dev) -> Tensor:
 
 
 def _check(params: Tensor, spec: StarSpec, coords: Tensor):
+    if not params.is_contiguous():
+        raise ValueError("params must be one contiguous flat vector (it is updated in place)")
     params = K._check_dev(params, "params")
     coords = K._check_dev(coords, "coords")
     if params.numel() != spec.n_params:
