@@ -26,6 +26,10 @@
 #pragma once
 #include "flow.h"
 
+#ifndef RNVP_FWD_CLAMP
+#define RNVP_FWD_CLAMP 1   // the forward kernels use the clamped asm form too (0: fma + 2 x v_max; see rnvp_nets)
+#endif
+
 namespace {
 
 constexpr int RNVP_MAX_FLOWS = 32;
@@ -220,8 +224,8 @@ __device__ __forceinline__ void rnvp_nets(const Rec rec, int HID, const float (&
                 f32x2 pre = f32x2{v[2 * NIN], v[2 * NIN + 1]};
 #pragma unroll
                 for (int mm = 0; mm + 1 < NIN; ++mm) pre = pk_fma(f32x2{v[2 * mm], v[2 * mm + 1]}, splat2(zin[q][mm]), pre);
-                f32x2 h;   // relu(pre) 2^-32 (see the U = 1 body below for why the forward keeps v_max)
-                if constexpr (DU) {
+                f32x2 h;   // relu(pre) 2^-32
+                if constexpr (DU || RNVP_FWD_CLAMP) {
                     h = pk_fma_clamp_bcast(f32x2{v[2 * (NIN - 1)], v[2 * (NIN - 1) + 1]}, zin[q][NIN - 1], pre);
                 } else {
                     pre = pk_fma(f32x2{v[2 * (NIN - 1)], v[2 * (NIN - 1) + 1]}, splat2(zin[q][NIN - 1]), pre);
@@ -246,8 +250,18 @@ __device__ __forceinline__ void rnvp_nets(const Rec rec, int HID, const float (&
             }
         };
         const int steps = HID / U;
-#pragma unroll 4
-        for (int t = 0; t < steps; ++t) unit(rec.v4(RNVP_REC * (t * U + sl)), rec.v4(RNVP_REC * (t * U + sl) + 4));
+        int t = 0;
+        for (; t + 4 <= steps; t += 4) {   // batches of 4 units written out: hipcc does not unroll a loop around an asm statement
+            f32x4 r[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                r[2 * k] = rec.v4(RNVP_REC * ((t + k) * U + sl));
+                r[2 * k + 1] = rec.v4(RNVP_REC * ((t + k) * U + sl) + 4);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) unit(r[2 * k], r[2 * k + 1]);
+        }
+        for (; t < steps; ++t) unit(rec.v4(RNVP_REC * (t * U + sl)), rec.v4(RNVP_REC * (t * U + sl) + 4));
         if (steps * U + sl < HID) unit(rec.v4(RNVP_REC * (steps * U + sl)), rec.v4(RNVP_REC * (steps * U + sl) + 4));
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
@@ -288,12 +302,12 @@ __device__ __forceinline__ void rnvp_nets(const Rec rec, int HID, const float (&
                 f32x2 pre = f32x2{v[2 * NIN], v[2 * NIN + 1]};
 #pragma unroll
                 for (int mm = 0; mm + 1 < NIN; ++mm) pre = pk_fma(f32x2{v[2 * mm], v[2 * mm + 1]}, splat2(zin[q][mm]), pre);
-                if constexpr (DU) {
+                if constexpr (DU || RNVP_FWD_CLAMP) {
                     h = pk_fma_clamp_bcast(f32x2{v[2 * (NIN - 1)], v[2 * (NIN - 1) + 1]}, zin[q][NIN - 1], pre);
                 } else {
-                    // The forward keeps fma + 2 x v_max on the (scaled) records: with the clamped asm form its kernels were SLOWER (256x256,
-                    // C = 2: 16.95 vs 14.7 us; configs[3]: 55.8 vs 53.9) - hipcc orders and narrows the record reads of the plain loop
-                    // better than around the asm statements; the backward kernels gain (26.3 -> 24.4, 104.4 -> 98.6 us).
+                    // (RNVP_FWD_CLAMP = 0) fma + 2 x v_max on the scaled records.  The clamped asm form was first measured SLOWER in the
+                    // forward kernels (16.95 vs 14.7 us at 256x256, 55.8 vs 53.9 at configs[3]): hipcc does not unroll a loop around an asm
+                    // statement, so every unit paid its own LDS round trip; with the batches of 4 written out it is faster (13.8 / 52.0 us).
                     pre = pk_fma(f32x2{v[2 * (NIN - 1)], v[2 * (NIN - 1) + 1]}, splat2(zin[q][NIN - 1]), pre);
                     h = f32x2{fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f)};
                 }
@@ -343,6 +357,12 @@ __device__ __forceinline__ void rnvp_nets(const Rec rec, int HID, const float (&
                 __builtin_amdgcn_sched_barrier(0);
                 eval4(rb);
             }
+        }
+    } else if constexpr (RNVP_FWD_CLAMP && !DU) {   // batches of 4 written out: hipcc does not unroll a loop around an asm statement
+        for (; j + 4 <= HID; j += 4) {
+            f32x4 r[8];
+            load4(r, j);
+            eval4(r);
         }
     } else {   // hipcc's own order (it also narrows the record reads to what is used): the forward kernels are faster with it
 #pragma unroll 4
