@@ -358,7 +358,8 @@ __device__ __forceinline__ void rnvp_nets(const Rec rec, int HID, const float (&
                 eval4(rb);
             }
         }
-    } else if constexpr (RNVP_FWD_CLAMP && !DU) {   // batches of 4 written out: hipcc does not unroll a loop around an asm statement
+    } else if constexpr (DU || RNVP_FWD_CLAMP) {   // batches of 4 written out: hipcc does not unroll a loop around an asm statement
+                                                 // (step01 / the clamped fma); one register set (the C = 3 kernels run 4 waves per SIMD)
         for (; j + 4 <= HID; j += 4) {
             f32x4 r[8];
             load4(r, j);
