@@ -1665,15 +1665,20 @@ void launch_rnvp_bwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, i
     ua.m = w.rm;
     ua.chunks = w.chunks;
     // hidden units in blocks of 32 (8 per wave) - or 64 (16 per wave) when that needs no second block
+    // (16 units per wave at HID = 32 - two waves per block, the per-point loads amortised over twice the units - was measured slower:
+    // 114 vs 62.7 us at configs[3] (267 registers: one wave per SIMD), 14.4 vs 12.5 us at 256x256)
     const int upw = (w.rm.HID > 32 && w.rm.HID <= 64) ? 16 : 8;
     const dim3 g2(w.chunks, w.rm.F * ((w.rm.HID + 4 * upw - 1) / (4 * upw)), n_images);
     const size_t lds2 = (size_t)(RNVP_HDR + w.rm.fl) * sizeof(float);
+    // waves that own units: a block of 4 waves covers 4 upw units; with fewer units than that the idle waves are not launched
+    const int waves = (w.rm.HID + upw - 1) / upw < 4 ? (w.rm.HID + upw - 1) / upw : 4;
+    const dim3 b2(64 * waves);
     if (w.rm.C == 2) {
-        if (upw == 8) hipLaunchKernelGGL((rnvp_bwd_units_kernel<2, 8>), g2, dim3(256), lds2, s, ua);
-        else hipLaunchKernelGGL((rnvp_bwd_units_kernel<2, 16>), g2, dim3(256), lds2, s, ua);
+        if (upw == 8) hipLaunchKernelGGL((rnvp_bwd_units_kernel<2, 8>), g2, b2, lds2, s, ua);
+        else hipLaunchKernelGGL((rnvp_bwd_units_kernel<2, 16>), g2, b2, lds2, s, ua);
     } else {
-        if (upw == 8) hipLaunchKernelGGL((rnvp_bwd_units_kernel<3, 8>), g2, dim3(256), lds2, s, ua);
-        else hipLaunchKernelGGL((rnvp_bwd_units_kernel<3, 16>), g2, dim3(256), lds2, s, ua);
+        if (upw == 8) hipLaunchKernelGGL((rnvp_bwd_units_kernel<3, 8>), g2, b2, lds2, s, ua);
+        else hipLaunchKernelGGL((rnvp_bwd_units_kernel<3, 16>), g2, b2, lds2, s, ua);
     }
 }
 
