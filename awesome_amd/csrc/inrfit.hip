@@ -1524,6 +1524,18 @@ PcnWs carve_pcn(const KernelEntry* e, const InrRnvpDesc* r, const InrGridDesc* g
         if ((ub != 1 && ub != 2 && ub != 4) || C != 2) ub = 1;
         w.sf = FlowShape{1, uf, 256, (int)((N * uf + 255) / 256)};
         w.sb = FlowShape{1, ub, 256, (int)((N * ub + 255) / 256)};
+        // Large launches (several waves per SIMD anyway): Q = 2 points per lane - every record read serves two points, half the
+        // LDS instructions and half the partial-sum blocks.  configs[3] (262 144 points, C = 3): forward Q = 1 51.7 | 2 44.2 | 4 48.5 us
+        // (bit-identical), backward over points 89.8 | 82.0 us, the update behind it 24.7 -> 21.3 us.  (Round 2 had measured Q > 1
+        // slower - on unit loops that hipcc had not unrolled, profiles/NOTES.md.)  C = 3 by default; INR_RNVP_QF / _QB force it.
+        const char* qf = getenv("INR_RNVP_QF");
+        const char* qb = getenv("INR_RNVP_QB");
+        const bool large = N * n_images >= 196608;
+        int QF = qf ? atoi(qf) : (C == 3 ? 2 : 1), QB = qb ? atoi(qb) : (C == 3 ? 2 : 1);
+        if (!large || (QF != 1 && QF != 2 && QF != 4)) QF = 1;
+        if (!large || (QB != 1 && QB != 2)) QB = 1;
+        if (QF > 1) w.sf = FlowShape{QF, 1, 256, (int)((N + 256 * QF - 1) / (256 * QF))};
+        if (QB > 1) w.sb = FlowShape{QB, 1, 256, (int)((N + 256 * QB - 1) / (256 * QB))};
     }
     w.blocks1 = w.sb.blocks;
     w.chunks = 64;   // x F flows x 4 waves: enough waves for the 1024 SIMDs
@@ -1561,6 +1573,12 @@ int rnvp_set_lds() {
     bool ok = true;
     ok &= hipFuncSetAttribute((const void*)rnvp_fwd_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
     ok &= hipFuncSetAttribute((const void*)rnvp_fwd_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)rnvp_fwd_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)rnvp_fwd_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)rnvp_fwd_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)rnvp_fwd_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)rnvp_bwd_points_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)rnvp_bwd_points_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
     ok &= hipFuncSetAttribute((const void*)rnvp_bwd_points_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
     ok &= hipFuncSetAttribute((const void*)rnvp_bwd_points_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
     ok &= hipFuncSetAttribute((const void*)rnvp_fwd_kernel<2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
@@ -1628,11 +1646,15 @@ void launch_rnvp_fwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, i
     const dim3 g(w.sf.blocks, n_images), b(w.sf.threads);
     const size_t lds = (size_t)(w.rm.LDSF + 64) * sizeof(float);   // + slack: the pipelined unit loop reads one batch ahead
     if (w.rm.C == 2) {
-        if (w.sf.U == 2) hipLaunchKernelGGL((rnvp_fwd_kernel<2, 1, 2>), g, b, lds, s, a);
+        if (w.sf.Q == 2) hipLaunchKernelGGL((rnvp_fwd_kernel<2, 2>), g, b, lds, s, a);
+        else if (w.sf.Q == 4) hipLaunchKernelGGL((rnvp_fwd_kernel<2, 4>), g, b, lds, s, a);
+        else if (w.sf.U == 2) hipLaunchKernelGGL((rnvp_fwd_kernel<2, 1, 2>), g, b, lds, s, a);
         else if (w.sf.U == 4) hipLaunchKernelGGL((rnvp_fwd_kernel<2, 1, 4>), g, b, lds, s, a);
         else hipLaunchKernelGGL((rnvp_fwd_kernel<2, 1>), g, b, lds, s, a);   // (Q > 1: measured slower, flow.h)
     } else {
-        hipLaunchKernelGGL((rnvp_fwd_kernel<3, 1>), g, b, lds, s, a);
+        if (w.sf.Q == 2) hipLaunchKernelGGL((rnvp_fwd_kernel<3, 2>), g, b, lds, s, a);
+        else if (w.sf.Q == 4) hipLaunchKernelGGL((rnvp_fwd_kernel<3, 4>), g, b, lds, s, a);
+        else hipLaunchKernelGGL((rnvp_fwd_kernel<3, 1>), g, b, lds, s, a);
     }
 }
 
@@ -1650,11 +1672,13 @@ void launch_rnvp_bwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, i
     const dim3 g1(w.sb.blocks, n_images), b1(w.sb.threads);
     const size_t lds = (size_t)(w.rm.LDSF + 4 * w.S1) * sizeof(float);
     if (w.rm.C == 2) {
-        if (w.sb.U == 2) hipLaunchKernelGGL((rnvp_bwd_points_kernel<2, 1, 2>), g1, b1, lds, s, a);
+        if (w.sb.Q == 2) hipLaunchKernelGGL((rnvp_bwd_points_kernel<2, 2>), g1, b1, lds, s, a);
+        else if (w.sb.U == 2) hipLaunchKernelGGL((rnvp_bwd_points_kernel<2, 1, 2>), g1, b1, lds, s, a);
         else if (w.sb.U == 4) hipLaunchKernelGGL((rnvp_bwd_points_kernel<2, 1, 4>), g1, b1, lds, s, a);
         else hipLaunchKernelGGL((rnvp_bwd_points_kernel<2, 1>), g1, b1, lds, s, a);
     } else {
-        hipLaunchKernelGGL((rnvp_bwd_points_kernel<3, 1>), g1, b1, lds, s, a);
+        if (w.sb.Q == 2) hipLaunchKernelGGL((rnvp_bwd_points_kernel<3, 2>), g1, b1, lds, s, a);
+        else hipLaunchKernelGGL((rnvp_bwd_points_kernel<3, 1>), g1, b1, lds, s, a);
     }
     RnvpUnitsArgs ua{};
     ua.RP = rp;

@@ -286,9 +286,27 @@ def test_fit_images_path_connected_shape(dev):
     assert iou_pc > iou_cvx + 0.1, (iou_pc, iou_cvx)
 
 
+@pytest.mark.parametrize("q", [None, "1", "2", "4"])
 @pytest.mark.parametrize("C", [2, 3])
-def test_large_grid_two_points_per_lane(dev, C):
-    """>= 262144 points switch the point kernels to two points per lane: same results (ragged tail included)."""
+def test_large_grid_two_points_per_lane(dev, C, q):
+    """Launches of >= 196608 points run the RealNVP point kernels with Q points per lane (default: 2 at C = 3, 1 at C = 2;
+    INR_RNVP_QF / INR_RNVP_QB force 1 / 2 / 4 - the backward has 1 and 2): same results against the oracle (ragged tail included)."""
+    import os
+    from awesome_amd import rnvp as R
+    import awesome_amd as A
+    for k in ("INR_RNVP_QF", "INR_RNVP_QB"):
+        os.environ.pop(k, None)
+    if q is not None:
+        os.environ["INR_RNVP_QF"] = q
+        os.environ["INR_RNVP_QB"] = "2" if q == "4" else q
+    try:
+        _large_grid_case(dev, C)
+    finally:
+        for k in ("INR_RNVP_QF", "INR_RNVP_QB"):
+            os.environ.pop(k, None)
+
+
+def _large_grid_case(dev, C):
     from awesome_amd import rnvp as R
     import awesome_amd as A
     F = 4 if C == 2 else 6
