@@ -771,22 +771,40 @@ __device__ __forceinline__ void rnvp_units_body(const RnvpUnitsArgs& a, const Fl
 #pragma unroll
             for (int mm = 0; mm < NIN; ++mm) S1[u][k][mm] = f32x2{0.f, 0.f};
         }
-    for (int p = p0; p < p1; p += 64 * PPL) {
-        float zin[PPL][NIN];
-        f32x2 dd[PPL][NOUT], dz[PPL][NOUT][NIN];
+    // The (zin, do) values of the NEXT trip are requested before the current trip's units are evaluated: a trip (256 points x UPW units)
+    // is ~700 clocks of arithmetic, and loaded where they are used its four vector loads per array were an uncovered trip to memory each
+    // time (2.2 waves per SIMD resident).
+    float zin_n[PPL][NIN], ds_n[PPL][NOUT], dt_n[PPL][NOUT];
+    auto load_trip = [&](int p) {
 #pragma unroll
         for (int q = 0; q < PPL; ++q) {
             const int idx = p + q * 64 + lane;
             const bool in = idx < p1;   // do = 0 past the end: those points contribute nothing
 #pragma unroll
-            for (int mm = 0; mm < NIN; ++mm) zin[q][mm] = in ? zbase[(size_t)x.in(mm) * N + idx] : 0.f;
+            for (int mm = 0; mm < NIN; ++mm) zin_n[q][mm] = in ? zbase[(size_t)x.in(mm) * N + idx] : 0.f;
 #pragma unroll
             for (int k = 0; k < NOUT; ++k) {
-                dd[q][k] = in ? f32x2{base[(size_t)k * N + idx], base[(size_t)(NOUT + k) * N + idx]} : f32x2{0.f, 0.f};
+                ds_n[q][k] = in ? base[(size_t)k * N + idx] : 0.f;
+                dt_n[q][k] = in ? base[(size_t)(NOUT + k) * N + idx] : 0.f;
+            }
+        }
+    };
+    load_trip(p0);
+    for (int p = p0; p < p1; p += 64 * PPL) {
+        float zin[PPL][NIN];
+        f32x2 dd[PPL][NOUT], dz[PPL][NOUT][NIN];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+#pragma unroll
+            for (int mm = 0; mm < NIN; ++mm) zin[q][mm] = zin_n[q][mm];
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) {
+                dd[q][k] = f32x2{ds_n[q][k], dt_n[q][k]};
 #pragma unroll
                 for (int mm = 0; mm < NIN; ++mm) dz[q][k][mm] = dd[q][k] * f32x2{zin[q][mm], zin[q][mm]};
             }
         }
+        if (p + 64 * PPL < p1) load_trip(p + 64 * PPL);
 #pragma unroll
         for (int u = 0; u < UPW; ++u) {
             const int j = (ub * 4 + wave) * UPW + u;
