@@ -1527,11 +1527,12 @@ PcnWs carve_pcn(const KernelEntry* e, const InrRnvpDesc* r, const InrGridDesc* g
         // Large launches (several waves per SIMD anyway): Q = 2 points per lane - every record read serves two points, half the
         // LDS instructions and half the partial-sum blocks.  configs[3] (262 144 points, C = 3): forward Q = 1 51.7 | 2 44.2 | 4 48.5 us
         // (bit-identical), backward over points 89.8 | 82.0 us, the update behind it 24.7 -> 21.3 us.  (Round 2 had measured Q > 1
-        // slower - on unit loops that hipcc had not unrolled, profiles/NOTES.md.)  C = 3 by default; INR_RNVP_QF / _QB force it.
+        // slower - on unit loops that hipcc had not unrolled, profiles/NOTES.md.)  C = 2, 16 images of 256x256 per launch: 2501 -> 2444 us
+        // per step.  INR_RNVP_QF / _QB force a shape.
         const char* qf = getenv("INR_RNVP_QF");
         const char* qb = getenv("INR_RNVP_QB");
         const bool large = N * n_images >= 196608;
-        int QF = qf ? atoi(qf) : (C == 3 ? 2 : 1), QB = qb ? atoi(qb) : (C == 3 ? 2 : 1);
+        int QF = qf ? atoi(qf) : 2, QB = qb ? atoi(qb) : 2;
         if (!large || (QF != 1 && QF != 2 && QF != 4)) QF = 1;
         if (!large || (QB != 1 && QB != 2)) QB = 1;
         if (QF > 1) w.sf = FlowShape{QF, 1, 256, (int)((N + 256 * QF - 1) / (256 * QF))};

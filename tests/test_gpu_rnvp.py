@@ -289,7 +289,7 @@ def test_fit_images_path_connected_shape(dev):
 @pytest.mark.parametrize("q", [None, "1", "2", "4"])
 @pytest.mark.parametrize("C", [2, 3])
 def test_large_grid_two_points_per_lane(dev, C, q):
-    """Launches of >= 196608 points run the RealNVP point kernels with Q points per lane (default: 2 at C = 3, 1 at C = 2;
+    """Launches of >= 196608 points run the RealNVP point kernels with Q points per lane (default: 2;
     INR_RNVP_QF / INR_RNVP_QB force 1 / 2 / 4 - the backward has 1 and 2): same results against the oracle (ragged tail included)."""
     import os
     from awesome_amd import rnvp as R
