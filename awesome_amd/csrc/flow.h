@@ -188,12 +188,16 @@ inline FlowShape flow_launch_shape(long long n_points, int n_images, bool backwa
     FlowShape s;
     const char* fe = getenv("INR_FLOW_SHAPE");   // measurement / test switch: 10 U + Q for both kernels (read per call)
     const int force = fe ? atoi(fe) : 0;
-    const bool small = n_points * n_images <= 98304;
+    const long long total = n_points * n_images;
+    const bool small = total <= 98304, large = total >= 196608;
+    // small: lanes per point (above).  large (batches of images: several waves per SIMD anyway): two points per lane, every record
+    // read serves both - 16 images of 256x256 per launch: (1,1) 2692 | (1,2) 2547 | (2,1) 2700 | (4,2) 2628 us per optimizer step.
     s.U = force ? force / 10 : (small ? (backward ? 2 : 4) : 1);
-    s.Q = force ? force % 10 : (small ? (backward ? 1 : 2) : 1);
+    s.Q = force ? force % 10 : (small ? (backward ? 1 : 2) : (large ? 2 : 1));
     const bool fwd_only = (s.U == 2 && s.Q == 2) || (s.U == 4 && s.Q == 4);   // forward instantiations without a backward twin
     if (backward && fwd_only) s.Q = 1;
-    if (!((s.U == 1 && s.Q == 1) || (s.U == 4 && s.Q == 2) || (s.U == 4 && s.Q == 1) || (s.U == 2 && s.Q == 1) || (!backward && fwd_only)))
+    if (!((s.U == 1 && (s.Q == 1 || s.Q == 2)) || (s.U == 4 && s.Q == 2) || (s.U == 4 && s.Q == 1) || (s.U == 2 && s.Q == 1) ||
+          (!backward && fwd_only)))
         s.U = s.Q = 1;
     s.threads = 256;
     s.blocks = (int)((n_points * s.U + 256 * s.Q - 1) / (256 * s.Q));

@@ -1223,7 +1223,8 @@ void launch_flow_fwd(const CdnWs& w, const InrGridDesc* grid, int n_images, floa
     a.m = w.fm;
     const dim3 g(w.sf.blocks, n_images), b(w.sf.threads);
     const size_t lds = (w.fm.FE + 64) * sizeof(float);   // + slack: the pipelined unit loop reads one batch ahead
-    if (w.sf.U == 4 && w.sf.Q == 2) hipLaunchKernelGGL((flow_fwd_kernel<2, 4>), g, b, lds, s, a);
+    if (w.sf.U == 1 && w.sf.Q == 2) hipLaunchKernelGGL((flow_fwd_kernel<2, 1>), g, b, lds, s, a);
+    else if (w.sf.U == 4 && w.sf.Q == 2) hipLaunchKernelGGL((flow_fwd_kernel<2, 4>), g, b, lds, s, a);
     else if (w.sf.U == 4 && w.sf.Q == 4) hipLaunchKernelGGL((flow_fwd_kernel<4, 4>), g, b, lds, s, a);
     else if (w.sf.U == 2 && w.sf.Q == 2) hipLaunchKernelGGL((flow_fwd_kernel<2, 2>), g, b, lds, s, a);
     else if (w.sf.U == 4) hipLaunchKernelGGL((flow_fwd_kernel<1, 4>), g, b, lds, s, a);
@@ -1236,7 +1237,8 @@ void launch_flow_bwd_points(const CdnWs& w, int K, int n_images, const FlowBwdAr
     const size_t lds = (w.fm.FE + 64) * sizeof(float);
 #define INR_FLOW_BWD(KK)                                                                                 \
     do {                                                                                                 \
-        if (w.sb.U == 4 && w.sb.Q == 2) hipLaunchKernelGGL((flow_bwd_points_kernel<KK, 2, 4>), g1, b1, lds, s, a); \
+        if (w.sb.U == 1 && w.sb.Q == 2) hipLaunchKernelGGL((flow_bwd_points_kernel<KK, 2, 1>), g1, b1, lds, s, a); \
+        else if (w.sb.U == 4 && w.sb.Q == 2) hipLaunchKernelGGL((flow_bwd_points_kernel<KK, 2, 4>), g1, b1, lds, s, a); \
         else if (w.sb.U == 4) hipLaunchKernelGGL((flow_bwd_points_kernel<KK, 1, 4>), g1, b1, lds, s, a);     \
         else if (w.sb.U == 2) hipLaunchKernelGGL((flow_bwd_points_kernel<KK, 1, 2>), g1, b1, lds, s, a);     \
         else hipLaunchKernelGGL((flow_bwd_points_kernel<KK, 1, 1>), g1, b1, lds, s, a);                     \

@@ -114,7 +114,7 @@ def flow_shape(request):
         os.environ["INR_FLOW_SHAPE"] = old
 
 
-@pytest.mark.parametrize("flow_shape", [None, "11", "21", "41", "42"], indirect=True)
+@pytest.mark.parametrize("flow_shape", [None, "11", "12", "21", "41", "42"], indirect=True)
 @pytest.mark.parametrize("layers,width,K", [(1, 130, 6), (2, 24, 4), (1, 70, 2), (1, 200, 8), (2, 256, 2)])
 def test_hip_flow_forward_and_cdn_gradients(dev, layers, width, K, flow_shape):
     import awesome_amd as A
@@ -191,3 +191,37 @@ def test_hip_cdn_fit_end_to_end_vs_reference_modules(dev, golden_dir):
     assert abs(h[-1] - float(z["losses"][-1])) <= 0.05 * float(z["losses"][-1])
     agree = ((res.logits[0].cpu() > 0) == (torch.from_numpy(z["final_logits"]).reshape(-1) > 0)).float().mean()
     assert float(agree) > 0.95
+
+
+def test_large_launch_two_points_per_lane_equals_single_image_calls(dev):
+    """A batch of 4 images of 256x256 (262144 points: the point kernels run two points per lane) against the same images one at a
+    time at one lane per point, one point per lane: deformed coordinates bit for bit (the per-point arithmetic is the same), loss and
+    gradients up to the order of the partial sums."""
+    import os
+    import awesome_amd as A
+    from awesome_amd import flow as FL
+    from awesome_amd.dataset import convex_blob_unaries
+    m, sd = _cdn_case(2, 130, 6)
+    ispec, fspec = A.IcnnSpec(130, 2, 2), FL.FlowSpec(130, 6)
+    ip, fp = FL.split_cdn_state_dict(ispec, fspec, sd, dev)
+    n = 4
+    torch.manual_seed(3)
+    ipb = (ip[None].repeat(n, 1) * (1 + 0.01 * torch.randn(n, ip.numel(), device=dev))).contiguous()
+    fpb = (fp[None].repeat(n, 1) * (1 + 0.01 * torch.randn(n, fp.numel(), device=dev))).contiguous()
+    un = torch.stack([convex_blob_unaries(256, s).reshape(-1) for s in range(n)]).to(dev)
+    grid = A.Grid.linspace(256, 256, dev)
+    os.environ.pop("INR_FLOW_SHAPE", None)
+    xd_b = FL.flow_forward(fspec, fpb, grid)
+    loss_b, gi_b, gf_b = FL.cdn_loss_grad(ispec, fspec, ipb, fpb, grid, un, loss="bce")
+    os.environ["INR_FLOW_SHAPE"] = "11"
+    try:
+        for k in range(n):
+            xd = FL.flow_forward(fspec, fpb[k:k + 1].contiguous(), grid)
+            assert torch.equal(xd[0], xd_b[k])
+            loss, gi, gf = FL.cdn_loss_grad(ispec, fspec, ipb[k:k + 1].contiguous(), fpb[k:k + 1].contiguous(), grid, un[k:k + 1], loss="bce")
+            assert float(loss[0]) == pytest.approx(float(loss_b[k]), rel=1e-6)
+            for got, ref in ((gi_b[k], gi[0]), (gf_b[k], gf[0])):
+                scale = float(ref.abs().max())
+                np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-6 * scale + 1e-9)
+    finally:
+        os.environ.pop("INR_FLOW_SHAPE", None)
