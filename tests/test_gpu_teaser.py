@@ -330,3 +330,35 @@ def test_star_fused_fit_of_the_notebook_loop_is_star_shaped(dev):
         outside = (out >= 0).int()
         reenter = ((outside[:, 1:] - outside[:, :-1]).min(1).values < 0).float().mean()
         assert float(reenter) <= 0.05, f"{float(reenter):.3f} of the rays re-enter the region: not star-shaped"
+
+
+@pytest.mark.parametrize("h,n,batch", [(1, 1, 1), (7, 5, 3), (64, 19, 19), (257, 9, 4)])
+def test_star_fused_edge_sizes(dev, h, n, batch):
+    """Tiny and odd sizes (one hidden unit, one pixel, batches that fill no block, a width past 256): forward, loss and gradients
+    against the oracle's restatement of the notebook class, and a 3-epoch fit that stays finite."""
+    from awesome_amd import star as S
+    from awesome_amd.model import StarShapedNet
+    from oracle import inr_oracle as O
+    torch.manual_seed(100 + h)
+    m = StarShapedNet(h)
+    with torch.no_grad():
+        m.offset.copy_(torch.tensor([[0.03, -0.02]]))
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    x = (torch.rand(n, 2) - 0.5)
+    labels = (torch.rand(n) > 0.5).float()
+    idx = torch.randint(0, n, (batch,), dtype=torch.int32)
+    spec = S.StarSpec(h)
+    flat = S.flatten_state_dict(spec, {k: v.detach() for k, v in sd.items()}, dev)
+    y = S.star_forward(spec, flat, x.to(dev))
+    yo = O.star_shaped_forward(sd, x)
+    np.testing.assert_allclose(y.cpu().numpy(), yo.detach().numpy()[:, 0], rtol=2e-5, atol=2e-5)
+    lo = ((torch.sigmoid(O.star_shaped_forward(sd, x[idx.long()])).reshape(-1) - labels[idx.long()]) ** 2).mean()
+    lo.backward()
+    loss, grads = S.star_loss_grad(spec, flat, x.to(dev), labels.to(dev), idx.to(dev))
+    assert float(loss) == pytest.approx(float(lo.detach()), rel=2e-5, abs=1e-7)
+    g = S.unflatten(spec, grads)
+    for k in S.PARAM_ORDER:
+        ref = sd[k].grad.numpy()
+        np.testing.assert_allclose(g[k].cpu().numpy(), ref, rtol=5e-4, atol=5e-4 * float(np.abs(ref).max()) + 1e-8, err_msg=k)
+    res = S.star_fit(spec, flat, x.to(dev), labels.to(dev), idx[None].repeat(3, 1).to(dev), offset_first_step=1)
+    assert bool(torch.isfinite(res.params).all()) and bool(torch.isfinite(res.loss_hist).all())
