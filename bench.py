@@ -548,6 +548,27 @@ def path_variants(dev, S, steps=300, cpu_legs=True):
     us, h = timed(lambda n: pc3.fit_images(g3, u3, num_epochs=n))
     out["PathConnectedNet_RealNVP_C3_F18_L2_128x128x16"] = entry(us, 128 * 128 * 16, icnn_fwd_flop(130, 3, 2), 18 * 32 * 2 * 3 * 2, h,
                                                                  pcn_oracle(pc3, ds.coords().t().contiguous(), u3.cpu().reshape(-1, 1), 3, 18), 3)
+    # The same two 256x256 priors with a BATCH of images per launch (configs[2]'s shape of work for the path-connected priors: all
+    # images step together; the launches then hold several waves per SIMD and the per-launch costs are shared).
+    nb = 16
+    unb = torch.stack([convex_blob_unaries(S, s).reshape(-1) for s in range(nb)]).to(dev)
+
+    def batched(fn, fwd_flow):
+        fn(5)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = fn(100)
+        torch.cuda.synchronize()
+        us_img = (time.perf_counter() - t0) / 100 / nb * 1e6
+        flop = 3.0 * (icnn_fwd_flop(130, 2, 2) + fwd_flow) * N
+        hh = res.loss_hist.float().cpu()
+        return {"images_per_launch": nb, "us_per_step_per_image": round(us_img, 1),
+                "roofline_frac_wall_clock": round(flop / (us_img * 1e-6) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
+                "check": {"ok": bool(torch.isfinite(hh).all() and (hh[:, -1] < hh[:, 0]).all())}}
+    out["batched_16_images"] = {
+        f"ConvexDiffeomorphismNet_K6_w130_L2_{S}x{S}": batched(lambda n: cdn.fit_images(grid, unb, num_epochs=n), 6 * 8 * 130),
+        f"PathConnectedNet_RealNVP_C2_F12_L2_{S}x{S}": batched(lambda n: pc2.fit_images(grid, unb, num_epochs=n), 12 * 32 * 2 * 2 * 2),
+    }
     out["joint_step_configs4"] = joint_step_variant(dev, S, icnn_fwd_flop)
     return out
 
