@@ -9,6 +9,7 @@ ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "inrfit.hip")
 OUT = os.path.join(HERE, "csrc", "libinrfit.so")
 INCLUDE = os.path.join(ROOT, "include")
+MAP = os.path.join(HERE, "csrc", "inrfit.map")
 
 
 def hipcc_path() -> str:
@@ -21,7 +22,7 @@ def hipcc_path() -> str:
 def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
-    deps = [SRC, os.path.join(INCLUDE, "inrfit.h")] + [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".h")]
+    deps = [SRC, MAP, os.path.join(INCLUDE, "inrfit.h")] + [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".h")]
     return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
 
 
@@ -37,7 +38,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     # -amdgpu-mfma-vgpr-form: MFMA results in VGPRs where the allocation allows, instead of AGPRs read back with v_accvgpr_read.
     # Together 14 % fewer VALU instructions in the step kernels' chunk loop (every one of them costs MFMA issue slots),
     # no spills left in the L = 2 kernels: step kernel -1 %.
-    base = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", f"-I{INCLUDE}"]
+    base = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fvisibility=hidden", "-shared", "-fPIC", f"-Wl,--version-script={MAP}",
+            f"-I{INCLUDE}"]
     tuning = ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
     def command(flags):

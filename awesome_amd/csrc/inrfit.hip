@@ -1128,12 +1128,12 @@ struct CdnWs {
 
 long long align256(long long b) { return (b + 255) / 256 * 256; }
 
-bool flow_ok(const InrFlowDesc* f) {
+static bool flow_ok(const InrFlowDesc* f) {
     return f && f->width >= 1 && f->width <= 256 && (f->backbone == INR_FLOW_NORMAL_BLOCK || f->backbone == INR_FLOW_SIMPLE) &&
            (f->num_coupling == 2 || f->num_coupling == 4 || f->num_coupling == 6 || f->num_coupling == 8);
 }
 
-CdnWs carve_cdn(const KernelEntry* e, const InrFlowDesc* f, const InrGridDesc* grid, int n_images, void* base) {
+static CdnWs carve_cdn(const KernelEntry* e, const InrFlowDesc* f, const InrGridDesc* grid, int n_images, void* base) {
     CdnWs w;
     const long long N = grid->n_points;
     w.fm = make_flow_map(f->width, f->num_coupling, f->backbone == INR_FLOW_SIMPLE ? 0.f : LEAKY_SLOPE);
@@ -1204,7 +1204,7 @@ void launch_flow_update(const CdnWs& w, const InrFlowDesc* f, int n_images, int 
 }
 
 // the ICNN update `ui` and the flow's optimizer step in one launch (cdn_update_kernel)
-void launch_cdn_update(const KernelEntry* e, const UpdArgs& ui, FlowUpdArgs uf, const InrFlowDesc* f, int n_images, hipStream_t s) {
+static void launch_cdn_update(const KernelEntry* e, const UpdArgs& ui, FlowUpdArgs uf, const InrFlowDesc* f, int n_images, hipStream_t s) {
     const int nbf = 2 * f->num_coupling + 1;
     const dim3 gi = upd_grid(e->img.sl_cols, n_images, nbf);
     uf.status = nullptr;
@@ -1214,7 +1214,7 @@ void launch_cdn_update(const KernelEntry* e, const UpdArgs& ui, FlowUpdArgs uf, 
     hipLaunchKernelGGL(cdn_update_kernel, dim3(gi.x + nbf, n_images), upd_block(e->img.sl_cols, nbf), 0, s, ui, uf, (int)gi.x);
 }
 
-void launch_flow_fwd(const CdnWs& w, const InrGridDesc* grid, int n_images, float* out, hipStream_t s) {
+static void launch_flow_fwd(const CdnWs& w, const InrGridDesc* grid, int n_images, float* out, hipStream_t s) {
     FlowFwdArgs a{};
     a.FE = w.FE;
     a.xd = out;
@@ -1232,7 +1232,7 @@ void launch_flow_fwd(const CdnWs& w, const InrGridDesc* grid, int n_images, floa
     else hipLaunchKernelGGL((flow_fwd_kernel<1, 1>), g, b, lds, s, a);
 }
 
-void launch_flow_bwd_points(const CdnWs& w, int K, int n_images, const FlowBwdArgs& a, hipStream_t s) {
+static void launch_flow_bwd_points(const CdnWs& w, int K, int n_images, const FlowBwdArgs& a, hipStream_t s) {
     const dim3 g1(w.sb.blocks, n_images), b1(w.sb.threads);
     const size_t lds = (w.fm.FE + 64) * sizeof(float);
 #define INR_FLOW_BWD(KK)                                                                                 \
@@ -1252,7 +1252,7 @@ void launch_flow_bwd_points(const CdnWs& w, int K, int n_images, const FlowBwdAr
 #undef INR_FLOW_BWD
 }
 
-void launch_flow_bwd(const CdnWs& w, const InrFlowDesc* f, const InrGridDesc* grid, int n_images, hipStream_t s) {
+static void launch_flow_bwd(const CdnWs& w, const InrFlowDesc* f, const InrGridDesc* grid, int n_images, hipStream_t s) {
     FlowBwdArgs a{};
     a.FE = w.FE;
     a.dxd = w.dxd;
@@ -1293,7 +1293,7 @@ void launch_flow_bwd(const CdnWs& w, const InrFlowDesc* f, const InrGridDesc* gr
     }
 }
 
-int check_cdn(const InrModelDesc* model, const InrFlowDesc* flow, const InrGridDesc* grid, int n_images, void* workspace,
+static int check_cdn(const InrModelDesc* model, const InrFlowDesc* flow, const InrGridDesc* grid, int n_images, void* workspace,
               int64_t workspace_bytes, bool need_icnn, const KernelEntry** e_out, CdnWs* w_out) {
     if (!flow_ok(flow)) return INR_EUNSUPPORTED;
     const KernelEntry* e = nullptr;
@@ -1472,7 +1472,7 @@ struct PcnWs {
     InrGridDesc dgrid;
 };
 
-bool rnvp_ok(const InrRnvpDesc* r) {
+static bool rnvp_ok(const InrRnvpDesc* r) {
     if (!r || (r->channels != 2 && r->channels != 3)) return false;
     if (r->hidden_units < 1 || r->hidden_units > 256 || r->n_flows < 1 || r->n_flows > INR_RNVP_MAX_FLOWS) return false;
     if (r->output_fn != 0 && r->output_fn != 1) return false;
@@ -1485,7 +1485,7 @@ bool rnvp_ok(const InrRnvpDesc* r) {
     return (ldsf + 4 * (r->n_flows * 4 * r->channels + 2 * r->channels)) * 4 <= 160 * 1024;   // all flows' records live in LDS
 }
 
-RnvpMap make_rnvp_map(const InrRnvpDesc* r) {
+static RnvpMap make_rnvp_map(const InrRnvpDesc* r) {
     RnvpMap m{};
     m.C = r->channels;
     m.HID = r->hidden_units;
@@ -1509,7 +1509,7 @@ RnvpMap make_rnvp_map(const InrRnvpDesc* r) {
     return m;
 }
 
-PcnWs carve_pcn(const KernelEntry* e, const InrRnvpDesc* r, const InrGridDesc* grid, int n_images, void* base) {
+static PcnWs carve_pcn(const KernelEntry* e, const InrRnvpDesc* r, const InrGridDesc* grid, int n_images, void* base) {
     PcnWs w;
     const long long N = grid->n_points;
     w.rm = make_rnvp_map(r);
@@ -1569,7 +1569,7 @@ PcnWs carve_pcn(const KernelEntry* e, const InrRnvpDesc* r, const InrGridDesc* g
 }
 
 // the point kernels keep every flow's records in LDS: allow more than the default 64 KB of dynamic LDS (once per process)
-int rnvp_set_lds() {
+static int rnvp_set_lds() {
     static int rc = -1;
     if (rc >= 0) return rc;
     const int lim = 160 * 1024;
@@ -1594,7 +1594,7 @@ int rnvp_set_lds() {
     return rc;
 }
 
-int check_pcn(const InrModelDesc* model, const InrRnvpDesc* r, const InrGridDesc* grid, int n_images, void* workspace,
+static int check_pcn(const InrModelDesc* model, const InrRnvpDesc* r, const InrGridDesc* grid, int n_images, void* workspace,
               int64_t workspace_bytes, bool need_icnn, const KernelEntry** e_out, PcnWs* w_out) {
     if (!rnvp_ok(r)) return INR_EUNSUPPORTED;
     const KernelEntry* e = nullptr;
@@ -1625,7 +1625,7 @@ int check_pcn(const InrModelDesc* model, const InrRnvpDesc* r, const InrGridDesc
 }
 
 // parameters -> packed image; once per parameter set, in front of the forward
-void launch_rnvp_pack(const PcnWs& w, const float* rp, int n_images, hipStream_t s, bool unit_linear = false) {
+static void launch_rnvp_pack(const PcnWs& w, const float* rp, int n_images, hipStream_t s, bool unit_linear = false) {
     RnvpPackArgs a{};
     a.RP = rp;
     a.RE = w.RE;
@@ -1661,7 +1661,7 @@ void launch_rnvp_fwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, i
     }
 }
 
-void launch_rnvp_bwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, int n_images, hipStream_t s) {
+static void launch_rnvp_bwd(const PcnWs& w, const float* rp, const InrGridDesc* grid, int n_images, hipStream_t s) {
     RnvpBwdArgs a{};
     a.RE = w.RE;   // packed by the forward of this step
     a.dxd = w.dxd;
@@ -1738,7 +1738,7 @@ RnvpUpdArgs make_rnvp_upd_args(const PcnWs& w, int n_images, int mode, float* rp
 }
 
 // the ICNN update `ui` and the RealNVP's optimizer step in one launch (pcn_update_kernel)
-void launch_pcn_update(const KernelEntry* e, const PcnWs& w, const UpdArgs& ui, RnvpUpdArgs ur, int n_images, hipStream_t s) {
+static void launch_pcn_update(const KernelEntry* e, const PcnWs& w, const UpdArgs& ui, RnvpUpdArgs ur, int n_images, hipStream_t s) {
     const int nbf = w.rm.F + 1;
     const dim3 gi = upd_grid(e->img.sl_cols, n_images, nbf), g(gi.x + nbf, n_images), b = upd_block(e->img.sl_cols, nbf);
     ur.status = nullptr;
@@ -1749,7 +1749,7 @@ void launch_pcn_update(const KernelEntry* e, const PcnWs& w, const UpdArgs& ui, 
     else hipLaunchKernelGGL(pcn_update_kernel<3>, g, b, 0, s, ui, ur, (int)gi.x);
 }
 
-void launch_rnvp_update_args(const PcnWs& w, int n_images, const RnvpUpdArgs& u, hipStream_t s) {
+static void launch_rnvp_update_args(const PcnWs& w, int n_images, const RnvpUpdArgs& u, hipStream_t s) {
     const dim3 g(w.rm.F + 1, n_images);
     if (w.rm.C == 2) hipLaunchKernelGGL(rnvp_update_kernel<2>, g, dim3(256), 0, s, u);
     else hipLaunchKernelGGL(rnvp_update_kernel<3>, g, dim3(256), 0, s, u);
@@ -1990,7 +1990,7 @@ int64_t inrfit_joint_loss_workspace_bytes(int64_t n_elems) {
 
 namespace {
 
-int check_joint_desc(const InrJointLossDesc* d) {
+static int check_joint_desc(const InrJointLossDesc* d) {
     if (!d) return INR_EINVAL;
     if (d->kind != INR_LOSS_SE && d->kind != INR_LOSS_BCE) return INR_EINVAL;
     if (d->weight_mode < INR_WEIGHT_NONE || d->weight_mode > INR_WEIGHT_SSSDMS) return INR_EINVAL;
@@ -2154,7 +2154,7 @@ int joint_begin(const InrJointLossDesc* desc, const InrOptDesc* opt, const float
     return INR_OK;
 }
 
-void joint_finish(const JointCtx& c, const KernelEntry* e, const Workspace& w, float* loss_out, hipStream_t s) {
+static void joint_finish(const JointCtx& c, const KernelEntry* e, const Workspace& w, float* loss_out, hipStream_t s) {
     JointFinArgs f{};
     f.jl = c.jl;
     f.slabs = w.slabs;
@@ -2166,11 +2166,11 @@ void joint_finish(const JointCtx& c, const KernelEntry* e, const Workspace& w, f
     hipLaunchKernelGGL(joint_step_finish_kernel, dim3(1), dim3(256), 0, s, f);
 }
 
-void joint_dseg(const JointCtx& c, float* dseg, hipStream_t s) {
+static void joint_dseg(const JointCtx& c, float* dseg, hipStream_t s) {
     hipLaunchKernelGGL(joint_loss_grad_kernel<true>, dim3(c.jl.blocks), dim3(256), 0, s, c.jl, (const float*)c.logits, dseg);
 }
 
-void set_step_consts(UpdArgs& u, const InrOptDesc* opt, int t) {
+static void set_step_consts(UpdArgs& u, const InrOptDesc* opt, int t) {
     u.t = t;
     u.bc1 = 1.0 - pow((double)opt->beta1, (double)t);
     u.bc2_sqrt = (float)sqrt(1.0 - pow((double)opt->beta2, (double)t));

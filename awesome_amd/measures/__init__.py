@@ -1,1 +1,2 @@
-from .losses import SE, UnariesWeightedLoss, UnariesConversionLoss, criterion_targets, MIOU, AwesomeImageLoss, AwesomeLoss, FBMSJointLoss, criterion_to_desc  # noqa: F401
+from .losses import (SE, WeightedLoss, UnariesWeightedLoss, UnariesConversionLoss, criterion_targets, MIOU, AwesomeImageLoss,  # noqa: F401
+                     AwesomeLoss, AwesomeImageLossJoint, AwesomeLossJoint, RegularizerLoss, TV, FBMSJointLoss, criterion_to_desc)

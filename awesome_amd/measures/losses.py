@@ -12,55 +12,100 @@ import torch.nn.functional as F
 from .. import icnn as K
 
 
+_REDUCTIONS = {"sum": torch.sum, "mean": torch.mean, "max": torch.max, "min": torch.min}
+
+
+def _reduce(loss: torch.Tensor, reduction: str, reduction_dim=None) -> torch.Tensor:
+    """awesome/measures/torch_reducable_metric.py:36-55 compute_return_value."""
+    if reduction == "none":
+        return loss
+    return _REDUCTIONS[reduction](loss, **({} if reduction_dim is None else {"dim": reduction_dim}))
+
+
 class SE:
     """awesome/measures/se.py:21-23 - squared error with sum/mean/none reduction."""
 
-    def __init__(self, reduction: str = "mean", name: Optional[str] = None, **kwargs):
-        if reduction not in ("sum", "mean", "none"):
+    def __init__(self, reduction: str = "mean", name: Optional[str] = None, reduction_dim=None, **kwargs):
+        if reduction not in ("sum", "mean", "none", "max", "min"):
             raise ValueError(f"Value {reduction} for reduction is invalid.")
-        self.reduction, self.name = reduction, name
+        self.reduction, self.name, self.reduction_dim = reduction, name, reduction_dim
 
     def __call__(self, output: torch.Tensor, target: torch.Tensor, **kwargs) -> torch.Tensor:
-        se = (target - output) ** 2
-        return se if self.reduction == "none" else getattr(torch, self.reduction)(se)
+        return _reduce((target - output) ** 2, self.reduction, self.reduction_dim)
 
     def get_name(self) -> str:
         return self.name or (self.reduction[0].upper() + "SE")
 
 
-class UnariesWeightedLoss:
-    """awesome/measures/unaries_weighted_loss.py:9-69 (+ weighted_loss.py:67-92): criterion with reduction none,
-    per-class weight on target < 0.5 from the fg/bg count ratio, then mean."""
+class WeightedLoss:
+    """awesome/measures/weighted_loss.py:11-92: criterion (reduction forced to none) on CLASS targets {0 = fg, 1 = bg}, pixels whose
+    target equals `noneclass` dropped first (:71-74; the weak labels of the FBMS configs mark unlabeled pixels with 2), per-class
+    weight on the fg pixels from the bg / fg count ratio (modes equal / sssdms, :38-62), then the reduction.  The criterion of 153
+    of the reference's FBMSJointLoss configs is WeightedLoss(BCELoss, mode sssdms, noneclass 2)."""
 
-    def __init__(self, criterion=None, mode: str = "none", ratio: float = 1.0, reduction: str = "mean", name=None, **kwargs):
+    MODES = ("none", "sssdms", "equal")
+
+    def __init__(self, criterion=None, noneclass: Optional[float] = None, name: Optional[str] = None,
+                 forward_kwargs_criterion: bool = False, reduction: str = "mean", reduction_dim=None, mode: str = "none", **kwargs):
+        if reduction not in ("sum", "mean", "none", "max", "min"):
+            raise ValueError(f"Value {reduction} for reduction is invalid.")
         if criterion is None:
             raise ValueError("criterion must be specified")
-        if mode not in ("none", "equal", "ratio", "sssdms"):
+        if mode not in self.MODES:
             raise ValueError(f"Mode {mode} is not supported")
-        self.criterion, self.mode, self.ratio, self.reduction, self.name = criterion, mode, ratio, reduction, name
+        self.name, self.reduction, self.reduction_dim = name, reduction, reduction_dim
+        self.criterion, self.forward_kwargs_criterion, self.noneclass, self.mode = criterion, forward_kwargs_criterion, noneclass, mode
         if hasattr(criterion, "reduction"):
             criterion.reduction = "none"
 
+    def _classes(self, target: torch.Tensor):
+        """(fg pixels, bg pixels) as masks: class targets 0 / 1 (weighted_loss.py:42-43)."""
+        return target == 0, target == 1
+
     def _weight(self, target: torch.Tensor) -> torch.Tensor:
-        fg = (target < 0.5).sum()
-        bg = (target >= 0.5).sum()
-        cc = bg.float() / fg.float()
-        if self.mode == "ratio":
-            wv = (cc - 1) * self.ratio + 1
-        elif self.mode == "sssdms":
+        fg, bg = self._classes(target)
+        cc = bg.sum().float() / fg.sum().float()
+        if self.mode == "sssdms":
             wv = torch.round(cc / 10) + 1
+        elif self.mode == "ratio":
+            wv = (cc - 1) * self.ratio + 1
         else:
             wv = cc
-        return torch.where(target < 0.5, wv, torch.ones_like(target))
+        return torch.where(fg, wv, torch.ones_like(target))
 
     def __call__(self, output: torch.Tensor, target: torch.Tensor, **kwargs) -> torch.Tensor:
-        loss = self.criterion(output, target)
+        o, t = output, target
+        if self.noneclass is not None:
+            keep = target != self.noneclass
+            o, t = output[keep], target[keep]
+        if t.dim() >= 2:
+            if t.dim() == 3:
+                raise ValueError("Expected 4D target, got 3D target")
+            shape = (t.shape[0] * t.shape[2] * t.shape[3], t.shape[1])
+            o, t = o.permute(0, 2, 3, 1).reshape(shape), t.permute(0, 2, 3, 1).reshape(shape)
+        loss = self.criterion(o, t, **(kwargs if self.forward_kwargs_criterion else {}))
         if self.mode != "none":
-            loss = loss * self._weight(target)
-        return loss if self.reduction == "none" else getattr(torch, self.reduction)(loss)
+            loss = loss * self._weight(t)
+        return _reduce(loss, self.reduction, self.reduction_dim)
 
     def get_name(self) -> str:
         return self.name or type(self).__name__
+
+
+class UnariesWeightedLoss(WeightedLoss):
+    """awesome/measures/unaries_weighted_loss.py:9-69: WeightedLoss on UNARIES - fg is `target < 0.5`, the counts are those of
+    `target >= 0.5` - plus the `ratio` mode."""
+
+    MODES = ("none", "equal", "ratio", "sssdms")
+
+    def __init__(self, criterion=None, noneclass=None, name=None, forward_kwargs_criterion: bool = False, reduction: str = "mean",
+                 reduction_dim=None, mode: str = "none", ratio: float = 1.0, **kwargs):
+        super().__init__(criterion=criterion, noneclass=noneclass, name=name, forward_kwargs_criterion=forward_kwargs_criterion,
+                         reduction=reduction, reduction_dim=reduction_dim, mode=mode)
+        self.ratio = ratio
+
+    def _classes(self, target: torch.Tensor):
+        return target < 0.5, target >= 0.5      # unaries_weighted_loss.py:38-39
 
 
 class UnariesConversionLoss:
@@ -274,6 +319,115 @@ class FBMSJointLoss:
             scale = torch.where(pen > seg_loss, seg_loss / pen, torch.ones_like(pen)).detach()
             pen = pen * scale
         return seg_loss + pen
+
+    def get_name(self) -> str:
+        return self.name or type(self).__name__
+
+
+class TV(torch.nn.Module):
+    """awesome/measures/tv.py:6-55: mean squared forward differences of a (B, C, H, W) tensor along both image axes, optionally
+    weighted by exp(-5 * the same statistic of the clean image) (the `_input[-1]["clean_image"]` convention of the joint losses)."""
+
+    def forward(self, x: torch.Tensor, _input=None, **kwargs) -> torch.Tensor:
+        b, _, h, w = x.shape
+        count_h = x[:, :, 1:, :][0].numel()
+        count_w = x[:, :, :, 1:][0].numel()
+        h_tv = torch.pow(x[:, :, 1:, :] - x[:, :, :h - 1, :], 2).sum()
+        w_tv = torch.pow(x[:, :, :, 1:] - x[:, :, :, :w - 1], 2).sum()
+        weight = 1
+        image = None
+        if _input is not None and len(_input) > 0 and isinstance(_input[-1], dict):
+            image = _input[-1].get("clean_image", None)
+        if image is not None:
+            g = torch.mean(image, dim=1)
+            gh = torch.pow(g[:, 1:, :] - g[:, :-1, :], 2).sum()
+            gw = torch.pow(g[:, :, 1:] - g[:, :, :-1], 2).sum()
+            weight = torch.exp(-5 * (torch.abs(gh / count_h) + torch.abs(gw / count_w)) / b) / 2
+        return weight * 2 * (h_tv / count_h + w_tv / count_w) / b
+
+
+class RegularizerLoss:
+    """awesome/measures/regularizer_loss.py:9-43: criterion(output, target) + tau * regularizer(output, **kwargs)."""
+
+    def __init__(self, criterion=None, tau: float = 0.0, regularizer=None, name: Optional[str] = None, **kwargs):
+        if criterion is None:
+            raise ValueError("criterion must not be None")
+        if regularizer is None and tau > 0.0:
+            raise ValueError("regularizer must not be None if tau is larger zero!")
+        self.name, self.criterion, self.tau, self.regularizer = name, criterion, tau, regularizer
+
+    def __call__(self, output: torch.Tensor, target: torch.Tensor, **kwargs) -> torch.Tensor:
+        loss = self.criterion(output, target)
+        if self.tau > 0.0:
+            loss = loss + self.tau * self.regularizer(output, **kwargs)
+        return loss
+
+    def get_name(self) -> str:
+        return self.name or type(self).__name__
+
+
+class AwesomeImageLossJoint:
+    """awesome/measures/awesome_image_loss_joint.py:11-70 (the `segmentation_training_mode: multi` convexity configs): the same data
+    terms as AwesomeImageLoss with ONE criterion for both channels; the alignment term is `mean((prior - seg)^2)` - on the soft
+    segmentation output, where AwesomeImageLoss thresholds it - once `extra_penalty` is on, or `mean((prior - (seg > .5))^2)` from the
+    start with `map_initially_on_segmentation`.  The criterion is called with the step's kwargs and told through its
+    `apply_gradient_penalty` attribute not to add its penalty on the prior channel (:41-43)."""
+
+    def __init__(self, criterion=None, alpha: float = 1.0, beta: float = 1.0, gamma: float = 1, name: Optional[str] = None,
+                 map_initially_on_segmentation: bool = False, **kwargs):
+        self.name = name
+        self.criterion = criterion or torch.nn.BCELoss()
+        self.alpha, self.beta, self.gamma = alpha, beta, gamma
+        self.extra_penalty = False
+        self.map_initially_on_segmentation = map_initially_on_segmentation
+
+    def __call__(self, output: torch.Tensor, target: torch.Tensor, **kwargs) -> torch.Tensor:
+        c = output.shape[1] // 2
+        seg, prior = output[:, :c], output[:, c:]
+        takes_kwargs = not isinstance(self.criterion, torch.nn.modules.loss._Loss)
+        kw = kwargs if takes_kwargs else {}
+        seg_loss = self.criterion(seg, target, **kw)
+        self.criterion.apply_gradient_penalty = False
+        prior_loss = self.criterion(prior, target, **kw)
+        self.criterion.apply_gradient_penalty = True
+        loss = seg_loss + self.alpha * prior_loss
+        if self.extra_penalty:
+            loss = self.gamma * loss + self.beta * torch.mean((prior - seg) ** 2)
+        elif self.map_initially_on_segmentation:
+            loss = self.gamma * loss + self.beta * torch.mean((prior - (seg > 0.5).float()) ** 2)
+        return loss
+
+    def get_name(self) -> str:
+        return self.name or type(self).__name__
+
+
+class AwesomeLossJoint:
+    """awesome/measures/awesome_loss_joint.py:10-89 (pixel mode of the joint convexity configs): data terms on the first
+    floor(n * scribble_percentage) pixels for both channels, and with `extra_penalty` `gamma * loss + beta * mean((prior - seg)^2)` on
+    the pixels `[n - n_scribble, n)` - the reference's own slice, on the SOFT segmentation output."""
+
+    def __init__(self, criterion=None, alpha: float = 1.0, beta: float = 1.0, gamma: float = 1, name: Optional[str] = None,
+                 scribble_percentage: float = 1.0, **kwargs):
+        self.name = name
+        self.criterion = criterion or torch.nn.BCELoss()
+        self.alpha, self.beta, self.gamma = alpha, beta, gamma
+        self.extra_penalty = False
+        self.scribble_percentage = scribble_percentage
+
+    def __call__(self, output: torch.Tensor, target: torch.Tensor, **kwargs) -> torch.Tensor:
+        total = output.shape[-2]
+        n_scr = int(total * self.scribble_percentage // 1)
+        n_rand = total - n_scr
+        seg, prior = output[..., :n_scr, 0:1], output[..., :n_scr, 1:2]
+        seg_loss = self.criterion(seg, target)
+        self.criterion.apply_gradient_penalty = False
+        prior_loss = self.criterion(prior, target)
+        self.criterion.apply_gradient_penalty = True
+        loss = seg_loss + self.alpha * prior_loss
+        if self.extra_penalty and n_rand > 0:
+            seg_r, prior_r = output[..., n_rand:, 0:1], output[..., n_rand:, 1:2]
+            loss = self.gamma * loss + self.beta * torch.mean((prior_r - seg_r) ** 2)
+        return loss
 
     def get_name(self) -> str:
         return self.name or type(self).__name__

@@ -15,6 +15,7 @@ backward, get_deformation, the ActNorm data-dependent init and the fused fit - r
 from __future__ import annotations
 
 import math
+import os
 import re
 import copy
 from typing import Any, Dict, Optional, Tuple
@@ -307,9 +308,12 @@ class PathConnectedNet(nn.Module, PriorFitMixin):
             self.learn_convex_net(whole, frame_unaries.reshape(1, -1), lr=float(opts["prefit_convex_net_lr"]),
                                   weight_decay=float(opts["prefit_convex_net_weight_decay"]),
                                   max_iter=int(opts["prefit_convex_net_num_epochs"]))
-        from ..measures import criterion_to_desc
+        from ..measures import criterion_targets, criterion_to_desc
         crit = opts.get("criterion")
         kind, wmode, _ = criterion_to_desc(crit) if crit is not None else ("se", "none", 1.0)
+        frame_unaries = self._sequence_unaries(frame_unaries, opts, agent)
+        # criterion_to_desc unwraps UnariesConversionLoss; its effect - binarised targets - is applied here
+        frame_unaries = criterion_targets(crit, frame_unaries).contiguous()
         self.pretrain_epoch_losses = self.fit_sequence(frame_coords, frame_unaries, num_epochs=int(opts["num_epochs"]),
                                                        lr=float(opts["lr"]), flow_weight_decay=float(opts["flow_weight_decay"]),
                                                        batch_size=min(int(opts["batch_size"]), T),
@@ -319,6 +323,10 @@ class PathConnectedNet(nn.Module, PriorFitMixin):
             if hasattr(m, "data_dep_init_done"):
                 m.data_dep_init_done.fill_(1.0)
         return self.state_dict()
+
+    def _sequence_unaries(self, frame_unaries: torch.Tensor, opts: Dict[str, Any], agent=None) -> torch.Tensor:
+        """The unaries (T, HW) the mini-batch epochs train on; hook of NoisyPathConnectedNet."""
+        return frame_unaries
 
     def __init__(self, convex_net: ConvexNextNet, flow_net: NormNet, in_channels: int = 2, **kwargs):
         super().__init__()
@@ -614,10 +622,39 @@ class PathConnectedNet(nn.Module, PriorFitMixin):
                 own[k].copy_(v.to(own[k].device))
 
 
+class NoisyPathConnectedNet(PathConnectedNet):
+    """awesome/model/noisy_path_connected_net.py:35-280 - the noisy spatio-temporal demonstration (`network_type` of the 21
+    `config/path-connectedness/noisy-spatio-temporal` YAMLs): the spatio-temporal pretrain with the unaries of
+    `round(T * noisy_percentage)` frames (never the first or the last one, :141-143) replaced by `clamp(randn + 0.5, 0, 1)`, the same
+    noise in every epoch (:178-191); the replaced frames and their noise are saved next to the agent's outputs (:236-237)."""
+
+    def _sequence_unaries(self, frame_unaries: torch.Tensor, opts: Dict[str, Any], agent=None) -> torch.Tensor:
+        import numpy as np
+        T = frame_unaries.shape[0]
+        pct = float(opts.get("noisy_percentage", 0.333))
+        candidates = np.arange(1, T - 1)
+        n = int(round(T * pct))
+        if n > len(candidates):
+            raise ValueError(f"noisy_percentage {pct} asks for {n} noisy frames of {T} (the first and the last are never replaced)")
+        idx = sorted(np.random.choice(candidates, size=n, replace=False).tolist())
+        out = frame_unaries.clone()
+        noisy = {}
+        for k in idx:
+            noisy[k] = torch.clamp(torch.randn_like(out[k]) + 0.5, 0.0, 1.0)
+            out[k] = noisy[k]
+        self.noisy_unaries_dict = noisy
+        folder = getattr(agent, "agent_folder", None)
+        if folder:
+            os.makedirs(folder, exist_ok=True)
+            torch.save({k: v.cpu() for k, v in noisy.items()}, os.path.join(folder, "noisy_unaries_dict.pth"))
+        return out
+
+
 def real_nvp_path_connected_net(channels: int = 2, hidden_units: int = 130, flow_n_flows: int = 6,
                                 flow_output_fn: Optional[str] = None, flow_output_scale: Optional[float] = None,
                                 norm: str = "minmax", spatial_shape: tuple = (1000, 1000), convex_net_hidden_units: int = 130,
-                                convex_net_hidden_layers: int = 2, network_args: Optional[Dict[str, Any]] = None,
+                                convex_net_hidden_layers: int = 2, dtype: torch.dtype = torch.float32,
+                                network_type: Optional[type] = None, network_args: Optional[Dict[str, Any]] = None,
                                 **kwargs) -> PathConnectedNet:
     """awesome/model/net_factory.py:124-175.  The MinMax is fitted on create_normalized_grid (values in [0, 1] per channel,
     path_connected_net.py:273-296), i.e. min = 0, max = 1 per channel whatever spatial_shape is."""
@@ -630,6 +667,12 @@ def real_nvp_path_connected_net(channels: int = 2, hidden_units: int = 130, flow
     mm.max = torch.ones(1, channels, 1, 1)
     mm.fitted = True
     norm_flow = NormNet(net=PixelizeNet(flow_net), norm=mm)
-    return PathConnectedNet(convex_net=ConvexNextNet(n_hidden=convex_net_hidden_units, n_hidden_layers=convex_net_hidden_layers,
-                                                     in_features=channels),
-                            flow_net=norm_flow, in_channels=channels, **(network_args or {}))
+    if network_type is None:
+        network_type = PathConnectedNet
+    if not (isinstance(network_type, type) and issubclass(network_type, PathConnectedNet)):
+        raise TypeError(f"network_type must be a PathConnectedNet class of this build, got {network_type!r}")
+    if dtype != torch.float32:
+        raise ValueError("the kernels compute in float32 (every reference config: dtype torch.float32)")
+    return network_type(convex_net=ConvexNextNet(n_hidden=convex_net_hidden_units, n_hidden_layers=convex_net_hidden_layers,
+                                                 in_features=channels),
+                        flow_net=norm_flow, in_channels=channels, **(network_args or {}))

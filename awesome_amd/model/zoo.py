@@ -37,9 +37,7 @@ def _canonical(o: Any) -> Any:
 class Zoo:
     def __init__(self, zoo_folder: Optional[str] = "./data/zoo", **kwargs):
         self.zoo_folder = zoo_folder
-        self._mem: Dict[str, Dict[str, Any]] = {}
-        if zoo_folder is not None:
-            os.makedirs(zoo_folder, exist_ok=True)
+        self._mem: Dict[str, Dict[str, Any]] = {}      # the folder is created by the first save, not by decoding a config
 
     @staticmethod
     def compute_query_hash(name: str, str_repr: str, config: Optional[Dict[str, Any]]) -> str:
@@ -79,5 +77,6 @@ class Zoo:
         if p is not None:
             # ranks of one job can reach the same entry at once: write to a private temp file, then rename (atomic on POSIX)
             tmp = f"{p}.{os.getpid()}.tmp"
+            os.makedirs(self.zoo_folder, exist_ok=True)
             torch.save(e, tmp)
             os.replace(tmp, p)

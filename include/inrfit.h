@@ -31,6 +31,10 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: exactly the declarations between this push and the pop at the end of the file are
+ * exported (nm -D shows the inrfit_* entry points and nothing else of the library's own). */
+#pragma GCC visibility push(default)
+
 #define INRFIT_ABI_VERSION 6
 
 enum {
@@ -437,6 +441,8 @@ int inrfit_star_fit(const InrStarDesc* star, float* params, float* opt_state, co
                     int32_t offset_first_step, float* loss_hist, void* workspace, int64_t workspace_bytes, void* stream);
 
 const char* inrfit_strerror(int code);
+
+#pragma GCC visibility pop
 
 #ifdef __cplusplus
 }

@@ -4,10 +4,14 @@
     python scripts/run.py --config-path config/c2_blob256.yaml [--num-epochs N --seed S --device cuda:0 ...]
 
 Mirrors jp-schneider/awesome scripts/run.py:29-79 (argparse + YAML -> config -> runner.build() -> runner.train()).
-The YAML uses the reference's schema (`AwesomeConfig:` root or flat; `__class__` keys ignored) for the fields on the
-hot path: prior_model_type / prior_model_args (dotted type strings, resolved like awesome/util/reflection.py's
-dynamic_import; `awesome.model.convex_net.*` names map to the drop-in modules), dataset_type / dataset_args,
-loss_type / loss_args, agent_args.pretrain_args (num_epochs, lr, reuse_state...), seed, device, output_folder.
+The config file is the reference's own format: the YAML / JSON image of an `AwesomeConfig`, every nested object a mapping
+`{__class__: dotted.Type, **fields}` (awesome/serialization/json_convertible.py:632-727).  `awesome_amd.serialization` decodes the
+tags into this build's mirrors (criteria, value wrappers, Zoo ...) and RAISES on an in-scope tag it has no mirror for; objects under
+out-of-scope keys (`dataset_args.dataset`: loaders of files that are not in the image) are kept opaque.  Fields on the hot path:
+prior_model_type / prior_model_args (dotted type strings, resolved like awesome/util/reflection.py's dynamic_import;
+`awesome.model.*` names map to the drop-in modules), agent_args.pretrain_args (criterion, num_epochs, lr, reuse_state, zoo ...),
+loss_type / loss_args, optimizer_type / optimizer_args, the extra-penalty hook fields, seed, device, output_folder; a reference
+YAML runs with `--dataset-type / --dataset-args / --segmentation-model-type` replacing what is not in the image.
 Everything else the reference runner does (tensorboard, plots, UNet joint training) is out of scope.
 """
 import argparse
@@ -21,56 +25,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import yaml  # noqa: E402
+from awesome_amd import serialization as S  # noqa: E402
+from awesome_amd.run.config import AwesomeConfig  # noqa: E402
 
-ALIASES = {
-    "awesome.model.convex_net.ConvexNextNet": "awesome_amd.model.ConvexNextNet",
-    "awesome.model.convex_net.ConvexNet": "awesome_amd.model.ConvexNet",
-    "awesome.model.convex_diffeomorphism_net.ConvexDiffeomorphismNet": "awesome_amd.model.ConvexDiffeomorphismNet",
-    "awesome.model.net_factory.real_nvp_path_connected_net": "awesome_amd.model.real_nvp_path_connected_net",
-    "awesome.model.path_connected_net.PathConnectedNet": "awesome_amd.model.PathConnectedNet",
-    "awesome.model.fc_net.FCNet": "awesome_amd.model.FCNet",
-    "awesome.measures.se.SE": "awesome_amd.measures.SE",
-    "awesome.measures.unaries_weighted_loss.UnariesWeightedLoss": "awesome_amd.measures.UnariesWeightedLoss",
-    "awesome.measures.fbms_joint_loss.FBMSJointLoss": "awesome_amd.measures.FBMSJointLoss",
-    "awesome.measures.unaries_conversion_loss.UnariesConversionLoss": "awesome_amd.measures.UnariesConversionLoss",
-    "awesome.measures.awesome_loss.AwesomeLoss": "awesome_amd.measures.AwesomeLoss",
-    "awesome.measures.awesome_image_loss.AwesomeImageLoss": "awesome_amd.measures.AwesomeImageLoss",
-    "awesome.model.forward_module.ForwardModule": "awesome_amd.model.ForwardModule",
-    "awesome.model.wrapper_module.WrapperModule": "awesome_amd.model.WrapperModule",
-}
+ALIASES = S.ALIASES                 # reference type names -> the mirrors of this build
+dynamic_import = S.dynamic_import
 
 
-def dynamic_import(path: str):
-    path = ALIASES.get(path, path)
-    mod, _, name = path.rpartition(".")
-    return getattr(importlib.import_module(mod), name)
-
-
-def strip_class_tags(obj):
-    if isinstance(obj, dict):
-        return {k: strip_class_tags(v) for k, v in obj.items() if k != "__class__"}
-    if isinstance(obj, list):
-        return [strip_class_tags(v) for v in obj]
-    return obj
-
-
-def build_criterion(loss_type, loss_args):
-    import torch
-    if loss_type is None:
-        return None
-    args = dict(loss_args or {})
-    crit = args.get("criterion")
-    if isinstance(crit, dict):  # nested {"type": ..., "args": {...}}
-        args["criterion"] = build_criterion(crit.get("type"), crit.get("args"))
-    elif isinstance(crit, str):
-        args["criterion"] = torch.nn.BCELoss() if crit.endswith("BCELoss") else dynamic_import(crit)()
-    if loss_type.endswith("BCELoss"):
-        return torch.nn.BCELoss()
-    return dynamic_import(loss_type)(**args)
-
-
-def get_config():
+def get_config(argv=None) -> AwesomeConfig:
     ap = argparse.ArgumentParser(description="MI355X INR prior fit (awesome-compatible config entrypoint)")
     ap.add_argument("--config-path", type=str, required=True)
     ap.add_argument("--num-epochs", type=int, default=None)
@@ -78,23 +40,29 @@ def get_config():
     ap.add_argument("--device", type=str, default=None)
     ap.add_argument("--output-folder", type=str, default=None)
     ap.add_argument("--name-experiment", type=str, default=None)
-    ap.add_argument("--dataset-args", type=str, default=None, help="JSON dict merged into the config's dataset_args")
+    ap.add_argument("--dataset-type", type=str, default=None, help="replaces the config's dataset_type (a reference YAML names a "
+                    "loader of files that are not in this image; e.g. awesome_amd.dataset.SyntheticUnariesDataset)")
+    ap.add_argument("--dataset-args", type=str, default=None, help="JSON dict; merged into the config's dataset_args, or replacing "
+                    "them when --dataset-type is given")
+    ap.add_argument("--segmentation-model-type", type=str, default=None)
     ap.add_argument("--prior-model-args", type=str, default=None, help="JSON dict merged into the config's prior_model_args")
-    ap.add_argument("--override", type=str, default=None, help="JSON dict deep-merged into the whole config (e.g. agent_args)")
+    ap.add_argument("--override", type=str, default=None, help="JSON dict deep-merged into the whole config (e.g. agent_args); "
+                    "may hold __class__-tagged objects")
     ap.add_argument("--save-masks", action="store_true", help="export every fitted prior's mask as <output>/masks/<index>.png "
                     "(1 bit per pixel; thresholded and bit-packed on the device, awesome_amd.run.evaluate_dataset)")
-    args = ap.parse_args()
-    with open(args.config_path) as f:
-        cfg = yaml.safe_load(f)
-    cfg = strip_class_tags(cfg.get("AwesomeConfig", cfg))
-    for k in ("num_epochs", "seed", "device", "output_folder", "name_experiment"):
+    args = ap.parse_args(argv)
+    # the reference's file format: {AwesomeConfig: {__class__: ..., field: value | {__class__: dotted.Type, **fields}}}
+    # (awesome/serialization/json_convertible.py:632-727); nested objects are decoded into the mirrors, nothing is dropped
+    cfg = AwesomeConfig.load_from_file(args.config_path)
+    for k in ("num_epochs", "seed", "device", "output_folder", "name_experiment", "dataset_type", "segmentation_model_type"):
         v = getattr(args, k)
         if v is not None:
             cfg[k] = v
-    for k in ("dataset_args", "prior_model_args"):
-        v = getattr(args, k)
-        if v is not None:
-            cfg[k] = dict(cfg.get(k) or {}, **json.loads(v))
+    if args.dataset_args is not None:
+        extra = S.decode(json.loads(args.dataset_args), in_scope=False, path="dataset_args")
+        cfg["dataset_args"] = extra if args.dataset_type else dict(cfg.get("dataset_args") or {}, **extra)
+    if args.prior_model_args is not None:
+        cfg["prior_model_args"] = dict(cfg.get("prior_model_args") or {}, **S.decode(json.loads(args.prior_model_args), path="prior_model_args"))
 
     def deep_merge(dst, src):
         for k, v in src.items():
@@ -103,7 +71,11 @@ def get_config():
             else:
                 dst[k] = v
     if args.override:
-        deep_merge(cfg, json.loads(args.override))
+        over = {k: S.decode(v, in_scope=k in S.IN_SCOPE_KEYS, path=k) for k, v in json.loads(args.override).items()}
+        merged = cfg.to_dict()
+        deep_merge(merged, over)
+        for k in over:
+            cfg[k] = merged[k]
     if args.save_masks:
         cfg["save_masks"] = True
     return cfg
@@ -138,16 +110,25 @@ def main(cfg):
     seed = int(cfg.get("seed", 42))
     torch.manual_seed(seed)
 
-    model_type = dynamic_import(cfg.get("prior_model_type", "awesome_amd.model.ConvexNextNet"))
-    model_args = dict(cfg.get("prior_model_args") or {})
-    dataset_type = dynamic_import(cfg.get("dataset_type", "awesome_amd.dataset.SyntheticUnariesDataset"))
-    dataset_args = dict(cfg.get("dataset_args") or {})
-    pre = dict((cfg.get("agent_args") or {}).get("pretrain_args") or {})
-    num_epochs = int(cfg.get("num_epochs", pre.get("num_epochs", 2000)))
-    criterion = build_criterion(cfg.get("loss_type"), cfg.get("loss_args"))
-    opt_type = cfg.get("optimizer_type", "torch.optim.Adamax").rsplit(".", 1)[-1].lower()
-    opt_args = dict(cfg.get("optimizer_args") or {})
-    out_dir = os.path.join(cfg.get("output_folder", "runs"), cfg.get("name_experiment", "inr_fit"))
+    model_type = cfg.prior_model_factory()
+    model_args = dict(cfg.prior_model_args or {})
+    ds_name = cfg.dataset_type if "dataset_type" in cfg.explicit else "awesome_amd.dataset.SyntheticUnariesDataset"
+    if isinstance(ds_name, str) and ds_name.startswith("awesome.dataset."):
+        raise SystemExit(f"dataset_type {ds_name} reads files that are not part of this build (SURVEY.md section 8: data loaders are "
+                         "out of scope); pass --dataset-type awesome_amd.dataset.SyntheticUnariesDataset --dataset-args '{...}'")
+    dataset_type = dynamic_import(ds_name) if isinstance(ds_name, str) else ds_name
+    dataset_args = dict(cfg.dataset_args or {})
+    # the per-image fit takes ITS arguments from agent_args.pretrain_args (criterion, lr, num_epochs, reuse_state, zoo ... -
+    # torch_agent.py:561-627 hands them to PretrainableModule.pretrain); optimizer_type / optimizer_args / loss_type / num_epochs of
+    # the config belong to the joint training that follows (awesome_runner.py:246-283)
+    pre = cfg.pretrain_args()
+    num_epochs = int(pre.get("num_epochs", 2000))
+    if "num_epochs" in cfg.explicit and "num_epochs" not in pre:   # this repo's own YAMLs / --num-epochs without a pretrain block
+        num_epochs = int(cfg.num_epochs)
+    criterion = cfg.build_loss() if "loss_type" in cfg.explicit else None
+    opt_type = cfg.optimizer_name()
+    opt_args = dict(cfg.optimizer_args or {})
+    out_dir = os.path.join(cfg.get("output_folder") or "runs", cfg.get("name_experiment") or "inr_fit")
     if rank == 0:
         os.makedirs(out_dir, exist_ok=True)
     parallel.barrier()
@@ -163,12 +144,10 @@ def main(cfg):
     wrapper = WrapperModule(ForwardModule(), model_type(**model_args), use_segmentation_output_inversion=True).to(device)
     kw = dict(pre)
     kw["num_epochs"] = num_epochs
-    kw.setdefault("lr", float(opt_args.get("lr", 1e-3)))
-    kw.setdefault("optimizer", opt_type)
-    kw.setdefault("weight_decay", float(opt_args.get("weight_decay", 0.0)))
-    kw.setdefault("reuse_state", False)         # the synthetic images are unrelated fits (FBMS sequence configs set it true)
+    if getattr(ds, "independent_images", True):
+        kw.setdefault("reuse_state", False)     # the synthetic images are unrelated fits (FBMS sequence configs chain the frames)
     if criterion is not None and _fusable(criterion):
-        kw.setdefault("criterion", criterion)
+        kw.setdefault("criterion", criterion)   # extension: a fusable loss_type doubles as the fit's criterion when pretrain_args has none
     if kw.get("zoo") and not hasattr(kw["zoo"], "load_model_state"):
         from awesome_amd.model import Zoo
         kw["zoo"] = Zoo(None if kw["zoo"] == "memory" else str(kw["zoo"]))
@@ -176,7 +155,11 @@ def main(cfg):
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    report, joint_losses, joint_epochs, error = [], [], int((cfg.get("agent_args") or {}).get("joint_epochs", 0)), None
+    # joint training after the fits: `agent_args.joint_epochs` (this entrypoint's switch), or - a reference YAML - `num_epochs` epochs
+    # unless `agent_args.pretrain_only` is set (awesome_runner.py:318-340 trains `num_epochs` after the agent's pretraining)
+    agent_args = dict(cfg.agent_args or {})
+    joint_epochs = int(agent_args.get("joint_epochs", 0 if agent_args.get("pretrain_only", True) else cfg.num_epochs))
+    report, joint_losses, error = [], [], None
     try:                                        # rank-local work: an exception here must not strand the other ranks (below)
         report, joint_losses = _fit_shard(cfg, ds, mine, agent, wrapper, criterion, model_type, model_args, opt_args, device, joint_epochs)
     except Exception as err:   # noqa: BLE001 - reported, agreed on by all ranks, and turned into a non-zero exit
@@ -287,7 +270,11 @@ def _fit_shard(cfg, ds, mine, agent, wrapper, criterion, model_type, model_args,
     if joint_epochs > 0 and mine and criterion is not None and not _fusable(criterion):
         from awesome_amd.agent import JointTrainer
         from awesome_amd.prior_bank import PriorBank
-        seg_type = dynamic_import(cfg.get("segmentation_model_type", "awesome_amd.model.ConvSegStandIn"))
+        seg_name = cfg.segmentation_model_type if "segmentation_model_type" in cfg.explicit else "awesome_amd.model.ConvSegStandIn"
+        if isinstance(seg_name, str) and seg_name.startswith("awesome.model.") and seg_name not in ALIASES:
+            raise SystemExit(f"segmentation_model_type {seg_name} is outside this build (SURVEY.md section 8: backbones run on torch as "
+                             "they are); pass --segmentation-model-type with an importable torch module type")
+        seg_type = dynamic_import(seg_name) if isinstance(seg_name, str) else seg_name
         seg = seg_type(**dict(cfg.get("segmentation_model_args") or {})).to(device)
         prior = wrapper.prior_module
         jw = WrapperModule(seg, prior, use_segmentation_output_inversion=True).to(device)
@@ -297,7 +284,8 @@ def _fit_shard(cfg, ds, mine, agent, wrapper, criterion, model_type, model_args,
             prior.load_state_dict({n: v.to(device) for n, v in cache0[k].items()})
             bank.row(k).copy_(torch.cat([p.detach().reshape(-1) for p in bank_params(prior)]))
         params = [p for p in seg.parameters()] + bank_params(prior)
-        opt = torch.optim.Adam(params, lr=float(opt_args.get("lr", 1e-3)))
+        opt_cls = cfg.optimizer_type if not isinstance(cfg.optimizer_type, str) else dynamic_import(cfg.optimizer_type)
+        opt = opt_cls(params, **opt_args)       # awesome_runner.py:246-252: optimizer_type(**optimizer_args)
         trainer = JointTrainer(jw, bank, criterion, opt)
         for epoch in range(joint_epochs):
             # the runner's extra-penalty hook (awesome/run/awesome_runner.py:351-371; config fields awesome_config.py:164-173): from
@@ -335,7 +323,8 @@ def _run_sequence(cfg, A, parallel, rank, world, device, model_type, model_args,
     from awesome_amd.measures import criterion_to_desc
     mine = list(parallel.shard_range(len(dataset), rank, world))
     grid = A.Grid.explicit(dataset.coords().to(device))
-    lr = float(opt_args.get("lr", pre.get("lr", 1e-3)))
+    lr = float(pre.get("lr", 1e-3))
+    opt_type = str(pre.get("optimizer", "adamax")).lower()
     kind, wmode, _ = criterion_to_desc(criterion) if criterion is not None else ("se", "none", 1.0)
     kw = dict(num_epochs=num_epochs, lr=lr, loss=kind, weight_mode=wmode, flow_weight_decay=float(pre.get("flow_weight_decay", 1e-5)),
               optimizer=opt_type)
