@@ -15,7 +15,7 @@ INR_LOSS_SE, INR_LOSS_BCE = 0, 1
 INR_WEIGHT_NONE, INR_WEIGHT_EQUAL, INR_WEIGHT_RATIO, INR_WEIGHT_SSSDMS, INR_WEIGHT_EXPLICIT = 0, 1, 2, 3, 4
 INR_OPT_ADAM, INR_OPT_ADAMAX = 0, 1
 INR_OPT_HEADER_FLOATS = 8
-INRFIT_ABI_VERSION = 6
+INRFIT_ABI_VERSION = 7
 INR_ACT_RELU, INR_ACT_COS, INR_ACT_SIN = 0, 1, 2
 ACT_KINDS = {"relu": INR_ACT_RELU, "cos": INR_ACT_COS, "sin": INR_ACT_SIN}
 INR_FLOW_NORMAL_BLOCK, INR_FLOW_SIMPLE = 0, 1
@@ -59,7 +59,8 @@ class InrLossDesc(C.Structure):
 class InrJointLossDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("weight_mode", C.c_int32), ("ratio", C.c_float), ("alpha", C.c_float), ("beta", C.c_float),
                 ("clip_penalty", C.c_int32), ("form", C.c_int32), ("prior_kind", C.c_int32), ("prior_weight_mode", C.c_int32),
-                ("prior_ratio", C.c_float), ("gamma", C.c_float), ("extra_penalty", C.c_int32), ("n_scribble", C.c_int64)]
+                ("prior_ratio", C.c_float), ("gamma", C.c_float), ("extra_penalty", C.c_int32), ("n_scribble", C.c_int64),
+                ("target_rule", C.c_int32), ("use_noneclass", C.c_int32), ("noneclass", C.c_float)]   # ABI v7 (zero tail = v6 meaning)
 
 
 JOINT_FBMS, JOINT_AWESOME_IMAGE, JOINT_AWESOME_PIXEL = 0, 1, 2
@@ -190,7 +191,8 @@ def load() -> C.CDLL:
         fn.argtypes = argtypes
     ver = C.c_int(0)
     lib.inrfit_query(C.byref(ver), None, None)
-    if ver.value != INRFIT_ABI_VERSION:
+    # (INRFIT_ABI_ANY=1: kernel A/B tools only - tools/ab.py times an older build's untouched entry points next to this one's)
+    if ver.value != INRFIT_ABI_VERSION and os.environ.get("INRFIT_ABI_ANY", "0") != "1":
         raise InrfitError(f"libinrfit ABI {ver.value} != expected {INRFIT_ABI_VERSION}")
     _lib = lib
     return lib

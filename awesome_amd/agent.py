@@ -128,7 +128,11 @@ class JointTrainer:
     `shared_prior_moments=True`, the default; False keeps Adam moments and step counts per image (fused path only)."""
 
     def __init__(self, wrapper: torch.nn.Module, bank: PriorBank, criterion: Callable, optimizer: torch.optim.Optimizer,
-                 fused: Optional[bool] = None, shared_prior_moments: bool = True):
+                 fused: Optional[bool] = None, shared_prior_moments: bool = True, check_finite: str = "epoch"):
+        if check_finite not in ("step", "epoch"):
+            raise ValueError("check_finite: 'step' (raise before backward like the reference, one host sync per step) or 'epoch' "
+                             "(device flag, the caller polls raise_if_failed())")
+        self.check_finite = check_finite
         self.wrapper, self.bank, self.criterion, self.optimizer = wrapper, bank, criterion, optimizer
         self.forward_additional_loss_args = _loss_takes_input(criterion)
         self.shared_prior_moments = bool(shared_prior_moments)
@@ -139,6 +143,64 @@ class JointTrainer:
         self._t: Dict[Any, int] = {}
         self._opt_state: Dict[Any, Tuple[torch.Tensor, Optional[torch.Tensor]]] = {}
         self.last_status: Optional[torch.Tensor] = None
+        self.failed = torch.zeros((), dtype=torch.bool, device=bank.device)   # any step so far had a non-finite loss (device flag)
+        self._path: Optional[str] = None       # which implementation took the previous step ("fused" / "autograd")
+
+    # -- ONE optimizer state for the prior, whichever implementation steps it -----------------------------------------------
+    # The reference has one torch optimizer for the whole run (torch_agent.py:812-839).  The fused step keeps the prior's moments
+    # in its own flat buffers; when a step has to take the other implementation (AwesomeImageLoss once the runner's hook has set
+    # `extra_penalty`, a batch of more than one image, the step that initialises ActNorm) the moments and the step count move
+    # with it, so the trajectory is the single-optimizer one (ADVICE r03).  Per-image moments (shared_prior_moments=False) exist
+    # in the fused buffers only and are not carried over.
+    def _prior_params(self):
+        from .prior_bank import _ordered_parameters
+        return list(_ordered_parameters(self.wrapper.prior_module))
+
+    def _moment_keys(self) -> Tuple[str, str]:
+        return ("exp_avg", "exp_inf") if self._fused_plan["kind"] == "adamax" else ("exp_avg", "exp_avg_sq")
+
+    def _flat_moment_views(self, plan):
+        """[(parameter, first-moment view, second-moment view)] into the fused buffers, in bank-row order."""
+        iopt, fopt = self._state_for(None, plan)
+        P = plan["ispec"].n_params
+        Pd = 0 if plan["dspec"] is None else plan["dspec"].n_params
+        out, off = [], 0
+        for p in self._prior_params():
+            n = p.numel()
+            if off < P:
+                m, v = iopt[off:off + n], iopt[P + off:P + off + n]
+            else:
+                o = off - P
+                m, v = fopt[o:o + n], fopt[Pd + o:Pd + o + n]
+            out.append((p, m, v))
+            off += n
+        assert off == P + Pd, (off, P, Pd)
+        return out
+
+    def _hand_over(self, to: str) -> None:
+        plan = self._fused_plan
+        if plan is None or not self.shared_prior_moments or self._path in (None, to):
+            self._path = to
+            return
+        k1, k2 = self._moment_keys()
+        views = self._flat_moment_views(plan)
+        if to == "autograd":      # fused buffers -> torch.optim state
+            t = self._t.get(None, 0)
+            if t > 0:
+                for p, m, v in views:
+                    st = self.optimizer.state[p]
+                    st["step"] = torch.tensor(float(t), dtype=torch.float32)
+                    st[k1], st[k2] = m.detach().clone().view_as(p), v.detach().clone().view_as(p)
+        else:                     # torch.optim state -> fused buffers
+            steps = [float(self.optimizer.state[p]["step"]) for p, _, _ in views if "step" in self.optimizer.state.get(p, {})]
+            if steps:
+                for p, m, v in views:
+                    st = self.optimizer.state.get(p, {})
+                    if k1 in st:
+                        m.copy_(st[k1].reshape(-1))
+                        v.copy_(st[k2].reshape(-1))
+                self._t[None] = int(max(steps))
+        self._path = to
 
     # -- fused path ----------------------------------------------------------------------------------------------------------
     def _plan_fused(self) -> Optional[Dict[str, Any]]:
@@ -168,6 +230,8 @@ class JointTrainer:
                 return None
         elif hasattr(prior, "spec"):
             ispec, dspec, family = prior.spec, None, "icnn"
+            if not ispec.fused():   # n_hidden > 130 or L > 2: inrfit_joint_step has no kernel (INR_EUNSUPPORTED); autograd step
+                return None
             if getattr(prior, "fit_options", None):   # FCNet / encode nets: frozen ranges, no clamp - not part of the joint configs
                 return None
         else:
@@ -196,7 +260,7 @@ class JointTrainer:
         g = plan["group"]
         if desc is None or (plan["family"] != "icnn" and float(g.get("weight_decay", 0.0)) != 0.0):
             return None
-        if desc.form != 0 and (desc.form != 1 or desc.extra_penalty):
+        if desc.form != 0 and (desc.form != 1 or desc.extra_penalty or desc.target_rule or desc.use_noneclass):
             return None   # AwesomeImageLoss with its extra penalty on: two data terms on the prior (inrfit_joint_step: INR_EUNSUPPORTED)
         xi = inputs[0] if inputs[0].dim() == 4 else inputs[0][None]
         if xi.shape[0] != 1:
@@ -204,6 +268,7 @@ class JointTrainer:
         if plan["family"] == "pcn" and not all(float(b) > 0 for n, b in w.prior_module.named_buffers() if n.endswith("data_dep_init_done")):
             return None   # ActNorm's data-dependent initialisation happens in the module's first forward: take the autograd step once
         ai = tuple(a if not isinstance(a, torch.Tensor) or a.dim() == 4 else a[None] for a in inputs[1:])
+        self._hand_over("fused")
         self.optimizer.zero_grad()
         seg = w.segmentation_output(xi, ai)                                   # (1, H, W), autograd attached
         pa, _ = w.get_prior_args(xi, *ai, segm=seg)
@@ -228,6 +293,14 @@ class JointTrainer:
             res = J.cdn_joint_step(plan["ispec"], plan["dspec"], row[:P], row[P:], iopt, fopt, grid, segd, tgt, desc,
                                    weight_decay_on_weight_g=0.0, **hp)
         self.last_status = res.status
+        # A non-finite loss froze the prior's row on the device.  The reference raises ValueError('Loss is nan or inf!') before
+        # backward (torch_agent.py:484-487), which needs the loss on the host: check_finite="step" does exactly that (one 4-byte
+        # read per step).  The default keeps the step free of host syncs: the failure is latched in `failed`, the caller polls it
+        # (scripts/run.py: once per epoch) and raises then - the run is over either way, and a backbone that has produced a NaN
+        # cannot be stepped meaningfully (its own backward multiplies any gradient by NaN).
+        self.failed |= res.status.reshape(-1)[0] != 0
+        if self.check_finite == "step":
+            self.raise_if_failed()
         if seg.requires_grad:
             seg.backward(res.dseg.view_as(seg))
         self.optimizer.step()                                                  # segmentation parameters only
@@ -241,11 +314,20 @@ class JointTrainer:
             done = self._perform_step_fused(key, inputs, labels)
             if done is not None:
                 return done
+        self._hand_over("autograd")
         self.optimizer.zero_grad()
         with self.bank.manager(self.wrapper.prior_module, key):
             out = self.wrapper(*inputs)
             loss = self.criterion(out, labels, _input=list(inputs)) if self.forward_additional_loss_args else self.criterion(out, labels)
+            self.failed |= ~torch.isfinite(loss.detach())
+            if self.check_finite == "step":
+                self.raise_if_failed()
             loss.backward()
             self.optimizer.step()
             self.wrapper.enforce_convexity()   # batch_processed hook (awesome_runner.py:294-297)
         return loss.detach(), out.detach()
+
+    def raise_if_failed(self) -> None:
+        """One host sync: the reference's `ValueError("Loss is nan or inf!")` (torch_agent.py:484-487), checked when the caller asks."""
+        if bool(self.failed):
+            raise ValueError("Loss is nan or inf!")

@@ -732,10 +732,11 @@ __device__ __forceinline__ void flow_update_body(const FlowUpdArgs& u, const int
     // from the unchanged parameters.  ONE source of truth with the ICNN update: the "frozen" flag it has written for step t
     // into the header's double buffer (hdr[6 + ((t + 1) & 1)], one launch earlier on this stream; `status` may be NULL) - or, when
     // that update runs in THIS launch (cdn_update_kernel), the same decision from the same numbers (frozen_in_launch).
-    const bool frozen = (u.mode == 0 && u.loss_slabs != nullptr)
-                            ? frozen_in_launch(u.loss_slabs, u.loss_wgs, u.loss_PS, u.lr_hdr, u.hdr_stride, u.t, img, tid)
-                            : ((u.lr_hdr != nullptr && u.lr_hdr[(size_t)img * u.hdr_stride + 6 + ((u.t + 1) & 1)] != 0.f) ||
-                               (u.status != nullptr && u.status[img] != INR_STATUS_OK));
+    const bool frozen = !isfinite(gmul) ||    // the joint step's composite loss was not finite (joint_step_finish_kernel)
+                        ((u.mode == 0 && u.loss_slabs != nullptr)
+                             ? frozen_in_launch(u.loss_slabs, u.loss_wgs, u.loss_PS, u.lr_hdr, u.hdr_stride, u.t, img, tid)
+                             : ((u.lr_hdr != nullptr && u.lr_hdr[(size_t)img * u.hdr_stride + 6 + ((u.t + 1) & 1)] != 0.f) ||
+                                (u.status != nullptr && u.status[img] != INR_STATUS_OK)));
     const int mode = (u.mode == 0 && frozen) ? 2 : u.mode;
     const int W = m.W, K = m.K;
     float* __restrict__ fp = u.FP + (size_t)img * m.FP;

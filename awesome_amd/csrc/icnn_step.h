@@ -259,6 +259,13 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
+// log(x) clamped at -100 like torch.nn.BCELoss - with a compare + select, NOT fmaxf: fmaxf(NaN, -100) = -100 would turn a NaN
+// probability into a finite loss, while torch's clamp keeps the NaN and the reference then raises "Loss is nan or inf!".
+__device__ __forceinline__ float bce_log(float x) {
+    const float l = logf(x);
+    return l < -100.f ? -100.f : l;
+}
+
 __device__ __forceinline__ float sum_over_points(float v) {  // the 16 lanes sharing lane>>4 (one DPP row)
     v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
     v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
@@ -302,6 +309,20 @@ __device__ __forceinline__ float sum_over_groups(float v) {  // the 4 lanes shar
 #else
 #define MFMA_STEP_FENCE()
 #define OPERAND_FENCE()
+#endif
+
+// The backward product's k-steps as explicit pipelines (sched_group_barrier: MFMA, one LDS read, a few VALU instructions, repeated)
+// instead of the two fences: the VALU work that shares the product - the dy chain, the staging of the dW operands - is then spread
+// between the MFMAs instead of sitting in blocks (A/B in profiles/NOTES.md).
+#ifndef INR_BWD_SGB
+#define INR_BWD_SGB 0
+#endif
+#if INR_BWD_SGB
+#define BWD_OPERAND_FENCE()
+#define BWD_STEP_FENCE()
+#else
+#define BWD_OPERAND_FENCE() OPERAND_FENCE()
+#define BWD_STEP_FENCE() MFMA_STEP_FENCE()
 #endif
 
 // Diagnostic build only (-DINR_STAMPS=1): per-phase cycle sums of workgroup 0 / wave 0, read back by tools/stamps.py.
@@ -582,99 +603,113 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
         }
 
         STAMP(2);
-        // relu mask of layer 0 in the transposed layout of the backward product (rows = points): z0^T is the layer-0 product
-        // with swapped operands, TM more MFMAs - issued here, where the matrix pipe would otherwise idle under the VALU work
-        // of the output layer and the data term.
-        f32x4 z0p[TM];
-        if (TRAIN) {
-            float wie[TM];
-#pragma unroll
-            for (int t = 0; t < TM; ++t) wie[t] = WinE[g * PT + 16 * t + l15];
-            OPERAND_FENCE();
-#pragma unroll
-            for (int t = 0; t < TM; ++t) z0p[t] = MFMA16(xe, wie[t], (f32x4{0.f, 0.f, 0.f, 0.f}));
-            MFMA_STEP_FENCE();
-        }
-        // ---- output layer, sigmoid, data term ------------------------------------------------------------------
+        // ---- output layer: z1 = relu(.) in place, then - TRAIN - the backward product starts AT ONCE -----------------------------
+        // Everything behind the output layer is linear in dy = dL/dy of the point: dZ1 = dy (.) (m (.) w_o) with the relu mask m of z1,
+        // dZ0 = dZ1 W1, the layer-0 gradients and the coordinate gradient likewise.  The backward product therefore runs on the
+        // UNSCALED operand m (.) w_o (one select per k-step on the z1 registers) and dy joins at the very end (the 4 + C ext values of
+        // the layer-0 gradient product, the leftover units' sums, the DX output).  The dependent chain that produces dy - two cross-lane
+        // reductions, sigmoid, the data term: ~1.6 k cycles per chunk during which the matrix pipe used to idle - now sits in the
+        // shadow of the product's first k-steps; so do the relu / w_o dot product of tiles 1.. (tile 0 feeds k-steps 0-3).
+        // The staged operands of the dW product keep their arithmetic (dz1 = dy w_o m, computed once dy exists, tiles staged from
+        // k-step STAGE0 on); only dZ0's rounding changes: dy (sum_o m w_o W) instead of sum_o (dy m w_o) W.
         float ypart = 0.f;
-#pragma unroll
-        for (int t = 0; t < TM; ++t) {
+        auto relu_dot_tile = [&](int t) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 acc[t][r] = relu0(acc[t][r]);  // z1
                 ypart = fmaf(wo[t][r], acc[t][r], ypart);
             }
-        }
-        ypart = sum_over_groups(ypart);
-        float z1l[HRA];
+        };
+        float z1l[HRA], y = 0.f;
+        auto output_layer = [&]() {          // needs every tile's share of ypart
+            ypart = sum_over_groups(ypart);
 #pragma unroll
-        for (int u = 0; u < HR; ++u) {
-            z1l[u] = relu0(sum_over_groups(la[u]));
-            ypart = fmaf(wol[u], z1l[u], ypart);
-        }
-        float y = ypart + b_o;
+            for (int u = 0; u < HR; ++u) {
+                z1l[u] = relu0(sum_over_groups(la[u]));
+                ypart = fmaf(wol[u], z1l[u], ypart);
+            }
+            y = ypart + b_o;
 #pragma unroll
-        for (int c = 0; c < C; ++c) y = fmaf(s_o[c], x[c], y);
-        if (a.logits != nullptr && valid && g == 0) a.logits[(size_t)img * N + p] = y;
+            for (int c = 0; c < C; ++c) y = fmaf(s_o[c], x[c], y);
+        };
+        if (!TRAIN) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) relu_dot_tile(t);
+            output_layer();
+            if (a.logits != nullptr && valid && g == 0) a.logits[(size_t)img * N + p] = y;
+        }
 
         if (TRAIN) {
-            const float pr = 1.f / (1.f + expf(-y));
-            const float cw = tg < 0.5f ? cfg_ : cbg_;
-            float l, dy;
-            if (a.loss_kind == INR_LOSS_SE) {
-                const float d = tg - pr;
-                l = d * d * cw;
-                dy = 2.f * (pr - tg) * pr * (1.f - pr) * cw;
-            } else if (a.loss_kind == INR_LOSS_EXTERNAL) {
-                l = 0.f;
-                dy = tg;  // `targets` carries dL/dlogit
-            } else {
-                const float lp = fmaxf(logf(pr), -100.f), lq = fmaxf(logf(1.f - pr), -100.f);
-                l = -(tg * lp + (1.f - tg) * lq) * cw;
-                const float pq = pr * (1.f - pr);
-                dy = (pr - tg) / fmaxf(pq, 1e-12f) * pq * cw;
-            }
-            if (!valid) {
-                l = 0.f;
-                dy = 0.f;
-            }
-            float dzl[HRA];  // dz1 of the leftover units (same value in all 4 lane groups)
+            float dy = 0.f;
+            float mwl[HRA];  // m (.) w_o of the leftover units (same value in all 4 lane groups)
 #pragma unroll
-            for (int u = 0; u < HRA; ++u) dzl[u] = 0.f;
+            for (int u = 0; u < HRA; ++u) mwl[u] = 0.f;
+            // data term, in three pieces so that each fits the shadow of one k-step's MFMAs (INR_BWD_SGB: every k-step is its own
+            // scheduling region).  The criterion is a wave-uniform branch with a short SE arm.
+            float pr = 0.f, lterm = 0.f;
+            auto sigmoid_y = [&]() { pr = 1.f / (1.f + expf(-y)); };
+            auto data_term = [&]() {
+                const float cw = tg < 0.5f ? cfg_ : cbg_;
+                if (a.loss_kind == INR_LOSS_SE) {
+                    const float d = tg - pr;
+                    lterm = d * d * cw;
+                    dy = 2.f * (pr - tg) * pr * (1.f - pr) * cw;
+                } else if (a.loss_kind == INR_LOSS_EXTERNAL) {
+                    lterm = 0.f;
+                    dy = tg;  // `targets` carries dL/dlogit
+                } else {
+                    const float lp = bce_log(pr), lq = bce_log(1.f - pr);   // clamped at -100, NaN kept (torch.nn.BCELoss)
+                    lterm = -(tg * lp + (1.f - tg) * lq) * cw;
+                    const float pq = pr * (1.f - pr);
+                    dy = (pr - tg) / fmaxf(pq, 1e-12f) * pq * cw;
+                }
+                lterm = valid ? lterm : 0.f;
+                dy = valid ? dy : 0.f;
+            };
+            auto point_sums = [&]() {
 #pragma unroll
-            for (int u = 0; u < HR; ++u) dzl[u] = z1l[u] > 0.f ? dy * wol[u] : 0.f;
-            if (g == 0) {
-                loss_acc += l;
-                dbo += dy;
+                for (int u = 0; u < HR; ++u) mwl[u] = z1l[u] > 0.f ? wol[u] : 0.f;
+                const float dyg = g == 0 ? dy : 0.f, lg = g == 0 ? lterm : 0.f;   // per-point sums live in lane group 0
+                loss_acc += lg;
+                dbo += dyg;
 #pragma unroll
-                for (int c = 0; c < C; ++c) dso[c] = fmaf(dy, x[c], dso[c]);
+                for (int c = 0; c < C; ++c) dso[c] = fmaf(dyg, x[c], dso[c]);
 #pragma unroll
-                for (int u = 0; u < HR; ++u) dwol[u] = fmaf(dy, z1l[u], dwol[u]);
-            }
+                for (int u = 0; u < HR; ++u) dwol[u] = fmaf(dyg, z1l[u], dwol[u]);
+            };
             const int pl = wave * 16 + l15;  // this lane's row in the stages
             float* const sa = stA + pl * G::SA + 4 * g;
             float* const sb = stB + pl * G::SB + 4 * g;
-            // dz1 of tile t (in place over acc), dw_o accumulation, staging of dz1 (A) and z0ext (B)
+            constexpr int DY_COL = 10;       // free slot of k-group TM's 16 positions (ext inputs end at 9): this point's dy, read back by rows
+            static_assert(G::ext_pos(NEXT - 1) - HM < DY_COL && DY_COL < 12, "dy column must be a free, staged slot");
+            // stores of a subset of the lanes go to a dummy slot instead of under a branch (same reason as above)
+            float* const dummyA = stA + SP * G::SA, * const dummyB = stB + SP * G::SB;   // the 16 pad floats behind each stage
+            auto stage_rest = [&]() {        // leftover units' dz1 (A), k-group TM's z0 + dy (B)
+                if (HR > 0) {
+                    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < HR; ++u) v[u] = dy * mwl[u];
+                    *(f32x4*)(g == 0 ? sa + HM : dummyA) = v;
+                }
+                f32x4 zb = z0[TM];
+                zb[DY_COL & 3] = (g == (DY_COL >> 2)) ? dy : zb[DY_COL & 3];
+                *(f32x4*)(g < 3 ? sb + HM : dummyB) = zb;
+            };
+            // dz1 of tile t, dw_o accumulation, staging of dz1 (A) and z0ext (B)
             auto dz1_tile = [&](int t) {
+                f32x4 dz;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float z1 = acc[t][r];
                     dwo[t][r] = fmaf(dy, z1, dwo[t][r]);
-                    acc[t][r] = z1 > 0.f ? dy * wo[t][r] : 0.f;
+                    dz[r] = z1 > 0.f ? dy * wo[t][r] : 0.f;
                 }
-                *(f32x4*)(sa + 16 * t) = acc[t];
+                *(f32x4*)(sa + 16 * t) = dz;
                 *(f32x4*)(sb + 16 * t) = z0[t];
             };
-            if (HR > 0 && g == 0) {
-                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int u = 0; u < HR; ++u) v[u] = dzl[u];
-                *(f32x4*)(sa + HM) = v;
-            }
-            if (g < 3) *(f32x4*)(sb + HM) = z0[TM];
 
             STAMP(3);
-            // ---- backward through layer 1 (MFMA, pipelined): dZ0 = dZ1 . W1 ----------------------------------------
+            // ---- backward through layer 1 (MFMA, pipelined): U = (m (.) w_o) . W1, dZ0 = dy (.) U ------------------------------
             // Operands swapped w.r.t. the forward product (same registers): the D tile comes out transposed - rows =
             // this wave's points 4g+r, columns = hidden unit 16t + l15 - which is the A operand of the layer-0
             // gradient product dW_in = dZ0^T . (1, x), so that product needs no staging and no barrier.
@@ -685,6 +720,11 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
 #pragma unroll
             for (int u = 0; u < HRA; ++u) dz0l[u] = 0.f;
             constexpr int KS = 4 * TM + HR;  // k-steps over the hidden outputs
+            // where the pieces of the dy chain sit in the stream of k-steps (every one is VALU / LDS-write work in the shadow of TM MFMAs)
+            constexpr int KS_OUT = TM >= 8 ? 4 : (TM > 1 ? 1 : 0), KS_DATA = KS_OUT + 2, STAGE0 = KS_DATA + 3;
+            constexpr int TPK = KS_OUT > 0 ? (TM - 1 + KS_OUT - 1) / KS_OUT : 0;   // output-layer tiles per k-step in front of KS_OUT
+            constexpr int STAGE_EVERY = (KS - 2 - STAGE0) / TM > 0 ? (KS - 2 - STAGE0) / TM : 1;
+            static_assert(TM == 1 || STAGE0 + STAGE_EVERY * (TM - 1) < KS, "every tile must be staged inside the k-step loop");
             float bq[2][TM];      // B operands (weights): row o of this k-step, columns 16t + l15
             f32x4 wcq[2][HRA];    // leftover input columns W1[o][HM+u] at this lane's positions of a tile
             auto b_row = [&](int ks) -> const float* {  // LDS row of the weight operand for k-step ks
@@ -692,7 +732,6 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 if (tk < TM) return wb + (16 * tk + 4 * g + r) * S;
                 return wb + (g == 0 ? (HM + r) * S : 0);  // leftover outputs live in lane group 0 (others: A = 0)
             };
-            dz1_tile(0);
             {
                 const float* br = b_row(0);
 #pragma unroll
@@ -701,6 +740,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
 #pragma unroll
                 for (int u = 0; u < HR; ++u) wcq[0][u] = *(const f32x4*)(WcT + u * PT + 4 * g);
             }
+            if (TM > 1) relu_dot_tile(0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int tk = ks >> 2, r = ks & 3;
@@ -712,33 +752,74 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
 #pragma unroll
                     for (int u = 0; u < HR; ++u) wcq[(tk + 1) & 1][u] = *(const f32x4*)(WcT + u * PT + 16 * (tk + 1) + 4 * g);
                 }
-                OPERAND_FENCE();
-                const float bop = tk < TM ? acc[tk < TM ? tk : 0][r] : (g == 0 ? dzl[r < HRA ? r : 0] : 0.f);
+                BWD_OPERAND_FENCE();
+                const float bop = tk < TM ? (acc[tk < TM ? tk : 0][r] > 0.f ? wo[tk < TM ? tk : 0][r] : 0.f)
+                                          : (g == 0 ? mwl[r < HRA ? r : 0] : 0.f);
 #pragma unroll
-                for (int t = 0; t < TM; ++t) {  // D = dZ0 with POINTS on the rows; next k-step's operand reads one per product
+                for (int t = 0; t < TM; ++t) {  // D = U with POINTS on the rows; next k-step's operand reads one per product
                     dz0[t] = MFMA16(bop, bq[ks & 1][t], ks == 0 ? (f32x4{0.f, 0.f, 0.f, 0.f}) : dz0[t]);
                     if (ks + 1 < KS) bq[(ks + 1) & 1][t] = b_row(ks + 1)[16 * t];
-                    OPERAND_FENCE();
+                    BWD_OPERAND_FENCE();
                 }
                 if (DX) dzx = MFMA16(bop, bqx[ks & 1], dzx);
-                MFMA_STEP_FENCE();
-                if (r == 1 && tk + 1 < TM) dz1_tile(tk + 1);  // next tile's dz1 + staging, in the shadow of the MFMAs
-                // leftover hidden inputs: dz0l[u] += W1[:, HM+u] . dz1 - this k-step's share (HR FMAs per MFMA block, not 4 HR
-                // in one gap every fourth block)
+                BWD_STEP_FENCE();
+                // in the shadow of these MFMAs: the output layer's remaining tiles (one per k-step), then the dy chain, then the staging
+                if (ks < KS_OUT) {
 #pragma unroll
-                for (int u = 0; u < HR; ++u) {
-                    if (tk < TM) dz0l[u] = fmaf(wcq[tk & 1][u][r], acc[tk < TM ? tk : 0][r], dz0l[u]);
-                    else if (g == 0) dz0l[u] = fmaf(wcq[tk & 1][u][r], dzl[r < HRA ? r : 0], dz0l[u]);
+                    for (int t = 1 + ks * TPK; t < 1 + (ks + 1) * TPK; ++t)
+                        if (t < TM) relu_dot_tile(t);
                 }
-                MFMA_STEP_FENCE();
-            }
-            STAMP(4);
-            // relu mask of layer 0 (z0p, computed before the output layer); then dL0[t] += dZ0[:, tile t]^T . ext columns of
-            // this wave's own stage-B rows.
-            {
-                float bfe[4];
+                if (ks == KS_OUT) output_layer();
+                if (ks == KS_OUT + 1) sigmoid_y();
+                if (ks == KS_DATA) data_term();
+                if (ks == KS_DATA + 1) point_sums();
+                if (ks == KS_DATA + 2) stage_rest();
+                if (ks >= STAGE0 && (ks - STAGE0) % STAGE_EVERY == 0 && (ks - STAGE0) / STAGE_EVERY < TM) dz1_tile((ks - STAGE0) / STAGE_EVERY);
+                // leftover hidden inputs: dz0l[u] += W1[:, HM+u] . (m w_o) - this k-step's share (HR FMAs per MFMA block)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bfe[r] = stB[(wave * 16 + 4 * g + r) * G::SB + HM + l15];
+                for (int u = 0; u < HR; ++u) dz0l[u] = fmaf(wcq[tk & 1][u][r], bop, dz0l[u]);
+#if INR_BWD_SGB
+                // this k-step as a pipeline: after every product one operand read of the next k-step and (at most) three VALU
+                // instructions of whatever shares the k-step - the select of the next operand, a piece of the dy chain, a staged tile
+#pragma unroll
+                for (int t = 0; t < TM + (DX ? 1 : 0); ++t) {
+                    SGB(SG_MFMA, 1);
+                    SGB(SG_DS_READ, 1);
+                    SGB(SG_VALU, 3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#else
+                MFMA_STEP_FENCE();
+#endif
+            }
+            if (TM == 1) {   // (degenerate shapes: nothing was interleaved)
+                relu_dot_tile(0);
+                output_layer();
+                sigmoid_y();
+                data_term();
+                point_sums();
+                stage_rest();
+                dz1_tile(0);
+            }
+            if (a.logits != nullptr && valid && g == 0) a.logits[(size_t)img * N + p] = y;
+            STAMP(4);
+            // relu mask of layer 0 in the transposed layout of this product (rows = points): z0^T is the layer-0 product with swapped
+            // operands, TM more MFMAs; then dL0[t] += (mask (.) U[:, tile t])^T . (dy (.) ext columns of this wave's own stage-B rows).
+            f32x4 z0p[TM];
+            {
+                float wie[TM];
+#pragma unroll
+                for (int t = 0; t < TM; ++t) wie[t] = WinE[g * PT + 16 * t + l15];
+                float bfe[4], dyr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    bfe[r] = stB[(wave * 16 + 4 * g + r) * G::SB + HM + l15];
+                    dyr[r] = stB[(wave * 16 + 4 * g + r) * G::SB + HM + DY_COL];   // dy of point 4g + r (a broadcast read)
+                }
+                OPERAND_FENCE();
+#pragma unroll
+                for (int t = 0; t < TM; ++t) z0p[t] = MFMA16(xe, wie[t], (f32x4{0.f, 0.f, 0.f, 0.f}));
+                MFMA_STEP_FENCE();
 #pragma unroll
                 for (int t = 0; t < TM; ++t)
 #pragma unroll
@@ -748,9 +829,18 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                     }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    const float be = bfe[r] * dyr[r];
 #pragma unroll
-                    for (int t = 0; t < TM; ++t) dL0[t] = MFMA16(dz0[t][r], bfe[r], dL0[t]);
+                    for (int t = 0; t < TM; ++t) dL0[t] = MFMA16(dz0[t][r], be, dL0[t]);
                     MFMA_STEP_FENCE();
+                }
+                if (DX) {   // the coordinate gradient needs dZ0 itself
+#pragma unroll
+                    for (int t = 0; t < TM; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dz0[t][r] *= dyr[r];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dzx[r] *= dyr[r];
                 }
             }
             // leftover rows of the layer-0 gradient (lane group 0, VALU)
@@ -759,7 +849,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
             for (int c = 0; c < C; ++c) hx[c] = s_o[c] * dy;
 #pragma unroll
             for (int u = 0; u < HR; ++u) {
-                const float d = sum_over_groups(dz0l[u]);
+                const float d = sum_over_groups(dz0l[u]) * dy;
                 // position HM + u lives in lane group 0, k-step u (DX needs it in every lane group)
                 const float z0u = DX ? __shfl(z0[TM][u], l15) : z0[TM][u];
                 float dm;

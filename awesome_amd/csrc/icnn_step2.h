@@ -470,7 +470,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn2_step_kernel(const StepArg
                 l = 0.f;
                 dy = tg;
             } else {
-                const float lp = fmaxf(logf(pr), -100.f), lq = fmaxf(logf(1.f - pr), -100.f);
+                const float lp = bce_log(pr), lq = bce_log(1.f - pr);   // clamped at -100, NaN kept (torch.nn.BCELoss)
                 l = -(tg * lp + (1.f - tg) * lq) * cw;
                 const float pq = pr * (1.f - pr);
                 dy = (pr - tg) / fmaxf(pq, 1e-12f) * pq * cw;

@@ -200,7 +200,7 @@ __device__ __forceinline__ void icnn_update_body(const UpdArgs& u, const int bx,
     float loss_now = 0.f;
 #pragma unroll
     for (int k = 0; k < UPD_GROUPS; ++k) loss_now += redl[k];
-    const bool frozen = bad_before || !isfinite(loss_now);
+    const bool frozen = bad_before || !isfinite(loss_now) || (u.gscale != nullptr && !isfinite(u.gscale[img]));
     if (j == u.P) {
         // loss bookkeeping + ReduceLROnPlateau (torch semantics, mode 'min', relative threshold)
         const float loss = gsum;
@@ -1995,6 +1995,7 @@ static int check_joint_desc(const InrJointLossDesc* d) {
     if (d->kind != INR_LOSS_SE && d->kind != INR_LOSS_BCE) return INR_EINVAL;
     if (d->weight_mode < INR_WEIGHT_NONE || d->weight_mode > INR_WEIGHT_SSSDMS) return INR_EINVAL;
     if (d->form < INR_JOINT_FBMS || d->form > INR_JOINT_AWESOME_PIXEL) return INR_EINVAL;
+    if (d->target_rule != 0 && d->target_rule != 1) return INR_EINVAL;
     if (d->form == INR_JOINT_AWESOME_IMAGE) {
         if (d->prior_kind != INR_LOSS_SE && d->prior_kind != INR_LOSS_BCE) return INR_EINVAL;
         if (d->prior_weight_mode < INR_WEIGHT_NONE || d->prior_weight_mode > INR_WEIGHT_SSSDMS) return INR_EINVAL;
@@ -2084,13 +2085,14 @@ struct JointFinArgs {
 __global__ __launch_bounds__(256) void joint_step_finish_kernel(const JointFinArgs f) {
     __shared__ float sm[4];
     const JointLossArgs& a = f.jl;
-    float v[3] = {0.f, 0.f, 0.f};
+    constexpr int SLOT[5] = {0, 1, 2, 6, 7};   // seg loss over fg / the rest, fg count, valid pixels, bg count
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     for (int b = threadIdx.x; b < a.blocks; b += 256)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) v[k] += a.part[JL_PART * b + k];
-    float tot[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 5; ++k) v[k] += a.part[JL_PART * b + SLOT[k]];
+    float tot[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) tot[k] = jl_block_sum(v[k], sm);
+    for (int k = 0; k < 5; ++k) tot[SLOT[k]] = jl_block_sum(v[k], sm);
     float lc = 0.f;   // the prior's share, as the step kernel summed it: FBMS mean((prior - seg)^2); AWESOME_IMAGE mean(w' pcrit)
     for (int w = threadIdx.x; w < f.wgs; w += 256) lc += f.slabs[(size_t)w * f.PS + f.loss_col];
     const float prior_term = jl_block_sum(lc, sm);
@@ -2100,8 +2102,8 @@ __global__ __launch_bounds__(256) void joint_step_finish_kernel(const JointFinAr
         jl_finish(a, tot, prior_term * (float)a.total);     // jl_finish divides the penalty sum by n again
         gs = a.res[3] * a.d.beta;                           // d penalty / d theta = clip * beta * d mean((p - s)^2) / d theta
     } else {
-        const float nd = (float)a.total, nfg = tot[2];
-        const float w = jl_class_weight(a.d.weight_mode, a.d.ratio, nfg, nd - nfg);
+        const float nd = tot[6], nfg = tot[2];
+        const float w = jl_class_weight(a.d.weight_mode, a.d.ratio, nfg, tot[7]);
         const float seg_raw = (w * tot[0] + tot[1]) / nd;
         a.res[0] = seg_raw + a.d.alpha * prior_term;
         a.res[1] = seg_raw;
@@ -2113,7 +2115,9 @@ __global__ __launch_bounds__(256) void joint_step_finish_kernel(const JointFinAr
         a.res[7] = nfg;
         gs = a.d.alpha;
     }
-    f.gscale[0] = gs;
+    // a non-finite COMPOSITE loss freezes the row: the update kernels read a non-finite gradient scale as "no step" (a NaN in
+    // `seg` does not reach the prior's own loss column in the AWESOME_IMAGE form)
+    f.gscale[0] = isfinite(a.res[0]) ? gs : __builtin_nanf("");
     if (f.loss_out) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) f.loss_out[k] = a.res[k];
@@ -2136,6 +2140,8 @@ int joint_begin(const InrJointLossDesc* desc, const InrOptDesc* opt, const float
     if (!opt || (opt->kind != INR_OPT_ADAM && opt->kind != INR_OPT_ADAMAX) || step < 1) return INR_EINVAL;
     if (desc->form == INR_JOINT_AWESOME_PIXEL) return INR_EUNSUPPORTED;            // pixel mode has no dense-grid prior pass
     if (desc->form == INR_JOINT_AWESOME_IMAGE && desc->extra_penalty) return INR_EUNSUPPORTED;   // two data terms on the prior
+    // the AWESOME_IMAGE prior term runs inside the step kernel, which reads unaries (fg < 0.5) and has no pixel mask
+    if (desc->form == INR_JOINT_AWESOME_IMAGE && (desc->target_rule != 0 || desc->use_noneclass)) return INR_EUNSUPPORTED;
     // seg-side sums over the single image: output = seg (channel stride unused), PRIOR = false
     if ((rc = make_joint_args(seg, target, 1, N, desc, nullptr, jws, &c->jl))) return rc;
     c->gscale = c->jl.res + JL_RES;

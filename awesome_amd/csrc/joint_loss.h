@@ -13,7 +13,8 @@
 //       extra_penalty and n > n_scribble:  loss = gamma * loss + beta * mean((prior_r - (seg_r > 0.5))^2) over pixels [n - n_scribble, n)
 //       (the reference slices [random:] with random = n - n_scribble, awesome_loss.py:58-59; gamma = 0.1, beta = 100 are its constants)
 //   crit / pcrit = BCELoss | SE, w = UnariesWeightedLoss._compute_weight (awesome/measures/unaries_weighted_loss.py:35-69; fg/bg counts
-//   over the whole batch of targets).
+//   over the whole batch of targets) or WeightedLoss._compute_weight on class labels (weighted_loss.py:38-62, target_rule 1), after
+//   the `noneclass` pixels have left the data terms (weighted_loss.py:71-74).
 //
 // The reference decides FBMS's clip on the host (one device -> host sync per training step) and runs ~15 elementwise torch kernels
 // for value + autograd.  Here: three launches, no sync - partial sums per block, one block that combines them in fixed order and
@@ -32,7 +33,8 @@ struct JointLossArgs {
     const float* output;   // image forms: [B][2][n]; pixel form: [B][n][2]
     const float* target;   // [B][n_data]
     float* doutput;        // like output, or null
-    float* part;           // [blocks][JL_PART]: seg loss over fg, over bg, fg count, penalty, prior loss over fg, over bg
+    float* part;           // [blocks][JL_PART]: seg loss over fg, over the rest, fg count, penalty, prior loss over fg, over the rest,
+                           //                    valid pixels (not noneclass), bg count
     float* res;            // [JL_RES], see joint_loss_finish_kernel
     long long n;           // pixels per batch item
     long long n_data;      // leading pixels of a batch item that carry the data terms (n for the image forms)
@@ -49,7 +51,7 @@ __device__ __forceinline__ float jl_crit(int kind, float x, float t) {
         const float d = t - x;
         return d * d;
     }
-    return -(t * fmaxf(logf(x), -100.f) + (1.f - t) * fmaxf(logf(1.f - x), -100.f));   // torch.nn.BCELoss (log clamped at -100)
+    return -(t * bce_log(x) + (1.f - t) * bce_log(1.f - x));   // torch.nn.BCELoss (log clamped at -100, a NaN stays a NaN)
 }
 __device__ __forceinline__ float jl_dcrit(int kind, float x, float t) {
     if (kind == INR_LOSS_SE) return 2.f * (x - t);
@@ -62,6 +64,10 @@ __device__ __forceinline__ float jl_class_weight(int mode, float ratio, float nf
     if (mode == INR_WEIGHT_RATIO) return (cc - 1.f) * ratio + 1.f;
     return rintf(cc / 10.f) + 1.f;   // sssdms (torch.round: half to even)
 }
+
+// which pixels the class weight applies to / which count as background for the ratio (InrJointLossDesc.target_rule)
+__device__ __forceinline__ bool jl_is_fg(int rule, float t) { return rule ? t == 0.f : t < 0.5f; }
+__device__ __forceinline__ bool jl_is_bg(int rule, float t) { return rule ? t == 1.f : t >= 0.5f; }
 
 __device__ __forceinline__ float jl_block_sum(float v, float* sm) {   // 256 threads, fixed order
     v = sum_over_groups(sum_over_points(v));
@@ -76,7 +82,7 @@ __device__ __forceinline__ float jl_block_sum(float v, float* sm) {   // 256 thr
 template <bool PRIOR>
 __global__ __launch_bounds__(256) void joint_loss_partial_kernel(const JointLossArgs a) {
     __shared__ float sm[4];
-    float lfg = 0.f, lbg = 0.f, nfg = 0.f, pen = 0.f, pfg = 0.f, pbg = 0.f;
+    float lfg = 0.f, lbg = 0.f, nfg = 0.f, pen = 0.f, pfg = 0.f, pbg = 0.f, nval = 0.f, nbg = 0.f;
     const bool fbms = a.d.form == INR_JOINT_FBMS;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < a.total; e += (long long)a.blocks * 256) {
         const long long b = e / a.n, i = e - b * a.n;
@@ -84,15 +90,19 @@ __global__ __launch_bounds__(256) void joint_loss_partial_kernel(const JointLoss
         const float p = PRIOR ? a.output[b * a.bs + i * a.es + a.cs] : 0.f;
         if (i < a.n_data) {
             const float t = a.target[b * a.n_data + i];
-            const float l = jl_crit(a.d.kind, s, t);
-            const float lp = (PRIOR && !fbms) ? jl_crit(a.d.prior_kind, p, t) : 0.f;
-            if (t < 0.5f) {
-                lfg += l;
-                pfg += lp;
-                nfg += 1.f;
-            } else {
-                lbg += l;
-                pbg += lp;
+            if (!(a.d.use_noneclass && t == a.d.noneclass)) {
+                const float l = jl_crit(a.d.kind, s, t);
+                const float lp = (PRIOR && !fbms) ? jl_crit(a.d.prior_kind, p, t) : 0.f;
+                nval += 1.f;
+                if (jl_is_fg(a.d.target_rule, t)) {
+                    lfg += l;
+                    pfg += lp;
+                    nfg += 1.f;
+                } else {
+                    lbg += l;
+                    pbg += lp;
+                    if (jl_is_bg(a.d.target_rule, t)) nbg += 1.f;
+                }
             }
         }
         if (PRIOR && a.pen_on && i >= a.pen_lo) {
@@ -101,19 +111,20 @@ __global__ __launch_bounds__(256) void joint_loss_partial_kernel(const JointLoss
         }
     }
     const float r0 = jl_block_sum(lfg, sm), r1 = jl_block_sum(lbg, sm), r2 = jl_block_sum(nfg, sm), r3 = jl_block_sum(pen, sm);
-    const float r4 = jl_block_sum(pfg, sm), r5 = jl_block_sum(pbg, sm);
+    const float r4 = jl_block_sum(pfg, sm), r5 = jl_block_sum(pbg, sm), r6 = jl_block_sum(nval, sm), r7 = jl_block_sum(nbg, sm);
     if (threadIdx.x == 0) {
         float* o = a.part + JL_PART * blockIdx.x;
-        o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3; o[4] = r4; o[5] = r5;
+        o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3; o[4] = r4; o[5] = r5; o[6] = r6; o[7] = r7;
     }
 }
 
 // res: [0] loss, [1] mean weighted crit(seg) (before alpha / gamma), [2] mean penalty (before beta), [3] FBMS clip factor,
 //      [4] [5] d loss / d crit(seg_i) for a foreground / background pixel, [6] coefficient of the penalty gradient,
 //      [7] fg count, [8] [9] d loss / d pcrit(prior_i) fg / bg, [10] mean weighted pcrit(prior) (before alpha)
-__device__ __forceinline__ void jl_finish(const JointLossArgs& a, const float (&tot)[6], float pen_sum) {
-    const float nd = (float)((long long)a.batch * a.n_data), npen = (float)((long long)a.batch * (a.n - a.pen_lo));
-    const float nfg = tot[2], nbg = nd - nfg;
+//      tot: [0..5] as `part`, [6] valid pixels, [7] bg count
+__device__ __forceinline__ void jl_finish(const JointLossArgs& a, const float (&tot)[8], float pen_sum) {
+    const float nd = tot[6], npen = (float)((long long)a.batch * (a.n - a.pen_lo));
+    const float nfg = tot[2], nbg = tot[7];
     const float w = jl_class_weight(a.d.weight_mode, a.d.ratio, nfg, nbg);
     const float seg_raw = (w * tot[0] + tot[1]) / nd;
     const float pen_raw = a.pen_on ? pen_sum / npen : 0.f;
@@ -155,13 +166,13 @@ __device__ __forceinline__ void jl_finish(const JointLossArgs& a, const float (&
 
 __global__ __launch_bounds__(256) void joint_loss_finish_kernel(const JointLossArgs a) {
     __shared__ float sm[4];
-    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int b = threadIdx.x; b < a.blocks; b += 256)
 #pragma unroll
-        for (int k = 0; k < 6; ++k) v[k] += a.part[JL_PART * b + k];
-    float tot[6];
+        for (int k = 0; k < 8; ++k) v[k] += a.part[JL_PART * b + k];
+    float tot[8];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) tot[k] = jl_block_sum(v[k], sm);
+    for (int k = 0; k < 8; ++k) tot[k] = jl_block_sum(v[k], sm);
     if (threadIdx.x != 0) return;
     jl_finish(a, tot, tot[3]);
 }
@@ -179,8 +190,11 @@ __global__ __launch_bounds__(256) void joint_loss_grad_kernel(const JointLossArg
         float gs = 0.f, gp = 0.f;
         if (i < a.n_data) {
             const float t = a.target[b * a.n_data + i];
-            gs = (t < 0.5f ? cfg : cbg) * jl_dcrit(a.d.kind, s, t);
-            if (!fbms && !SEG_ONLY) gp = (t < 0.5f ? pfg : pbg) * jl_dcrit(a.d.prior_kind, p, t);
+            if (!(a.d.use_noneclass && t == a.d.noneclass)) {
+                const bool fg = jl_is_fg(a.d.target_rule, t);
+                gs = (fg ? cfg : cbg) * jl_dcrit(a.d.kind, s, t);
+                if (!fbms && !SEG_ONLY) gp = (fg ? pfg : pbg) * jl_dcrit(a.d.prior_kind, p, t);
+            }
         }
         if (a.pen_on && i >= a.pen_lo) {
             if (fbms) {

@@ -995,10 +995,11 @@ __device__ __forceinline__ void rnvp_update_body(const RnvpUpdArgs& u, const int
     const int F = m.F, HID = m.HID;
     // one source of truth with the ICNN update: the flag it has written for step t (hdr[6 + ((t + 1) & 1)]; `status` may be NULL) -
     // or, when that update runs in THIS launch (pcn_update_kernel), the same decision from the same numbers (frozen_in_launch)
-    const bool frozen = u.loss_slabs != nullptr
-                            ? frozen_in_launch(u.loss_slabs, u.loss_wgs, u.loss_PS, u.lr_hdr, u.hdr_stride, u.t, img, tid)
-                            : ((u.lr_hdr != nullptr && u.lr_hdr[(size_t)img * u.hdr_stride + 6 + ((u.t + 1) & 1)] != 0.f) ||
-                               (u.status != nullptr && u.status[img] != INR_STATUS_OK));
+    const bool frozen = !isfinite(gmul) ||    // the joint step's composite loss was not finite (joint_step_finish_kernel)
+                        (u.loss_slabs != nullptr
+                             ? frozen_in_launch(u.loss_slabs, u.loss_wgs, u.loss_PS, u.lr_hdr, u.hdr_stride, u.t, img, tid)
+                             : ((u.lr_hdr != nullptr && u.lr_hdr[(size_t)img * u.hdr_stride + 6 + ((u.t + 1) & 1)] != 0.f) ||
+                                (u.status != nullptr && u.status[img] != INR_STATUS_OK)));
     float* __restrict__ rp = u.RP + (size_t)img * m.RP;
     float* __restrict__ om = u.opt ? u.opt + (size_t)img * 2 * m.RP : nullptr;
     float* __restrict__ ov = om ? om + m.RP : nullptr;

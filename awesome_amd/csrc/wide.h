@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void wide_out_kernel(const WideOutArgs a) {
                     l = d * d * cw;
                     dy = 2.f * (pr - tg) * pr * (1.f - pr) * cw;
                 } else {
-                    const float lp = fmaxf(logf(pr), -100.f), lq = fmaxf(logf(1.f - pr), -100.f);
+                    const float lp = bce_log(pr), lq = bce_log(1.f - pr);   // clamped at -100, NaN kept (torch.nn.BCELoss)
                     l = -(tg * lp + (1.f - tg) * lq) * cw;
                     const float pq = pr * (1.f - pr);
                     dy = (pr - tg) / fmaxf(pq, 1e-12f) * pq * cw;

@@ -15,7 +15,7 @@ from typing import Callable, Dict, List, Optional, Sequence
 import torch
 
 from . import icnn as K
-from .measures import criterion_to_desc
+from .measures import criterion_targets, criterion_to_desc
 
 
 class NonFiniteLossError(ValueError):
@@ -58,7 +58,8 @@ class BatchedPriorFitter:
         if criterion is None:
             self.loss_kind, self.weight_mode, self.ratio = "se", "none", 1.0
         else:
-            self.loss_kind, self.weight_mode, self.ratio = criterion_to_desc(criterion)
+            self.loss_kind, self.weight_mode, self.ratio = criterion_to_desc(criterion, "targets")   # _run converts the targets
+        self.criterion = criterion
         probe = model_factory()
         self.spec: K.IcnnSpec = probe.spec
         self._convexnet_keys = hasattr(probe, "W0y")
@@ -70,6 +71,7 @@ class BatchedPriorFitter:
         return torch.stack([self.model_factory().flat_parameters() for _ in range(n)]).to(device)
 
     def _run(self, params, grid, unaries, epochs):
+        unaries = criterion_targets(self.criterion, unaries).contiguous()      # UnariesConversionLoss: binarised targets
         return K.fit(self.spec, params, grid, unaries, epochs, lr=self.lr, loss=self.loss_kind, weight_mode=self.weight_mode,
                      ratio=self.ratio, optimizer=self.optimizer, betas=self.betas, eps=self.eps,
                      weight_decay=self.weight_decay, plateau=self.plateau, record_loss=True, want_logits=True, **self._fit_options)

@@ -58,6 +58,11 @@ class IcnnSpec:
         """Weights projected onto >= 0 by enforce_convexity (convex_net.py:151-154, 216-220)."""
         return [f"skip.{k}.ln.weight" for k in range(self.n_layers)] + ["out.ln.weight"]
 
+    def fused(self) -> bool:
+        """A fused MFMA step kernel serves this shape (n_hidden <= 130, L <= 2; other widths zero-padded) - what the composite
+        priors and the fused joint step need; wider / deeper nets run layer by layer (csrc/wide.h) through inrfit_fit etc. only."""
+        return self.supported() and self.n_hidden <= 130 and self.n_layers <= 2
+
     def supported(self) -> bool:
         d = self.desc()
         return bool(L.load().inrfit_supported(C.byref(d)))

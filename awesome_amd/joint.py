@@ -28,10 +28,12 @@ class JointStepResult:
 
 def joint_desc(kind: str = "bce", weight_mode: str = "sssdms", ratio: float = 1.0, alpha: float = 1.0, beta: float = 1.0,
                clip_penalty: bool = True, form: int = L.JOINT_FBMS, prior_kind: str = "bce", prior_weight_mode: str = "none",
-               prior_ratio: float = 1.0, gamma: float = 1.0, extra_penalty: bool = False, n_scribble: int = 0) -> L.InrJointLossDesc:
+               prior_ratio: float = 1.0, gamma: float = 1.0, extra_penalty: bool = False, n_scribble: int = 0,
+               class_targets: bool = False, noneclass=None) -> L.InrJointLossDesc:
     return L.InrJointLossDesc(L.LOSS_KINDS[kind], L.WEIGHT_MODES[weight_mode], float(ratio), float(alpha), float(beta),
                               int(bool(clip_penalty)), int(form), L.LOSS_KINDS[prior_kind], L.WEIGHT_MODES[prior_weight_mode],
-                              float(prior_ratio), float(gamma), int(bool(extra_penalty)), int(n_scribble))
+                              float(prior_ratio), float(gamma), int(bool(extra_penalty)), int(n_scribble),
+                              int(bool(class_targets)), int(noneclass is not None), float(noneclass if noneclass is not None else 0.0))
 
 
 def _opt_desc(optimizer: str, lr: float, betas, eps: float, weight_decay: float, clamp: bool) -> L.InrOptDesc:

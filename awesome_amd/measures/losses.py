@@ -150,6 +150,33 @@ class MIOU:
         return self.name or "MIOU"
 
 
+def joint_criterion_form(criterion):
+    """How the composite losses' kernels (csrc/joint_loss.h) evaluate `criterion`:
+    (loss kind, weight mode, ratio, class_targets, noneclass) - or TypeError if it has no kernel form.  Unlike the per-image fits
+    (`criterion_to_desc`) these kernels know WeightedLoss on class labels (fg = target == 0, bg = target == 1) and the `noneclass`
+    mask (weighted_loss.py:38-74); a UnariesConversionLoss would need its targets binarised first and is refused."""
+    mode, ratio, inner, class_targets, noneclass = "none", 1.0, criterion, False, None
+    if isinstance(criterion, UnariesConversionLoss):
+        raise TypeError("UnariesConversionLoss binarises its targets; the composite losses' kernels read them as they are")
+    if isinstance(criterion, WeightedLoss):
+        if criterion.reduction != "mean" or criterion.reduction_dim is not None or criterion.forward_kwargs_criterion:
+            raise TypeError("only reduction='mean' over all pixels has a kernel form")
+        mode, ratio, inner = criterion.mode, getattr(criterion, "ratio", 1.0), criterion.criterion
+        class_targets = not isinstance(criterion, UnariesWeightedLoss)
+        noneclass = None if criterion.noneclass is None else float(criterion.noneclass)
+    elif getattr(inner, "reduction", "mean") != "mean":
+        raise TypeError("only reduction='mean' has a kernel form")
+    if isinstance(inner, SE) and inner.reduction_dim is None:
+        return "se", mode, ratio, class_targets, noneclass
+    if isinstance(inner, torch.nn.BCELoss) and inner.weight is None:
+        return "bce", mode, ratio, class_targets, noneclass
+    raise TypeError(f"{type(criterion).__name__} has no kernel form (supported: SE, BCELoss, WeightedLoss / UnariesWeightedLoss of those)")
+
+
+def _target_fields(class_targets: bool, noneclass):
+    return int(bool(class_targets)), int(noneclass is not None), float(noneclass if noneclass is not None else 0.0)
+
+
 class AwesomeImageLoss:
     """awesome/measures/awesome_image_loss.py:34-53: crit(seg,t) + alpha*crit(prior,t) [+ penalty].
 
@@ -167,18 +194,15 @@ class AwesomeImageLoss:
         """InrJointLossDesc of this loss, or None if a criterion has no kernel form."""
         from .. import _lib as L
         try:
-            kind, mode, ratio = criterion_to_desc(self.criterion)
-            pkind, pmode, pratio = criterion_to_desc(self.prior_criterion)
+            kind, mode, ratio, ct, nc = joint_criterion_form(self.criterion)
+            pkind, pmode, pratio, pct, pnc = joint_criterion_form(self.prior_criterion)
         except TypeError:
             return None
-        for c in (self.criterion, self.prior_criterion):
-            if getattr(c, "reduction", "mean") not in ("mean", "none") or (isinstance(c, UnariesWeightedLoss) and c.reduction != "mean"):
-                return None
-            if isinstance(c, torch.nn.BCELoss) and c.reduction != "mean":
-                return None
+        if (ct, nc) != (pct, pnc):      # one reading of the targets per kernel pass
+            return None
         return L.InrJointLossDesc(L.LOSS_KINDS[kind], L.WEIGHT_MODES[mode], float(ratio), float(self.alpha), float(self.beta), 0,
                                   L.JOINT_AWESOME_IMAGE, L.LOSS_KINDS[pkind], L.WEIGHT_MODES[pmode], float(pratio),
-                                  float(self.gamma), int(bool(self.extra_penalty)), 0)
+                                  float(self.gamma), int(bool(self.extra_penalty)), 0, *_target_fields(ct, nc))
 
     def __call__(self, output: torch.Tensor, target: torch.Tensor, **kwargs) -> torch.Tensor:
         if output.is_cuda and output.dim() == 4 and output.shape[1] == 2:
@@ -210,15 +234,13 @@ class AwesomeLoss:
     def joint_desc(self, total: int = 0):
         from .. import _lib as L
         try:
-            kind, mode, ratio = criterion_to_desc(self.criterion)
+            kind, mode, ratio, ct, nc = joint_criterion_form(self.criterion)
         except TypeError:
-            return None
-        if isinstance(self.criterion, (torch.nn.BCELoss, UnariesWeightedLoss)) and self.criterion.reduction != "mean":
             return None
         n_scr = int(total * self.scribble_percentage // 1)
         return L.InrJointLossDesc(L.LOSS_KINDS[kind], L.WEIGHT_MODES[mode], float(ratio), float(self.alpha), 100.0, 0,
                                   L.JOINT_AWESOME_PIXEL, L.LOSS_KINDS[kind], L.WEIGHT_MODES[mode], float(ratio), 0.1,
-                                  int(bool(self.extra_penalty)), n_scr)
+                                  int(bool(self.extra_penalty)), n_scr, *_target_fields(ct, nc))
 
     def __call__(self, output: torch.Tensor, target: torch.Tensor, **kwargs) -> torch.Tensor:
         total = output.shape[-2]
@@ -295,16 +317,15 @@ class FBMSJointLoss:
     def joint_desc(self):
         """InrJointLossDesc of this loss for the fused joint step (awesome_amd.agent.JointTrainer), or None."""
         from .. import _lib as L
-        if not (isinstance(self.penalty_criterion, SE) and self.penalty_criterion.reduction == "mean"):
-            return None
-        if isinstance(self.criterion, UnariesWeightedLoss) and self.criterion.reduction != "mean":
+        if not (isinstance(self.penalty_criterion, SE) and self.penalty_criterion.reduction == "mean"
+                and self.penalty_criterion.reduction_dim is None):
             return None
         try:
-            kind, mode, ratio = criterion_to_desc(self.criterion)
+            kind, mode, ratio, ct, nc = joint_criterion_form(self.criterion)
         except TypeError:
             return None
         return L.InrJointLossDesc(L.LOSS_KINDS[kind], L.WEIGHT_MODES[mode], float(ratio), float(self.alpha), float(self.beta),
-                                  int(bool(self.clip_penalty)))
+                                  int(bool(self.clip_penalty)), L.JOINT_FBMS, 0, 0, 1.0, 1.0, 0, 0, *_target_fields(ct, nc))
 
     def __call__(self, output: torch.Tensor, target: torch.Tensor, **kwargs) -> torch.Tensor:
         desc = self._fused_desc(output)
@@ -433,15 +454,26 @@ class AwesomeLossJoint:
         return self.name or type(self).__name__
 
 
-def criterion_to_desc(criterion) -> Tuple[str, str, float]:
-    """(loss kind, weight mode, ratio) for the fused kernel, or raise if the criterion has no fused form."""
+def criterion_to_desc(criterion, conversion: str = "reject") -> Tuple[str, str, float]:
+    """(loss kind, weight mode, ratio) for the fused kernels, or raise TypeError if the criterion has no fused form.
+
+    A UnariesConversionLoss changes the TARGETS, not the criterion: a caller that binarises its targets with `criterion_targets`
+    (the per-image fits) passes conversion="targets" and gets the inner criterion's form; everyone else (the composite joint losses,
+    whose kernels read the targets as they are) keeps the default and gets the TypeError -> the torch composition."""
     mode, ratio, inner = "none", 1.0, criterion
-    if isinstance(criterion, UnariesConversionLoss):   # only changes the targets: see criterion_targets
+    if isinstance(criterion, UnariesConversionLoss):
+        if conversion != "targets":
+            raise TypeError("UnariesConversionLoss binarises its targets; this caller does not (no fused form)")
         criterion = inner = criterion.criterion
-    if isinstance(criterion, UnariesWeightedLoss):
+    if isinstance(criterion, WeightedLoss):
+        if criterion.noneclass is not None or type(criterion) is WeightedLoss:
+            # class targets {0, 1, noneclass}: a form of the composite losses' kernels (joint_weighting), not of the per-image fits
+            raise TypeError("WeightedLoss on class targets / with a noneclass has no fused per-image form")
+        if criterion.reduction != "mean" or criterion.reduction_dim is not None:
+            raise TypeError("only reduction='mean' over all pixels has a fused form")
         mode, ratio, inner = criterion.mode, criterion.ratio, criterion.criterion
-    if isinstance(inner, SE):
+    if isinstance(inner, SE) and inner.reduction_dim is None:
         return "se", mode, ratio
-    if isinstance(inner, torch.nn.BCELoss):
+    if isinstance(inner, torch.nn.BCELoss) and inner.weight is None:
         return "bce", mode, ratio
     raise TypeError(f"{type(criterion).__name__} has no fused kernel form (supported: SE, BCELoss, UnariesWeightedLoss of those)")

@@ -93,7 +93,7 @@ class _IcnnModule(nn.Module, PriorFitMixin):
     def _engine_fit(self, grid, unaries, flat, epochs, cold, opts, states=None):
         from ..measures import criterion_to_desc
         crit = opts.get("criterion")
-        kind, wmode, ratio = criterion_to_desc(crit) if crit is not None else ("se", "none", 1.0)
+        kind, wmode, ratio = criterion_to_desc(crit, "targets") if crit is not None else ("se", "none", 1.0)
         res = K.fit(self.spec, flat, grid, unaries, epochs, lr=float(opts.get("lr", 1e-3)), loss=kind, weight_mode=wmode, ratio=ratio,
                     optimizer=opts.get("optimizer", "adamax"), weight_decay=float(opts.get("weight_decay", 0.0)),
                     plateau=dict(patience=200, factor=0.5) if opts.get("use_plateau", True) else None, record_loss=False,

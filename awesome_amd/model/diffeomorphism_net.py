@@ -277,7 +277,7 @@ class ConvexDiffeomorphismNet(nn.Module, PriorFitMixin):
         ispec, fspec = self._specs()
         P = ispec.n_params
         crit = opts.get("criterion")
-        kind, wmode, ratio = criterion_to_desc(crit) if crit is not None else ("bce", "none", 1.0)   # UnariesWeightedLoss(BCELoss, 'none')
+        kind, wmode, ratio = criterion_to_desc(crit, "targets") if crit is not None else ("bce", "none", 1.0)   # UnariesWeightedLoss(BCELoss, 'none')
         res = FL.cdn_fit(ispec, fspec, flat[:, :P].contiguous(), flat[:, P:].contiguous(), grid, unaries, epochs,
                          lr=float(opts.get("lr", 0.003)), loss=kind, weight_mode=wmode, ratio=ratio,
                          weight_decay_on_weight_g=float(opts.get("weight_decay_on_weight_g", 5e-5)),

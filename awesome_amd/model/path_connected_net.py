@@ -258,7 +258,7 @@ class PathConnectedNet(nn.Module, PriorFitMixin):
                   weight_decay=float(opts.get("prefit_convex_net_weight_decay", 0.0)), plateau=None, record_loss=False,
                   want_logits=False)
         crit = opts.get("criterion")
-        kind, wmode, ratio = criterion_to_desc(crit) if crit is not None else ("se", "none", 1.0)
+        kind, wmode, ratio = criterion_to_desc(crit, "targets") if crit is not None else ("se", "none", 1.0)
         res = R.pcn_fit(ispec, rspec, ip, fp, grid, unaries, epochs, lr=float(opts.get("lr", 1e-3)),
                         optimizer=opts.get("optimizer", "adamax"), loss=kind, weight_mode=wmode, ratio=ratio,
                         flow_weight_decay=float(opts.get("flow_weight_decay", 1e-5)),
@@ -310,7 +310,7 @@ class PathConnectedNet(nn.Module, PriorFitMixin):
                                   max_iter=int(opts["prefit_convex_net_num_epochs"]))
         from ..measures import criterion_targets, criterion_to_desc
         crit = opts.get("criterion")
-        kind, wmode, _ = criterion_to_desc(crit) if crit is not None else ("se", "none", 1.0)
+        kind, wmode, _ = criterion_to_desc(crit, "targets") if crit is not None else ("se", "none", 1.0)
         frame_unaries = self._sequence_unaries(frame_unaries, opts, agent)
         # criterion_to_desc unwraps UnariesConversionLoss; its effect - binarised targets - is applied here
         frame_unaries = criterion_targets(crit, frame_unaries).contiguous()

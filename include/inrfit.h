@@ -35,7 +35,7 @@ extern "C" {
  * exported (nm -D shows the inrfit_* entry points and nothing else of the library's own). */
 #pragma GCC visibility push(default)
 
-#define INRFIT_ABI_VERSION 6
+#define INRFIT_ABI_VERSION 7
 
 enum {
     INR_OK = 0,
@@ -339,6 +339,16 @@ typedef struct InrJointLossDesc {
     float gamma;              /* AWESOME_*: factor on the data terms once extra_penalty is on */
     int32_t extra_penalty;
     int64_t n_scribble;       /* INR_JOINT_AWESOME_PIXEL: leading pixels with targets (0 = all) */
+    /* ABI v7 - the targets' meaning for the data terms (a zero-initialised tail keeps the v6 meaning):
+     * target_rule 0: unaries, UnariesWeightedLoss (awesome/measures/unaries_weighted_loss.py:35-69): fg = target < 0.5, bg = the rest;
+     * target_rule 1: class labels, WeightedLoss (awesome/measures/weighted_loss.py:38-62): fg = target == 0, bg = target == 1 (the
+     *                counts behind the class weight), any other value takes weight 1;
+     * use_noneclass: pixels whose target equals `noneclass` leave the data terms altogether - sums, counts and the mean's
+     *                denominator (weighted_loss.py:71-74; 2 in the reference's FBMS configs).  The penalty / align term has no
+     *                targets and keeps every pixel. */
+    int32_t target_rule;
+    int32_t use_noneclass;
+    float noneclass;
 } InrJointLossDesc;
 int64_t inrfit_joint_loss_workspace_bytes(int64_t n_elems);
 int inrfit_joint_loss(const float* output, const float* target, int batch, int64_t hw, const InrJointLossDesc* desc,
@@ -357,8 +367,10 @@ int inrfit_joint_loss(const float* output, const float* target, int batch, int64
  * by passing the same opt_state with every row and `step` = the global step count; a state per row with its own count is the
  * per-image variant.  `step` >= 1 is torch's state['step'] after this step (bias corrections); the learning rate is opt->lr (host
  * schedulers stay on the host), opt->plateau is ignored.  A non-finite loss leaves the row untouched and sets *status (optional).
- * Forms: INR_JOINT_FBMS, and INR_JOINT_AWESOME_IMAGE while extra_penalty is off (with it on the prior has two data terms: use
- * inrfit_joint_loss + inrfit_backward; returns INR_EUNSUPPORTED).
+ * Forms: INR_JOINT_FBMS (any target rule / noneclass: the prior's term has no targets), and INR_JOINT_AWESOME_IMAGE while
+ * extra_penalty is off (with it on the prior has two data terms: use inrfit_joint_loss + inrfit_backward) on unaries without a
+ * noneclass (its prior term is evaluated by the step kernel, which reads unaries); otherwise INR_EUNSUPPORTED.
+ * A non-finite COMPOSITE loss (a NaN in `seg` as much as in the prior) freezes the row.
  * How the clip stays on the device with a single prior pass: the prior's gradient is linear in the penalty's coefficient, so the step
  * kernel runs with the unclipped coefficient, its own loss column gives the penalty, and the update kernel multiplies the reduced
  * gradient by the (detached) clip factor. */

@@ -224,9 +224,33 @@ def unaries_weight(target: Tensor, mode: str, ratio: float = 1.0) -> Tensor:
     return w
 
 
-def weighted_loss(output: Tensor, target: Tensor, kind: str = "se", mode: str = "none", ratio: float = 1.0) -> Tensor:
+def class_weight(target: Tensor, mode: str) -> Tensor:
+    """WeightedLoss._compute_weight on CLASS labels (awesome/measures/weighted_loss.py:38-62): fg = target == 0, bg = target == 1,
+    the fg pixels weighted by bg / fg ('equal') or round((bg / fg) / 10) + 1 ('sssdms'); everything else weight 1."""
+    if mode == "none":
+        return torch.ones_like(target)
+    cc = (target == 1).sum().float() / (target == 0).sum().float()
+    if mode == "sssdms":
+        wv = torch.round(cc / 10) + 1
+    elif mode == "equal":
+        wv = cc
+    else:
+        raise ValueError(f"Mode {mode} is not supported")
+    w = torch.ones_like(target)
+    w[target == 0] = wv
+    return w
+
+
+def weighted_loss(output: Tensor, target: Tensor, kind: str = "se", mode: str = "none", ratio: float = 1.0,
+                  noneclass: Optional[float] = None, class_targets: bool = False) -> Tensor:
     """WeightedLoss.__call__ (awesome/measures/weighted_loss.py:67-92) with criterion SE
-    (awesome/measures/se.py:21-23) or nn.BCELoss, reduction 'mean' over all elements."""
+    (awesome/measures/se.py:21-23) or nn.BCELoss, reduction 'mean' over all elements.  `noneclass`: the pixels whose target equals
+    it are removed first (:71-74) - from the criterion, the class counts and the mean.  `class_targets`: the base class's weights on
+    labels {0, 1} (class_weight) instead of UnariesWeightedLoss's on unaries (unaries_weight).
+    Pinned by tests/golden/weighted_loss_noneclass.npz (the reference class, three modes x two criteria, with and without noneclass)."""
+    if noneclass is not None:
+        keep = target != noneclass
+        output, target = output[keep], target[keep]
     if kind == "se":
         l = (target - output) ** 2
     elif kind == "bce":
@@ -234,7 +258,7 @@ def weighted_loss(output: Tensor, target: Tensor, kind: str = "se", mode: str = 
     else:
         raise ValueError(kind)
     if mode != "none":
-        l = l * unaries_weight(target, mode, ratio)
+        l = l * (class_weight(target, mode) if class_targets else unaries_weight(target, mode, ratio))
     return l.mean()
 
 
@@ -249,14 +273,15 @@ def awesome_image_loss(output: Tensor, target: Tensor, alpha=1.0, beta=100.0, ga
 
 
 def fbms_joint_loss(output: Tensor, target: Tensor, alpha: float = 1.0, beta: float = 1.0, clip_penalty: bool = True,
-                    kind: str = "bce", mode: str = "sssdms", ratio: float = 1.0) -> Tensor:
+                    kind: str = "bce", mode: str = "sssdms", ratio: float = 1.0, noneclass: Optional[float] = None,
+                    class_targets: bool = False) -> Tensor:
     """FBMSJointLoss.__call__ (awesome/measures/fbms_joint_loss.py:35-59): output (B, 2, H, W) = [seg, prior];
     alpha * crit(seg, target) + beta * SE_mean(prior, seg), the penalty rescaled (detached factor) to the segmentation loss
     when it exceeds it.  Pinned by tests/golden/fbms_joint_loss.npz (both branches)."""
     c = output.shape[1] // 2
     seg, prior = output[:, :c], output[:, c:]
-    seg_loss = alpha * weighted_loss(seg, target, kind=kind, mode=mode, ratio=ratio)
-    pen = beta * torch.mean((seg - prior) ** 2)
+    seg_loss = alpha * weighted_loss(seg, target, kind=kind, mode=mode, ratio=ratio, noneclass=noneclass, class_targets=class_targets)
+    pen = beta * torch.mean((seg - prior) ** 2)      # the penalty has no targets: every pixel, noneclass or not
     if clip_penalty and bool(pen > seg_loss):     # the reference branches on the host exactly like this
         pen = pen * (seg_loss / pen).detach()
     return seg_loss + pen

@@ -58,6 +58,9 @@ def get_config(argv=None) -> AwesomeConfig:
         v = getattr(args, k)
         if v is not None:
             cfg[k] = v
+    if args.num_epochs is not None:   # this entrypoint's shorthand: the flag also sets the per-image fit's epochs
+        cfg.agent_args = dict(cfg.agent_args or {})
+        cfg.agent_args["pretrain_args"] = dict(cfg.agent_args.get("pretrain_args") or {}, num_epochs=args.num_epochs)
     if args.dataset_args is not None:
         extra = S.decode(json.loads(args.dataset_args), in_scope=False, path="dataset_args")
         cfg["dataset_args"] = extra if args.dataset_type else dict(cfg.get("dataset_args") or {}, **extra)
@@ -86,7 +89,7 @@ def _fusable(criterion):
     composite training losses (FBMSJointLoss, AwesomeImageLoss) belong to the joint step, not to the per-image fit."""
     from awesome_amd.measures import criterion_to_desc
     try:
-        criterion_to_desc(criterion)
+        criterion_to_desc(criterion, "targets")
         return True
     except TypeError:
         return False
@@ -151,7 +154,13 @@ def main(cfg):
     if kw.get("zoo") and not hasattr(kw["zoo"], "load_model_state"):
         from awesome_amd.model import Zoo
         kw["zoo"] = Zoo(None if kw["zoo"] == "memory" else str(kw["zoo"]))
-    agent = PretrainAgent(ds, device=device, agent_folder=os.path.join(out_dir, f"rank{rank}"), pretrain_args=kw)
+    aa = dict(cfg.agent_args or {})          # TorchAgent's pretraining switches (torch_agent.py:553-627)
+    state_path = aa.get("pretrain_state_path")
+    if state_path is not None and world > 1:
+        state_path = f"{state_path}.rank{rank}"     # every rank fits (and caches) its own shard
+    agent = PretrainAgent(ds, device=device, agent_folder=os.path.join(out_dir, f"rank{rank}"), pretrain_args=kw,
+                          do_pretraining=aa.get("do_pretraining", True), force_pretrain=aa.get("force_pretrain", False),
+                          pretrain_state_path=state_path)
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -302,6 +311,7 @@ def _fit_shard(cfg, ds, mine, agent, wrapper, criterion, model_type, model_args,
                 loss, _ = trainer.perform_step(k, (image[None].to(device), feat[None].to(device), xy[None].to(device)),
                                                target[None].to(device))
                 acc = acc + loss
+            trainer.raise_if_failed()          # ValueError("Loss is nan or inf!") like the reference, one sync per epoch
             joint_losses.append(float(acc) / len(mine))
         for k in mine:   # the jointly trained priors replace the pretrained ones in the cache
             with bank.manager(prior, k):
@@ -320,12 +330,12 @@ def _run_sequence(cfg, A, parallel, rank, world, device, model_type, model_args,
     """(x, y, t) sequences: ONE network over all frames of a sequence (the spatio-temporal mode, path_connected_net.py:511-728);
     whole sequences are the unit that is sharded over the ranks."""
     import torch
-    from awesome_amd.measures import criterion_to_desc
+    from awesome_amd.measures import criterion_targets, criterion_to_desc
     mine = list(parallel.shard_range(len(dataset), rank, world))
     grid = A.Grid.explicit(dataset.coords().to(device))
     lr = float(pre.get("lr", 1e-3))
     opt_type = str(pre.get("optimizer", "adamax")).lower()
-    kind, wmode, _ = criterion_to_desc(criterion) if criterion is not None else ("se", "none", 1.0)
+    kind, wmode, _ = criterion_to_desc(criterion, "targets") if criterion is not None else ("se", "none", 1.0)
     kw = dict(num_epochs=num_epochs, lr=lr, loss=kind, weight_mode=wmode, flow_weight_decay=float(pre.get("flow_weight_decay", 1e-5)),
               optimizer=opt_type)
     kw.update({k: v for k, v in pre.items() if k.startswith("prefit_")})
@@ -340,7 +350,7 @@ def _run_sequence(cfg, A, parallel, rank, world, device, model_type, model_args,
         for i in mine:
             torch.manual_seed(int(cfg.get("seed", 42)) + i)
             model = model_type(**model_args).to(device)
-            un = dataset.batch([i]).to(device)
+            un = criterion_targets(criterion, dataset.batch([i]).to(device))
             res = model.fit_images(grid, un, **kw)
             if int(res.status[0]) != 0:
                 raise ValueError(f"Loss is nan or inf! (sequence {i})")

@@ -242,3 +242,40 @@ def test_oracle_star_training_loop_matches_the_notebook_class(golden_dir):
     assert torch.equal(out2["offset"], sd["offset"]) and not torch.equal(out3["offset"], sd["offset"])
     # Adam's first step moves a parameter by lr whatever the gradient's size: the centre's own step count starts at its first gradient
     np.testing.assert_allclose((out3["offset"] - sd["offset"]).abs().numpy(), 1e-2, rtol=1e-3)
+
+
+def test_weighted_loss_on_class_labels_with_noneclass_matches_reference(golden_dir):
+    """WeightedLoss(criterion, mode, noneclass) of the reference's FBMS configs (awesome/measures/weighted_loss.py:11-92): the
+    oracle's restatement and the host mirror against the reference class's own values and gradients, alone and inside FBMSJointLoss
+    (both clip branches)."""
+    from awesome_amd.measures import FBMSJointLoss, SE, WeightedLoss
+    z = np.load(os.path.join(golden_dir, "weighted_loss_noneclass.npz"))
+    out, tgt = torch.from_numpy(z["output"]), torch.from_numpy(z["target"])
+    for kind in ("bce", "se"):
+        for mode in ("none", "sssdms", "equal"):
+            for tag, nc in (("all", None), ("nc2", 2.0)):
+                t = tgt if nc is not None else torch.where(tgt == 2.0, torch.ones_like(tgt), tgt)
+                key = f"{kind}.{mode}.{tag}"
+                o = out[:, :1].clone().requires_grad_(True)
+                lo = O.weighted_loss(o, t, kind=kind, mode=mode, noneclass=nc, class_targets=True)
+                lo.backward()
+                assert float(lo.detach()) == pytest.approx(float(z[key + ".loss"]), rel=1e-6), key
+                np.testing.assert_allclose(o.grad.numpy(), z[key + ".grad"], rtol=1e-5, atol=1e-9, err_msg=key)
+                inner = torch.nn.BCELoss() if kind == "bce" else SE("mean")
+                o2 = out[:, :1].clone().requires_grad_(True)
+                lm = WeightedLoss(inner, mode=mode, noneclass=nc)(o2, t)
+                lm.backward()
+                assert float(lm.detach()) == pytest.approx(float(z[key + ".loss"]), rel=1e-6), key
+                np.testing.assert_allclose(o2.grad.numpy(), z[key + ".grad"], rtol=1e-5, atol=1e-9, err_msg=key)
+    for case in range(2):
+        beta = float(z[f"fbms{case}.beta"])
+        o = out.clone().requires_grad_(True)
+        lo = O.fbms_joint_loss(o, tgt, alpha=1.0, beta=beta, kind="bce", mode="sssdms", noneclass=2.0, class_targets=True)
+        lo.backward()
+        assert float(lo.detach()) == pytest.approx(float(z[f"fbms{case}.loss"]), rel=1e-6)
+        np.testing.assert_allclose(o.grad.numpy(), z[f"fbms{case}.grad"], rtol=1e-5, atol=1e-9)
+        o2 = out.clone().requires_grad_(True)
+        lm = FBMSJointLoss(criterion=WeightedLoss(torch.nn.BCELoss(), mode="sssdms", noneclass=2), alpha=1.0, beta=beta)(o2, tgt)
+        lm.backward()
+        assert float(lm.detach()) == pytest.approx(float(z[f"fbms{case}.loss"]), rel=1e-6)
+        np.testing.assert_allclose(o2.grad.numpy(), z[f"fbms{case}.grad"], rtol=1e-5, atol=1e-9)

@@ -140,6 +140,51 @@ def test_run_py_two_ranks_save_every_prior(tmp_path):
         assert torch.allclose(a, b, rtol=5e-3, atol=5e-4), i
 
 
+def test_run_py_reads_a_reference_schema_yaml(tmp_path):
+    """a config in the REFERENCE's file format - every nested object a `{__class__: dotted.Type, **fields}`
+    mapping with the reference's own type names, the shape of config/path-connectedness/refit-unet-prior-only/*diffeo*.yaml:
+    ConvexDiffeomorphismNet (6 couplings x 130, ICNN 130 x 2), pretrain criterion UnariesConversionLoss(SE), FBMSJointLoss(WeightedLoss(
+    BCELoss, sssdms, noneclass 2)), Adam with a TupleValueWrapper for betas, an FBMSSequenceDataset under dataset_args, a UNet backbone -
+    runs through scripts/run.py with ONLY what is not in the image replaced on the command line (dataset, backbone, paths, epochs)."""
+    import yaml
+    from awesome_amd import serialization as S
+    from tests.test_config_trees import _tagged_cdn_config
+    cfg = _tagged_cdn_config()
+    cfg["dataset_type"] = "awesome.dataset.awesome_dataset.AwesomeDataset"
+    cfg["dataset_args"] = dict(batch_size=1, dimension="3d", xytype="edge",
+                               dataset=S.OpaqueObject("awesome.dataset.fbms_sequence_dataset.FBMSSequenceDataset",
+                                                      dict(dataset_path="data/local_datasets/FBMS-59/train/bear01", all_frames=True, dtype=torch.float32)))
+    cfg["segmentation_model_type"] = "awesome.model.unet.UNet"
+    cfg["segmentation_model_args"] = dict(in_chn=4)
+    cfg["use_segmentation_output_inversion"] = True
+    cfg.agent_args["pretrain_args"].update(do_pretrain_checkpoints=True, use_pretrain_checkpoints=True, use_logger=True, use_step_logger=False,
+                                           pretrain_checkpoint_dir="./data/checkpoints/pretrain_states/x")
+    cfg.agent_args.update(do_pretraining=True, force_pretrain=True, pretrain_state_path="./data/checkpoints/pretrain_states/x.pth")
+    path = cfg.save_to_file(str(tmp_path / "UNET+bear01+edge+diffeo+only_prior+REFIT.yaml"))
+    tree = yaml.safe_load(open(path))["AwesomeConfig"]
+    assert tree["agent_args"]["pretrain_args"]["criterion"]["__class__"] == "awesome.measures.unaries_conversion_loss.UnariesConversionLoss"
+    assert tree["dataset_args"]["dataset"]["__class__"] == "awesome.dataset.fbms_sequence_dataset.FBMSSequenceDataset"
+    run = [sys.executable, os.path.join(ROOT, "scripts", "run.py"), "--config-path", path, "--output-folder", str(tmp_path / "out")]
+    # as written: the loaders of the reference are not part of this build - a clear refusal, not a silent default
+    refused = subprocess.run(run, capture_output=True, text=True, timeout=600)
+    assert refused.returncode != 0 and "dataset_type" in refused.stderr and "out of scope" in refused.stderr
+    override = {"agent_args": {"pretrain_state_path": str(tmp_path / "state.pth"),
+                               "pretrain_args": {"num_epochs": 2000, "pretrain_checkpoint_dir": str(tmp_path / "ckpt")}}}
+    out = subprocess.run(run + ["--dataset-type", "awesome_amd.dataset.SyntheticUnariesDataset", "--dataset-args",
+                                json.dumps(dict(n_images=1, size=64, kind="blob")), "--segmentation-model-type",
+                                "awesome_amd.model.ConvSegStandIn", "--override", json.dumps(override)],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    summary = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert summary["images"] == 1 and summary["priors_saved"] == 1 and summary["epochs"] == 2000
+    assert summary["ForegroundBinaryMIOU_vs_unaries"] > 0.9, summary
+    assert "joint_epochs" not in summary                                   # agent_args.pretrain_only
+    cache = torch.load(os.path.join(summary["output"], "prior_cache_epoch_0.pth"), weights_only=False)
+    assert any(k.startswith("diffeo_net.") for k in cache["cache"]["0"]) and "convex_net.skip.1.ln.weight" in cache["cache"]["0"]
+    assert os.path.exists(tmp_path / "state.pth")                          # TorchAgent's pretrain_state_path
+    assert sorted(os.listdir(tmp_path / "ckpt")) == ["pretrain_checkpoint_0.pth"]
+
+
 @pytest.mark.parametrize("config,override,checks", [
     ("c5_refine_noisy256.yaml", {"dataset_args": {"n_images": 2, "size": 64}, "agent_args": {"joint_epochs": 3, "pretrain_args": {"num_epochs": 80}}},
      dict(images=2, joint_epochs=3)),
@@ -150,7 +195,7 @@ def test_run_py_two_ranks_save_every_prior(tmp_path):
                                  "use_reduce_lr_in_extra_penalty_hook": True},
      dict(images=2, joint_epochs=3, extra_penalty=True)),
     ("c2_blob256_path_connected.yaml", {"dataset_args": {"size": 64}, "agent_args": {"pretrain_args": {"num_epochs": 80}}}, dict(images=1)),
-    ("c4_sequence128x16.yaml", {"dataset_args": {"size": 32, "frames": 4}, "num_epochs": 60}, dict(images=1)),
+    ("c4_sequence128x16.yaml", {"dataset_args": {"size": 32, "frames": 4}, "agent_args": {"pretrain_args": {"num_epochs": 60}}}, dict(images=1)),
     ("c1_disc64_siren.yaml", {}, dict(images=1)),
     ("c1_disc64_no_prior.yaml", {}, dict(images=1)),
 ])

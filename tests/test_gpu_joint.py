@@ -244,7 +244,7 @@ def _joint_setup(dev, prior_factory, S=48, n=2, seed=5):
     return items, seg, wrapper, bank
 
 
-def _run_joint(dev, prior_factory, crit_factory, fused, steps, lr=2e-3, opt_type=torch.optim.Adam, perturb=None):
+def _run_joint(dev, prior_factory, crit_factory, fused, steps, lr=2e-3, opt_type=torch.optim.Adam, perturb=None, relabel=None):
     """`steps` joint steps from identical starting points; returns (losses, seg weights, bank rows)."""
     from awesome_amd.agent import JointTrainer
     items, seg, wrapper, bank = _joint_setup(dev, prior_factory)
@@ -260,6 +260,8 @@ def _run_joint(dev, prior_factory, crit_factory, fused, steps, lr=2e-3, opt_type
     for s in range(steps):
         i = s % len(items)
         (image, _, xy), target = items[i]
+        if relabel is not None:
+            target = relabel(target, 100 + i)
         loss, out = trainer.perform_step(i, (image[None].to(dev), feat, xy[None].to(dev)), target[None].to(dev))
         losses.append(float(loss))
         outs.append(out.cpu())
@@ -403,3 +405,283 @@ def test_awesome_image_and_pixel_losses_on_device(dev, golden_dir):
         crit(o_c, tgt).backward()
         assert float(l_h.detach()) == pytest.approx(float(zp[key]), rel=3e-6)
         np.testing.assert_allclose(o_h.grad.cpu().numpy(), o_c.grad.numpy(), rtol=3e-5, atol=1e-9)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# round 4: the reference's own criterion (WeightedLoss on class labels with a noneclass), the path-connected joint steps at
+# configs[4] size, one optimizer state across both step implementations, and the trainer's handling of shapes / failures
+# ----------------------------------------------------------------------------------------------------------------------------
+
+
+def test_weighted_loss_noneclass_in_the_device_losses(dev, golden_dir):
+    """inrfit_joint_loss with InrJointLossDesc.target_rule = 1 / use_noneclass (ABI v7): FBMSJointLoss(WeightedLoss(BCELoss, sssdms,
+    noneclass 2)) - the criterion of 153 reference configs - against the REFERENCE CLASS's fixture (value + both gradient channels,
+    both clip branches); AwesomeImageLoss and the other modes against the host mirror's torch composition on the CPU (itself
+    pinned on the same fixture, tests/test_boundary_golden.py)."""
+    from awesome_amd.measures import AwesomeImageLoss, FBMSJointLoss, SE, WeightedLoss
+    z = np.load(os.path.join(golden_dir, "weighted_loss_noneclass.npz"))
+    out, tgt = torch.from_numpy(z["output"]), torch.from_numpy(z["target"])
+    for case in range(2):
+        crit = FBMSJointLoss(criterion=WeightedLoss(torch.nn.BCELoss(), mode="sssdms", noneclass=2), alpha=1.0, beta=float(z[f"fbms{case}.beta"]))
+        d = crit.joint_desc()
+        assert d is not None and d.target_rule == 1 and d.use_noneclass == 1 and d.noneclass == 2.0
+        o = out.to(dev).requires_grad_(True)
+        loss = crit(o, tgt.to(dev))
+        loss.backward()
+        assert float(loss.detach()) == pytest.approx(float(z[f"fbms{case}.loss"]), rel=3e-6)
+        np.testing.assert_allclose(o.grad.cpu().numpy(), z[f"fbms{case}.grad"], rtol=3e-5, atol=1e-9)
+    for kind, mode, nc in (("se", "equal", 2.0), ("bce", "none", 2.0), ("se", "sssdms", None)):
+        inner = (lambda: torch.nn.BCELoss()) if kind == "bce" else (lambda: SE("mean"))
+        t = tgt if nc is not None else torch.where(tgt == 2.0, torch.ones_like(tgt), tgt)
+        for make in (lambda: FBMSJointLoss(criterion=WeightedLoss(inner(), mode=mode, noneclass=nc), alpha=0.8, beta=3.0),
+                     lambda: AwesomeImageLoss(criterion=WeightedLoss(inner(), mode=mode, noneclass=nc),
+                                              prior_criterion=WeightedLoss(torch.nn.BCELoss(), mode="sssdms", noneclass=nc), alpha=0.6)):
+            crit = make()
+            assert crit.joint_desc() is not None
+            o_h, o_c = out.to(dev).requires_grad_(True), out.clone().requires_grad_(True)
+            l_h, l_c = crit(o_h, t.to(dev)), make()(o_c, t)
+            l_h.backward()
+            l_c.backward()
+            assert float(l_h.detach()) == pytest.approx(float(l_c.detach()), rel=5e-6), (kind, mode, nc)
+            np.testing.assert_allclose(o_h.grad.cpu().numpy(), o_c.grad.numpy(), rtol=5e-5, atol=1e-9, err_msg=f"{kind} {mode} {nc}")
+
+
+def _labels_with_noneclass(target: torch.Tensor, seed: int) -> torch.Tensor:
+    """Class labels {0, 1} with ~30 % of the pixels marked unlabeled (2), like the FBMS weak labels."""
+    g = torch.Generator().manual_seed(seed)
+    lab = (target >= 0.5).float()
+    return torch.where(torch.rand(lab.shape, generator=g) < 0.3, torch.full_like(lab, 2.0), lab)
+
+
+def test_fused_joint_step_with_the_reference_configs_criterion(dev):
+    """The fused step (ICNN and both path-connected priors) under FBMSJointLoss(WeightedLoss(BCELoss, sssdms, noneclass 2)) on labels
+    with unlabeled pixels, against the autograd step with the same (fixture-pinned) loss: losses, backbone weights, prior rows."""
+    from awesome_amd.measures import FBMSJointLoss, WeightedLoss
+    from awesome_amd.model import ConvexNextNet, real_nvp_path_connected_net
+    crit = lambda: FBMSJointLoss(criterion=WeightedLoss(torch.nn.BCELoss(), mode="sssdms", noneclass=2), alpha=1.0, beta=2.0)   # noqa: E731
+    for factory, perturb in ((lambda: ConvexNextNet(n_hidden=64, in_features=2, n_hidden_layers=2), None),
+                             (lambda: real_nvp_path_connected_net(channels=2, hidden_units=16, flow_n_flows=4, flow_output_fn="tanh",
+                                                                  convex_net_hidden_units=64, convex_net_hidden_layers=2), _nonzero_last_layers)):
+        runs = []
+        for fused in (True, False):
+            runs.append(_run_joint(dev, factory, crit, fused, 4, perturb=perturb, relabel=_labels_with_noneclass))
+        (lf, wf, rf, of, tf), (la, wa, ra, oa, _) = runs
+        assert int(tf.last_status[0]) == 0
+        np.testing.assert_allclose(lf, la, rtol=2e-5)
+        np.testing.assert_allclose(wf.numpy(), wa.numpy(), rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(rf.numpy(), ra.numpy(), rtol=1e-3, atol=2e-5)
+
+
+def test_one_optimizer_state_across_fused_and_autograd_steps(dev):
+    """AwesomeImageLoss with the runner's extra-penalty hook switches the trainer from the fused to the autograd step in
+    the middle of a run (and `use_reduce_lr_in_extra_penalty_hook` rescales the learning rate at that moment); the reference has ONE
+    optimizer throughout (torch_agent.py:812-839).  The prior's moments and step count move with the step: the mixed run must follow
+    the pure autograd run - and must NOT look like a run whose prior moments restart at the switch."""
+    from awesome_amd.agent import JointTrainer
+    from awesome_amd.measures import AwesomeImageLoss
+    from awesome_amd.model import ConvexNextNet
+    from awesome_amd.prior_bank import _ordered_parameters
+    factory = lambda: ConvexNextNet(n_hidden=64, in_features=2, n_hidden_layers=2)   # noqa: E731
+    for opt_type in (torch.optim.Adam, torch.optim.Adamax):
+        rows, paths = {}, {}
+        for mode in ("mixed", "autograd", "restart"):
+            items, seg, wrapper, bank = _joint_setup(dev, factory)
+            crit = AwesomeImageLoss(alpha=0.7, beta=5.0, gamma=0.5)
+            opt = opt_type(list(seg.parameters()) + list(_ordered_parameters(wrapper.prior_module)), lr=2e-3)
+            tr = JointTrainer(wrapper, bank, crit, opt, fused=(mode != "autograd"))
+            feat, taken = torch.zeros(1, 1, 1, 1, device=dev), []
+            for s in range(8):
+                if s == 5:
+                    crit.extra_penalty = True               # awesome_runner.py:351-371
+                    for g in opt.param_groups:
+                        g["lr"] = g["lr"] * 0.5
+                    if mode == "restart":                    # what round 3 did: the autograd step starts from empty moments
+                        tr._path = None
+                i = s % len(items)
+                (image, _, xy), target = items[i]
+                tr.perform_step(i, (image[None].to(dev), feat, xy[None].to(dev)), target[None].to(dev))
+                taken.append(tr._path)
+            rows[mode], paths[mode] = bank.params.detach().cpu().clone(), taken
+        assert paths["mixed"] == ["fused"] * 5 + ["autograd"] * 3 and paths["autograd"] == ["autograd"] * 8
+        np.testing.assert_allclose(rows["mixed"].numpy(), rows["autograd"].numpy(), rtol=1e-3, atol=3e-5)
+        # the restarted run is measurably somewhere else (Adam's bias correction makes the first step after a restart ~lr * sign(g))
+        assert np.abs(rows["restart"].numpy() - rows["autograd"].numpy()).max() > 20 * np.abs(rows["mixed"].numpy() - rows["autograd"].numpy()).max()
+        # ... and back: the fused step continues from the autograd step's state
+        items, seg, wrapper, bank = _joint_setup(dev, factory)
+        crit = AwesomeImageLoss(alpha=0.7)
+        crit.extra_penalty = True
+        opt = opt_type(list(seg.parameters()) + list(_ordered_parameters(wrapper.prior_module)), lr=2e-3)
+        tr = JointTrainer(wrapper, bank, crit, opt)
+        feat = torch.zeros(1, 1, 1, 1, device=dev)
+        for s in range(6):
+            if s == 3:
+                crit.extra_penalty = False
+            (image, _, xy), target = items[s % 2]
+            tr.perform_step(s % 2, (image[None].to(dev), feat, xy[None].to(dev)), target[None].to(dev))
+        assert tr._path == "fused" and tr._t[None] == 6
+
+
+def test_joint_trainer_takes_the_autograd_step_for_shapes_without_a_fused_kernel(dev):
+    """ConvexNextNet(n_hidden=256) is a supported shape (layer-by-layer path) but has no fused joint step; under the
+    default `fused=None` the trainer must plan the autograd step instead of failing in the C-ABI call."""
+    from awesome_amd.agent import JointTrainer
+    from awesome_amd.measures import FBMSJointLoss
+    from awesome_amd.model import ConvexNextNet
+    from awesome_amd.prior_bank import _ordered_parameters
+    factory = lambda: ConvexNextNet(n_hidden=256, in_features=2, n_hidden_layers=1)   # noqa: E731
+    items, seg, wrapper, bank = _joint_setup(dev, factory, S=32)
+    opt = torch.optim.Adam(list(seg.parameters()) + list(_ordered_parameters(wrapper.prior_module)), lr=1e-3)
+    tr = JointTrainer(wrapper, bank, FBMSJointLoss(alpha=1.0, beta=2.0), opt)
+    assert tr.fused is False and not wrapper.prior_module.spec.fused() and wrapper.prior_module.spec.supported()
+    with pytest.raises(ValueError, match="no fused joint step"):
+        JointTrainer(wrapper, bank, FBMSJointLoss(), opt, fused=True)
+    before = bank.params.detach().clone()
+    (image, _, xy), target = items[0]
+    l0, _ = tr.perform_step(0, (image[None].to(dev), torch.zeros(1, 1, 1, 1, device=dev), xy[None].to(dev)), target[None].to(dev))
+    l1, _ = tr.perform_step(0, (image[None].to(dev), torch.zeros(1, 1, 1, 1, device=dev), xy[None].to(dev)), target[None].to(dev))
+    assert torch.isfinite(l0) and torch.isfinite(l1) and float(l1) != float(l0) and not torch.equal(bank.params[0], before[0])
+
+
+def test_nonfinite_segmentation_output_freezes_row_and_backbone(dev):
+    """a NaN in the segmentation output.  AWESOME_IMAGE form: the prior's own loss column does not contain `seg`, the
+    COMPOSITE loss does - the row freezes (status 1) all the same; the trainer hands the backbone a zero gradient instead of NaN and
+    raises the reference's ValueError when asked."""
+    import awesome_amd as A
+    from awesome_amd import joint as J
+    from awesome_amd import _lib as L
+    from awesome_amd.agent import JointTrainer
+    from awesome_amd.measures import AwesomeImageLoss
+    from awesome_amd.model import ConvexNextNet
+    from awesome_amd.prior_bank import _ordered_parameters
+    torch.manual_seed(0)
+    m = ConvexNextNet(n_hidden=64, in_features=2, n_hidden_layers=1)
+    row = m.flat_parameters().to(dev)
+    keep, S = row.clone(), 32
+    grid = A.Grid.linspace(S, S, dev)
+    seg = torch.rand(S * S, device=dev) * 0.9 + 0.05
+    seg[11] = float("nan")
+    tgt = (torch.rand(S * S, device=dev) > 0.5).float()
+    opt = torch.zeros(2 * m.spec.n_params + 8, device=dev)
+    bad = J.joint_step(m.spec, row, opt, grid, seg, tgt, J.joint_desc(form=L.JOINT_AWESOME_IMAGE, weight_mode="none", alpha=0.7), step=1, lr=1e-3)
+    assert int(bad.status[0]) == 1 and torch.equal(row, keep) and float(opt[: 2 * m.spec.n_params].abs().sum()) == 0.0
+
+    class NanSeg(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = torch.nn.Conv2d(1, 1, 3, padding=1)
+
+        def forward(self, image, *a, **k):
+            out = self.conv(image)
+            return out + torch.where(torch.arange(out.numel(), device=out.device).view_as(out) == 5, float("nan"), 0.0)
+
+    factory = lambda: ConvexNextNet(n_hidden=64, in_features=2, n_hidden_layers=1)   # noqa: E731
+    items, _, wrapper, bank = _joint_setup(dev, factory, S=32)
+    wrapper.segmentation_module = NanSeg().to(dev)
+    seg_mod = wrapper.segmentation_module
+    w0 = seg_mod.conv.weight.detach().clone()
+    opt = torch.optim.Adam(list(seg_mod.parameters()) + list(_ordered_parameters(wrapper.prior_module)), lr=1e-2)
+    tr = JointTrainer(wrapper, bank, AwesomeImageLoss(alpha=0.7), opt, fused=True)        # check_finite="epoch": no sync per step
+    before = bank.params.detach().clone()
+    (image, _, xy), target = items[0]
+    args = (0, (image[None].to(dev), torch.zeros(1, 1, 1, 1, device=dev), xy[None].to(dev)), target[None].to(dev))
+    tr.perform_step(*args)
+    assert int(tr.last_status[0]) == 1 and torch.equal(bank.params, before)
+    with pytest.raises(ValueError, match="Loss is nan or inf!"):
+        tr.raise_if_failed()
+    # check_finite="step": the reference's behaviour to the letter - the error BEFORE backward (torch_agent.py:484-487), the backbone
+    # untouched (one 4-byte device -> host read per step, which the reference pays anyway for loss.item())
+    seg_mod.load_state_dict({"conv.weight": w0, "conv.bias": seg_mod.conv.bias.detach().clone().nan_to_num(0.0)})
+    tr2 = JointTrainer(wrapper, bank, AwesomeImageLoss(alpha=0.7), opt, fused=True, check_finite="step")
+    with pytest.raises(ValueError, match="Loss is nan or inf!"):
+        tr2.perform_step(*args)
+    assert torch.equal(seg_mod.conv.weight.detach(), w0) and torch.equal(bank.params, before)
+
+
+@pytest.mark.parametrize("family", ["pcn", "cdn"])
+def test_configs4_path_connected_joint_step_at_full_size(dev, family):
+    """VERDICT r03 item 2 - BASELINE configs[4]'s named prior at ITS size: one `inrfit_pcn_joint_step` / `inrfit_cdn_joint_step` on a
+    256x256 noisy pseudo-label image with the CONFIG networks (PathConnectedNet: C = 2, 12 flows x 32 hidden units, tanh outputs, ICNN
+    130 x 2, `config/c5_refine_noisy256.yaml` = the reference's realnvp YAMLs; ConvexDiffeomorphismNet: 6 couplings x 130,
+    normal_block, ICNN 130 x 2, `config/path-connectedness/joint/*diffeo*.yaml`) against the oracle's restatement of
+    TorchAgent._perform_step (awesome/agent/torch_agent.py:428-551) with FBMSJointLoss (awesome/measures/fbms_joint_loss.py:35-59):
+    forward output, loss (rel 2e-5), d loss / d seg, and EVERY prior parameter after the Adam step + enforce_convexity.
+    The cdn oracle is PINNED (the reference's ConvexDiffeomorphismNet / FBMSJointLoss classes' fixtures); the pcn oracle restates
+    normflows 1.7.3's published definitions: parity UNPINNED for that variant."""
+    import awesome_amd as A
+    from awesome_amd import flow as FL
+    from awesome_amd import joint as J
+    from awesome_amd import rnvp as R
+    from awesome_amd.dataset import SyntheticPriorDataset
+    S, lr, alpha, beta = 256, 1e-3, 1.0, 2.0
+    torch.manual_seed(4)
+    ds = SyntheticPriorDataset(n_images=1, size=S, kind="noisy_blob")
+    (image, _, xy), target = ds[0]
+    seg = (1 - torch.sigmoid(image)).reshape(-1)                                  # WrapperModule: inverted sigmoid of the backbone's logits
+    rows = O.pixelize(xy[None])
+    if family == "pcn":
+        from tests.test_gpu_rnvp import _case, _merge, _split
+        ispec, dspec, sd = _case(2, 32, 12, 2, seed=12)
+        dspec = R.RnvpSpec(2, 32, 12, "tanh", None, (0.0, 0.0), (1.0, 1.0))
+        masks = O.rnvp_masks(2, 12)
+        fwd = lambda p: O.pcn_forward(p, rows, masks, torch.tensor(dspec.vmin), torch.tensor(dspec.vmax), output_fn="tanh", output_scale=None)  # noqa: E731
+        ip, fp = _split(ispec, dspec, sd, dev)
+        merge = lambda i, f: _merge(ispec, dspec, i, f)   # noqa: E731
+    else:
+        from awesome_amd.model import ConvexDiffeomorphismNet
+        torch.manual_seed(42)
+        net = ConvexDiffeomorphismNet(n_hidden=130, n_hidden_layers=2, nf_layers=6, nf_hidden=130, diffeo_args=dict(backbone="normal_block"))
+        sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        ispec, dspec = A.IcnnSpec(130, 2, 2), FL.FlowSpec(130, 6)
+        fwd = lambda p: O.convex_diffeo_forward(p, rows, 6)   # noqa: E731
+        i0, f0 = FL.split_cdn_state_dict(ispec, dspec, sd, dev)
+        ip, fp = i0[None].contiguous(), f0[None].contiguous()
+        merge = lambda i, f: FL.merge_cdn_state_dict(ispec, dspec, i, f)   # noqa: E731
+    clamp_keys = [k for k in sd if k.endswith("ln.weight")]      # enforce_convexity: hidden->hidden and hidden->out weights (convex_net.py:151-154, 216-220)
+    assert len(clamp_keys) == 3
+    # ---- the oracle's step: one Adam over the prior's parameters (the backbone's share is checked through d loss / d seg)
+    params = {k: torch.nn.Parameter(v.clone()) for k, v in sd.items() if v.is_floating_point() and not k.endswith("data_dep_init_done")}
+    full = dict(sd)
+    full.update(params)
+    seg_ref = seg.clone().requires_grad_(True)
+    opt = torch.optim.Adam(list(params.values()), lr=lr)
+    y = fwd(full)
+    out_ref = torch.cat([seg_ref.reshape(1, 1, S, S), torch.sigmoid(O.unpixelize(y, 1, S, S))], dim=1)
+    loss_ref = O.fbms_joint_loss(out_ref, target[None], alpha=alpha, beta=beta, kind="bce", mode="sssdms")
+    loss_ref.backward()
+    opt.step()
+    with torch.no_grad():
+        for k in clamp_keys:
+            params[k].clamp_(min=0)
+    # ---- the device's step
+    grid = A.Grid.explicit(xy.reshape(2, -1).to(dev).contiguous())
+    iopt = torch.zeros(2 * ispec.n_params + 8, device=dev)
+    fopt = torch.zeros(2 * dspec.n_params, device=dev)
+    desc = J.joint_desc(kind="bce", weight_mode="sssdms", alpha=alpha, beta=beta)
+    step = J.pcn_joint_step if family == "pcn" else J.cdn_joint_step
+    res = step(ispec, dspec, ip[0], fp[0], iopt, fopt, grid, seg.to(dev).contiguous(), target.reshape(-1).to(dev).contiguous(), desc, step=1, lr=lr)
+    assert int(res.status[0]) == 0
+    np.testing.assert_allclose(res.prior_logits.cpu().numpy(), y.detach().reshape(-1).numpy(), atol=3e-4, rtol=1e-3)
+    assert float(res.loss[0]) == pytest.approx(float(loss_ref.detach()), rel=2e-5)
+    g_ref = seg_ref.grad.numpy()
+    np.testing.assert_allclose(res.dseg.cpu().numpy(), g_ref, rtol=2e-4, atol=2e-6 * float(np.abs(g_ref).max()))
+    got = merge(ip[0].cpu(), fp[0].cpu())
+    worst, n_moved, n_loose = 0.0, 0, 0
+    gmax = max(float(p.grad.abs().max()) for p in params.values())
+    for k, p in params.items():
+        ref, new, g = p.detach().numpy(), got[k].numpy().reshape(p.shape), p.grad.numpy()
+        err = np.abs(new - ref)
+        worst = max(worst, float(err.max()))
+        n_moved += int((np.abs(ref - sd[k].numpy()) > 0).sum())
+        # Adam's FIRST step moves every parameter by lr * g / (|g| + eps): by lr in the gradient's direction whatever the gradient's
+        # size.  Where the gradient is above rounding level the two implementations agree to 2 % of that step; an entry whose
+        # gradient is at rounding level (|g| < 1e-4 of the model's largest; e.g. the 1x1 weight_v of a WNScale, whose gradient is
+        # exactly zero in exact arithmetic) may come out anywhere inside +-lr on either side
+        assert err.max() <= 2.0 * lr + 1e-7, k
+        loose = err > 0.02 * lr
+        n_loose += int(loose.sum())
+        assert np.all(np.abs(g[loose]) <= 1e-4 * gmax), (k, np.abs(g[loose]).max() / gmax, int(loose.sum()))
+    n_total = sum(p.numel() for p in params.values())
+    # (masked input columns of the RealNVP MLPs have an exactly zero gradient: Adam leaves them where they are, here and there)
+    assert n_moved > 0.5 * n_total and n_loose < 0.002 * n_total, (n_moved, n_loose, n_total)
+    print(f"\nconfigs[4] {family} joint step at 256x256: loss {float(res.loss[0]):.6f} vs {float(loss_ref.detach()):.6f}; max |d param| {worst:.2e} (lr {lr}), "
+          f"{n_loose} of {n_total} entries with rounding-level gradients outside 2 % of the step")

@@ -335,7 +335,17 @@ def test_unaries_conversion_loss_and_targets():
     crit = UnariesConversionLoss(SE("mean"))
     assert float(crit(out, tgt)) == pytest.approx(float(((out - (tgt >= 0.5).float()) ** 2).mean()))
     assert crit.get_name() == "UCMSE"
-    assert criterion_to_desc(crit) == ("se", "none", 1.0)
-    assert criterion_to_desc(UnariesConversionLoss(UnariesWeightedLoss(torch.nn.BCELoss(), mode="sssdms"))) == ("bce", "sssdms", 1.0)
+    # a caller that binarises its targets (the per-image fits) asks for the inner criterion's form; any other caller is refused
+    # (the composite losses' kernels read the targets as they are, so they take the torch composition instead)
+    assert criterion_to_desc(crit, "targets") == ("se", "none", 1.0)
+    assert criterion_to_desc(UnariesConversionLoss(UnariesWeightedLoss(torch.nn.BCELoss(), mode="sssdms")), "targets") == ("bce", "sssdms", 1.0)
+    with pytest.raises(TypeError):
+        criterion_to_desc(crit)
+    from awesome_amd.measures import AwesomeImageLoss, AwesomeLoss, FBMSJointLoss
+    assert FBMSJointLoss(criterion=crit).joint_desc() is None and AwesomeImageLoss(criterion=crit).joint_desc() is None
+    assert AwesomeLoss(criterion=crit).joint_desc(10) is None and FBMSJointLoss().joint_desc() is not None
+    soft_out = torch.rand(1, 2, 5, 7)
+    want = SE("mean")(soft_out[:, :1], (tgt[:1] >= 0.5).float()) + SE("mean")(soft_out[:, 1:], soft_out[:, :1])
+    assert float(FBMSJointLoss(criterion=crit, clip_penalty=False)(soft_out, tgt[:1])) == pytest.approx(float(want), rel=1e-6)
     assert torch.equal(criterion_targets(crit, tgt), (tgt >= 0.5).float())
     assert criterion_targets(SE("mean"), tgt) is tgt

@@ -132,6 +132,41 @@ def gen_fbms_joint_loss(ref, out):
     np.savez_compressed(os.path.join(out, "fbms_joint_loss.npz"), **rec)
 
 
+def gen_weighted_loss_noneclass(ref, out):
+    """WeightedLoss on CLASS labels with a `noneclass` (awesome/measures/weighted_loss.py:11-92) - the criterion of 153 of the
+    reference's FBMSJointLoss configs: WeightedLoss(BCELoss, mode sssdms, noneclass 2) - alone (three modes x two criteria) and inside
+    FBMSJointLoss (value + gradient w.r.t. both output channels, both clip branches)."""
+    import awesome.measures.weighted_loss as wl
+    rng = np.random.RandomState(17)
+    B, H, W = 2, 12, 15
+    out_t = torch.from_numpy(rng.uniform(0.03, 0.97, size=(B, 2, H, W)).astype(np.float32))
+    lab = rng.uniform(size=(B, 1, H, W))
+    tgt = torch.from_numpy(np.where(lab < 0.07, 0.0, np.where(lab < 0.55, 1.0, 2.0)).astype(np.float32))   # few fg, ~45 % unlabeled
+    rec = dict(output=out_t.numpy(), target=tgt.numpy())
+    for kind in ("bce", "se"):
+        for mode in ("none", "sssdms", "equal"):
+            inner = torch.nn.BCELoss() if kind == "bce" else ref.se.SE("mean")
+            for nc in (None, 2.0):
+                crit = wl.WeightedLoss(inner, mode=mode, noneclass=nc)
+                o = out_t[:, :1].clone().requires_grad_(True)
+                t = tgt if nc is not None else torch.where(tgt == 2.0, torch.ones_like(tgt), tgt)
+                loss = crit(o, t)
+                loss.backward()
+                tag = f"{kind}.{mode}.{'nc2' if nc is not None else 'all'}"
+                rec[tag + ".loss"] = np.float32(loss.item())
+                rec[tag + ".grad"] = o.grad.numpy().copy()
+    for case, beta in enumerate((1.0, 300.0)):
+        crit = ref.fbms.FBMSJointLoss(criterion=wl.WeightedLoss(torch.nn.BCELoss(), mode="sssdms", noneclass=2), alpha=1.0, beta=beta)
+        o = out_t.clone().requires_grad_(True)
+        loss = crit(o, tgt)
+        loss.backward()
+        rec[f"fbms{case}.beta"] = np.float32(beta)
+        rec[f"fbms{case}.loss"] = np.float32(loss.item())
+        rec[f"fbms{case}.grad"] = o.grad.numpy().copy()
+        print("fbms + WeightedLoss(noneclass 2) case", case, float(loss))
+    np.savez_compressed(os.path.join(out, "weighted_loss_noneclass.npz"), **rec)
+
+
 def gen_wrapper(ref, out):
     """WrapperModule(ForwardModule, ConvexNextNet) forward (fixture 4b): image mode, param_clean_grid; with and without the
     segmentation inversion; evaluate_prior off (what the pretrain loop reads the unaries from)."""
@@ -383,6 +418,9 @@ def main():
     ref = _import_reference()
     if args.only == "wrapper_pixel":
         return gen_wrapper_pixel(ref, args.out)
+    if args.only == "weighted_loss_noneclass":
+        return gen_weighted_loss_noneclass(ref, args.out)
+    gen_weighted_loss_noneclass(ref, args.out)
     gen_wrapper_pixel(ref, args.out)
     gen_encode_notebooks(args.out)
     gen_teaser_rotation_symmetric(args.out)
