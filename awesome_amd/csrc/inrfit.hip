@@ -837,7 +837,6 @@ static int wide_prepare(const InrModelDesc* model, const InrGridDesc* grid, int 
         return INR_EINVAL;
     }
     if (model->act0 < INR_ACT_RELU || model->act0 > INR_ACT_SIN) return INR_EINVAL;
-    if (!wide_blas().ok) return INR_EUNSUPPORTED;   // rocBLAS could not be opened: this shape has no path on this box
     *m = make_wide_map(model->n_hidden, model->in_features, model->n_layers);
     const bool pre0 = model->act0 != INR_ACT_RELU;
     if (workspace_bytes < wide_total_bytes(*m, grid->n_points, pre0, n_images)) return INR_EWORKSPACE;
@@ -2326,7 +2325,6 @@ static int check_star(const InrStarDesc* star, int64_t n_points, void* workspace
     *m = make_star_map(star->n_hidden);
     *w = carve_star(star->n_hidden, n_points, workspace);
     if (workspace_bytes < w->bytes) return INR_EWORKSPACE;
-    if (!wide_blas().ok) return INR_EUNSUPPORTED;   // rocBLAS could not be opened
     return INR_OK;
 }
 

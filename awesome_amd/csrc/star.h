@@ -10,7 +10,7 @@
 // The read-out takes two layers at once (x_old AND r_aug) and the logit is scaled per point by r: neither is in the layer chain of the
 // fused ICNN step kernels.  The notebook trains on 1000-pixel minibatches (500 background + 500 foreground pixels drawn per epoch),
 // i.e. 1000 x h activations per layer - a launch-bound problem, not an MFMA-bound one.  It therefore runs layer by layer like wide.h:
-// activations of the minibatch in HBM ([batch][h] row-major), the three h x h contractions as plain rocBLAS GEMMs (atomics off), and
+// activations of the minibatch in HBM ([batch][h] row-major), the three h x h contractions as the fp32-MFMA GEMMs of csrc/gemm.h (the minibatch contraction in slices added in order), and
 // everything else hand-written below: the polar split with layer 0, the epilogues, read-out + sigmoid + MSE + dL/dout, the relu masks
 // of the backward pass, fixed-order column and point reductions, the gradient of the centre, torch's single-tensor Adam with the
 // projection.  Twelve launches per optimizer step, none of them synchronises with the host; the minibatch indices of every epoch are an
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void star_update_kernel(const StarUpdArgs u) {
 
 // ---- workspace ---------------------------------------------------------------------------------------------------------------------------
 struct StarWs {
-    float *feat, *A0, *A1, *D1, *D0, *ds, *drd, *partial, *offp, *colp, *gW1, *scal;
+    float *feat, *A0, *A1, *D1, *D0, *ds, *drd, *partial, *offp, *colp, *gW1, *gpart, *scal;
     int nb4;           // blocks of the one-wave-per-point kernels
     long long bytes;
 };
@@ -331,6 +331,7 @@ inline StarWs carve_star(int h, long long N, void* base) {
     w.offp = take((long long)w.nb4 * 2 * 4);
     w.colp = take((long long)STAR_CHUNKS * STAR_COLQ * h * 4);
     w.gW1 = take((long long)h * h * 4);
+    w.gpart = take((long long)GEMM_SPLITK_MAX * h * h * 4);   // slices of the minibatch contraction (gemm_rm_splitk)
     w.scal = take(256);
     w.bytes = off;
     return w;
@@ -362,7 +363,7 @@ inline int star_backward_pass(const StarMap& m, const StarWs& w, const float* pr
     int rc = gemm_rm(s, false, false, (int)N, h, h, w.D1, h, prm + m.p_w1(), h, w.D0, h);     // D1 W1
     if (rc) return rc;
     hipLaunchKernelGGL(star_bwd0_kernel, star_elem_grid(N, h), dim3(256), 0, s, prm, m, (const float*)w.ds, (const float*)w.A0, N, w.D0);
-    if ((rc = gemm_rm(s, true, false, h, h, (int)N, w.D1, h, w.A0, h, w.gW1, h))) return rc;   // dW1 = D1^T x_old
+    if ((rc = gemm_rm_splitk(s, true, false, h, h, (int)N, w.D1, h, w.A0, h, w.gW1, w.gpart))) return rc;   // dW1 = D1^T x_old, slices added in order
     hipLaunchKernelGGL(star_col_kernel, dim3((h + 31) / 32, STAR_CHUNKS), dim3(256), 0, s, m, (const float*)w.feat, (const float*)w.ds,
                        (const float*)w.A0, (const float*)w.A1, (const float*)w.D0, (const float*)w.D1, N, w.colp);
     hipLaunchKernelGGL(star_point_kernel, dim3(w.nb4), dim3(256), 0, s, prm, m, (const float*)w.feat, (const float*)w.drd,

@@ -426,7 +426,7 @@ int inrfit_debug_tanh_exp(const float* x, int64_t n, float* tanh_out, float* exp
  *   offset[2] | W0.weight[h][2] | W0.bias[h] | W1.weight[h][h] | W1.bias[h] | W2.weight[h] | W2.bias | W1_r.weight[h] | W1_r.bias[h] |
  *   W2_r.weight[h] | W2_r.bias                                                      (inrfit_star_param_count = h^2 + 8 h + 4)
  * coords: [n_pixels][2] row-major (the notebook's pixel_info), labels [n_pixels]; 1 <= n_hidden <= 1024.  Layer-by-layer kernels with
- * rocBLAS for the h x h contractions (csrc/star.h); results reproducible run to run. */
+ * the hand-written fp32-MFMA GEMMs of csrc/gemm.h for the h x h contractions (csrc/star.h); results reproducible run to run. */
 typedef struct InrStarDesc {
     int32_t n_hidden;
 } InrStarDesc;

@@ -17,7 +17,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 S, E = 256, 2000
-FLOOR_FACTOR = 2.0     # per-image bar = FLOOR_FACTOR x the reference's own largest run-to-run |dIoU| (floored at 2e-3)
+FLOOR_FACTOR = 2.0     # per-image bar = FLOOR_FACTOR x the reference's own largest run-to-run difference of the same statistic
 
 
 @pytest.fixture(scope="module")
@@ -39,49 +39,104 @@ def _hist(d, edges=(0.0, 1e-4, 3e-4, 1e-3, 3e-3, 1e-2, 1.0)):
     return np.histogram(np.asarray(d), edges)[0].tolist()
 
 
-def test_configs2_batched_fit_against_the_reference_classes(amd, golden_dir):
-    """One device call fits the 16 reference-fitted images of configs[2] (plus 48 more, so that the launch is configs[2]'s per-GPU share
-    of 64 images with 4 gradient slabs each), and every image alone (256 slabs): dataset-mean fg-mIoU within 1e-3 of the reference's
-    mean (both reference runs), per-image |dIoU| within FLOOR_FACTOR x the reference's own run-to-run floor, early loss curves equal."""
-    from tests.test_gpu_determinism import _mask_iou, _problem
-    za, zb, seeds = _multi(golden_dir)
-    assert len(seeds) >= 16 and seeds[:16] == list(range(16))
-    n_ref = len(seeds)
-    ra = np.array([float(za[f"s{s}.final_miou"]) for s in seeds])
-    rb = np.array([float(zb[f"s{s}.final_miou"]) for s in seeds])
-    floor = float(np.abs(ra - rb).max())
-    bar = FLOOR_FACTOR * max(floor, 2e-3)
-    spec, init, grid, un = _problem(amd, seeds=tuple(range(64)))
-    res = amd.fit(spec, init.clone(), grid, un, E, lr=2e-3, record_loss=True, want_logits=True)
+def _tail_fit(amd, spec, init, grid, un, tail):
+    """The 2000-step fit with the outputs of its last `tail` TRAINING forwards (the tensors the reference's loop holds at steps
+    E - tail .. E - 1): one call for E - tail steps, then `tail` one-step calls that continue it (same optimizer state, step count) and
+    return the logits of that step's forward.  -> (final result, per-step fg-mIoU [tail, n], mean probability [n, N], losses [n, E])."""
+    res = amd.fit(spec, init.clone(), grid, un, E - tail, lr=2e-3, record_loss=True, want_logits=False)
+    losses, psum, per_step = [res.loss_hist], torch.zeros_like(un), []
+    gt = (un > 0.5).float()
+    for k in range(tail):
+        res = amd.fit(spec, res.params, grid, un, 1, lr=2e-3, opt_state=res.opt_state, step0=E - tail + k, record_loss=True,
+                      want_logits=True, gate_logits=True)
+        prob = torch.sigmoid(res.logits)
+        psum += prob
+        per_step.append(amd.miou((prob > 0.5).float(), gt, invert=True))
+        losses.append(res.loss_hist)
     assert int(res.status.sum()) == 0
-    mask, iou = _mask_iou(amd, res, un)
-    hip = iou[:n_ref].cpu().numpy().astype(np.float64)
-    # the early trajectory is THE reference's trajectory (the first 100 losses of every image, both runs agree there too)
-    for k, s in enumerate(seeds):
-        np.testing.assert_allclose(res.loss_hist[k, :100].cpu().numpy(), za[f"s{s}.losses"][:100], rtol=1e-3, err_msg=f"seed {s}")
-    d = np.minimum(np.abs(hip - ra), np.abs(hip - rb))
-    print(f"\nconfigs[2] batched vs reference over {n_ref} images: mean mIoU hip {hip.mean():.5f} ref a {ra.mean():.5f} b {rb.mean():.5f}; "
-          f"|dIoU| hist hip-vs-ref {_hist(d)} ref-vs-ref {_hist(np.abs(ra - rb))} (bins 0,1e-4,3e-4,1e-3,3e-3,1e-2); "
-          f"max hip {d.max():.2e} floor {floor:.2e}")
-    assert abs(hip.mean() - ra.mean()) <= 1e-3 and abs(hip.mean() - rb.mean()) <= 1e-3, (hip.mean(), ra.mean(), rb.mean())
-    assert d.max() <= bar, (d.max(), bar, floor)
-    assert np.median(d) <= max(np.median(np.abs(ra - rb)) * FLOOR_FACTOR, 5e-4)
-    # masks: a handful of boundary pixels (the reference's two runs differ from each other by about as many)
-    for k, s in enumerate(seeds):
-        m_ref = np.unpackbits(za[f"s{s}.final_mask_bits"])[: S * S].astype(bool)
-        m_ref_b = np.unpackbits(zb[f"s{s}.final_mask_bits"])[: S * S].astype(bool)
-        diff = int((mask[k].cpu().numpy() != m_ref).sum())
-        assert diff <= max(3 * int((m_ref != m_ref_b).sum()), int(0.004 * S * S)), (s, diff)
-    # every image alone (its own slab count): the same bars
-    single = []
+    return res, torch.stack(per_step), psum / tail, torch.cat(losses, 1)
+
+
+def _final_iou(amd, spec, res, grid, un):
+    """fg-mIoU of the mask at the FINAL parameters (the reference's `final_miou`: a forward after the last optimizer step)."""
+    prob = torch.sigmoid(amd.forward(spec, res.params, grid))
+    return amd.miou((prob > 0.5).float(), (un > 0.5).float(), invert=True)
+
+
+def test_configs2_batched_fit_against_the_reference_classes(amd, golden_dir):
+    """configs[2] against the REFERENCE CLASSES' own fits, per image, with a statistic that can fail.
+
+    The end-of-fit snapshot cannot discriminate: full-batch Adam at lr 2e-3 spikes, and two runs of the reference itself (3 and 2 OpenMP
+    threads) end up to 6.5e-3 of fg-mIoU apart on the same image.  What both reference runs DO agree on, to 2.9e-4 over the 16 images,
+    are spike-robust statistics of the fit's last TAIL = 50 training forwards, recorded in the fixtures by tools/gen_golden_scale.py:
+      * tailmean: fg-mIoU of the mask of the MEAN probability over the tail,
+      * tailbest: the best per-step fg-mIoU of the tail (what an IoU gate polling the last steps would accept).
+    Asserted, for the batched fit (16 reference-fitted images + 48 more = configs[2]'s per-GPU share of 64, 4 gradient slabs per image)
+    AND for every image fitted alone (256 slabs): per image both statistics within FLOOR_FACTOR x the reference's own run-to-run
+    difference of that statistic (~6e-4: below north_star's 1e-3), the tail-mean mask within a handful of pixels, the dataset means
+    within 1e-3 (also for the end-of-fit snapshot, the number the reference reports), and the head of every loss curve.  Printed: the
+    step-wise divergence of the device fit from reference run a next to the reference's own a-vs-b divergence (fixture keys `ab.*`)."""
+    from tests.test_gpu_determinism import _problem
+    za, zb, seeds = _multi(golden_dir)
+    assert len(seeds) >= 16 and seeds[:16] == list(range(16)) and int(za["tail"]) == 50
+    n_ref, TAIL = len(seeds), int(za["tail"])
+    ref = {st: (np.array([float(za[f"s{s}.{st}"]) for s in seeds]), np.array([float(zb[f"s{s}.{st}"]) for s in seeds]))
+           for st in ("final_miou", "tailmean_miou", "tailbest_miou")}
+    floor = {st: float(np.abs(a - b).max()) for st, (a, b) in ref.items()}
+    assert floor["tailmean_miou"] < 1e-3 and floor["tailbest_miou"] < 1e-3 < floor["final_miou"]     # why the snapshot is not the bar
+    spec, init, grid, un = _problem(amd, seeds=tuple(range(64)))
+    div_steps = [int(t) for t in za["ab.div_steps"]]
+
+    def check(tag, per_step, pmean, final_iou, losses, un_k, idx):
+        """idx: positions (in `seeds`) of the images in this launch"""
+        gt = (un_k > 0.5).float()
+        tm = amd.miou((pmean > 0.5).float(), gt, invert=True).cpu().numpy().astype(np.float64)
+        tb = per_step.max(0).values.cpu().numpy().astype(np.float64)
+        got = {"tailmean_miou": tm, "tailbest_miou": tb, "final_miou": final_iou.cpu().numpy().astype(np.float64)}
+        out = {}
+        for st in ("tailmean_miou", "tailbest_miou"):
+            a, b = ref[st][0][idx], ref[st][1][idx]
+            d = np.minimum(np.abs(got[st] - a), np.abs(got[st] - b))
+            out[st] = d
+            assert d.max() <= FLOOR_FACTOR * floor[st] + 1e-6, (tag, st, d.max(), floor[st], got[st], a, b)
+        for k, i in enumerate(idx):   # the tail-mean mask against the nearer reference run's
+            m = (pmean[k] > 0.5).cpu().numpy().reshape(-1)
+            ma = np.unpackbits(za[f"s{seeds[i]}.tailmean_mask_bits"])[: S * S].astype(bool)
+            mb = np.unpackbits(zb[f"s{seeds[i]}.tailmean_mask_bits"])[: S * S].astype(bool)
+            assert min(int((m != ma).sum()), int((m != mb).sum())) <= max(2 * int((ma != mb).sum()), 12), (tag, seeds[i])
+            np.testing.assert_allclose(losses[k, :100].cpu().numpy(), za[f"s{seeds[i]}.losses"][:100], rtol=1e-3, err_msg=f"{tag} seed {seeds[i]}")
+        return got, out
+
+    # ---- one launch of 64 images
+    res, per_step, pmean, losses = _tail_fit(amd, spec, init, grid, un, TAIL)
+    final_iou = _final_iou(amd, spec, res, grid, un)
+    idx = np.arange(n_ref)
+    got, dist = check("batched", per_step[:, :n_ref], pmean[:n_ref], final_iou[:n_ref], losses[:n_ref], un[:n_ref], idx)
+    div = np.array([[abs(float(losses[k, t]) - float(za[f"s{seeds[k]}.losses"][t])) / float(za[f"s{seeds[k]}.losses"][t]) for t in div_steps]
+                    for k in range(n_ref)])
+    print(f"\nconfigs[2], {n_ref} images of one 64-image launch vs the reference classes' two runs (floors: "
+          + ", ".join(f"{k} {v:.1e}" for k, v in floor.items()) + ")")
+    for st in ("tailmean_miou", "tailbest_miou"):
+        print(f"  {st:14s}: max |d| to the nearer reference run {dist[st].max():.2e}  hist {_hist(dist[st])}  mean hip {got[st].mean():.5f} "
+              f"ref a {ref[st][0].mean():.5f} b {ref[st][1].mean():.5f}")
+    print(f"  final snapshot: mean hip {got['final_miou'].mean():.5f} ref a {ref['final_miou'][0].mean():.5f} b {ref['final_miou'][1].mean():.5f}; "
+          f"max |d| {np.minimum(np.abs(got['final_miou'] - ref['final_miou'][0]), np.abs(got['final_miou'] - ref['final_miou'][1])).max():.2e} "
+          f"(reference a vs b: {floor['final_miou']:.2e})")
+    print("  step-wise rel. loss divergence at steps", div_steps)
+    print("    device vs reference a, median", np.median(div, 0).round(6).tolist(), "max", div.max(0).round(5).tolist())
+    print("    reference a vs b,      median", np.median(za["ab.div_rel_loss"], 0).round(6).tolist(), "max", za["ab.div_rel_loss"].max(0).round(5).tolist())
+    for st in ("final_miou", "tailmean_miou", "tailbest_miou"):
+        for r in ref[st]:
+            assert abs(got[st].mean() - r.mean()) <= 1e-3, (st, got[st].mean(), r.mean())
+    # ---- every image alone (its own slab count): the same bars
+    tm1, tb1, fin1 = [], [], []
     for k in range(n_ref):
-        r1 = amd.fit(spec, init[k:k + 1].clone(), grid, un[k:k + 1], E, lr=2e-3, record_loss=False, want_logits=True)
-        single.append(float(_mask_iou(amd, r1, un[k:k + 1])[1][0]))
-    single = np.asarray(single)
-    d1 = np.minimum(np.abs(single - ra), np.abs(single - rb))
-    print(f"single-image fits vs reference: mean {single.mean():.5f}; |dIoU| hist {_hist(d1)}; max {d1.max():.2e}")
-    assert abs(single.mean() - ra.mean()) <= 1e-3 and abs(single.mean() - rb.mean()) <= 1e-3
-    assert d1.max() <= bar, (d1.max(), bar)
+        r1, ps1, pm1, l1 = _tail_fit(amd, spec, init[k:k + 1], grid, un[k:k + 1], TAIL)
+        g1, _ = check(f"single {k}", ps1, pm1, _final_iou(amd, spec, r1, grid, un[k:k + 1]), l1, un[k:k + 1], np.array([k]))
+        tm1.append(g1["tailmean_miou"][0]); tb1.append(g1["tailbest_miou"][0]); fin1.append(g1["final_miou"][0])
+    print(f"  single-image fits: tailmean mean {np.mean(tm1):.5f} tailbest mean {np.mean(tb1):.5f} final mean {np.mean(fin1):.5f}")
+    for r in ref["final_miou"]:
+        assert abs(np.mean(fin1) - r.mean()) <= 1e-3
 
 
 def test_convex_diffeomorphism_net_full_size_fit_against_the_reference_class(amd, golden_dir):
@@ -114,7 +169,7 @@ def test_convex_diffeomorphism_net_full_size_fit_against_the_reference_class(amd
     d = min(abs(gate - r) for r in refs)
     print(f"\nCDN 256x256 K6 w130 L2: gate mIoU hip {gate:.5f} reference {refs} (floor {floor:.2e}); final loss hip {h[-1]:.3e} "
           f"reference {float(z['losses'][-1]):.3e}")
-    assert d <= max(FLOOR_FACTOR * floor, 5e-3), (gate, refs)
+    assert d <= FLOOR_FACTOR * max(floor, 5.6e-4), (gate, refs)   # 2 x the reference's own measured floor (was 5e-3)
     assert h[-1] <= 3.0 * float(z["losses"][-1]) and float(z["losses"][-1]) <= 3.0 * h[-1]
     m_ref = np.unpackbits(z["gate_mask_bits"])[: S * S].astype(bool)
     m_hip = (torch.sigmoid(res.logits[0]) > 0.5).cpu().numpy()

@@ -21,6 +21,8 @@
 
 Nothing in the product imports this file; the reference never travels - only the .npz files do.
 Usage:  python tools/gen_golden_scale.py multi --tag a --threads 3 --seeds 16
+        python tools/gen_golden_scale.py multi --tag b --threads 2 --seeds 16
+        python tools/gen_golden_scale.py finalize
         python tools/gen_golden_scale.py cdn --threads 3
 """
 import argparse
@@ -96,6 +98,31 @@ def gen_multi(out, tag, threads, n_seeds, first=0):
               f"tailbest {max(tail):.5f} loss {losses[-1]:.3e} ({time.time() - t0:.0f} s)", flush=True)
 
 
+DIV_STEPS = (1, 3, 10, 30, 100, 300, 1000, 1999)
+
+
+def finalize_multi(out):
+    """After both runs: the step-wise divergence of the reference FROM ITSELF (hard part 1) - relative loss
+    difference |loss_a - loss_b| / loss_a at DIV_STEPS, per image - and the run-to-run floors of every end-of-fit statistic, written
+    into run a's file (`ab.*` keys).  This is what a per-image bar of the device fit can be set against."""
+    pa, pb = (os.path.join(out, f"fits_blob256_multi_{t}.npz") for t in "ab")
+    za, zb = dict(np.load(pa)), np.load(pb)
+    seeds = sorted(int(k[1:].split(".")[0]) for k in za if k.endswith(".final_miou") and k in zb.files)
+    div = np.array([[abs(float(za[f"s{s}.losses"][t]) - float(zb[f"s{s}.losses"][t])) / float(za[f"s{s}.losses"][t]) for t in DIV_STEPS]
+                    for s in seeds], dtype=np.float32)
+    za["ab.seeds"] = np.asarray(seeds, np.int32)
+    za["ab.div_steps"] = np.asarray(DIV_STEPS, np.int32)
+    za["ab.div_rel_loss"] = div                                          # [n_seeds, len(DIV_STEPS)]
+    for stat in ("final_miou", "tailmean_miou", "tailbest_miou"):
+        d = np.array([abs(float(za[f"s{s}.{stat}"]) - float(zb[f"s{s}.{stat}"])) for s in seeds], dtype=np.float32)
+        za[f"ab.absdiff.{stat}"] = d
+        print(f"[finalize] reference run a vs run b, {stat:14s}: max {d.max():.2e} median {np.median(d):.2e}  "
+              f"mean a {np.mean([float(za[f's{s}.{stat}']) for s in seeds]):.5f} b {np.mean([float(zb[f's{s}.{stat}']) for s in seeds]):.5f}")
+    print("[finalize] rel. loss divergence a vs b at steps", DIV_STEPS, ": median", np.median(div, 0).round(6).tolist(), "max", div.max(0).round(6).tolist())
+    np.savez_compressed(pa + ".tmp.npz", **za)
+    os.replace(pa + ".tmp.npz", pa)
+
+
 def gen_cdn(out, threads, tag=""):
     import gen_golden as G
     import gen_golden_boundary as GB
@@ -147,14 +174,16 @@ def gen_cdn(out, threads, tag=""):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["multi", "cdn"])
+    ap.add_argument("what", choices=["multi", "cdn", "finalize"])
     ap.add_argument("--out", default=os.path.join(HERE, "..", "tests", "golden"))
     ap.add_argument("--tag", default="a")
     ap.add_argument("--threads", type=int, default=3)
     ap.add_argument("--seeds", type=int, default=16)
     ap.add_argument("--first", type=int, default=0)
     a = ap.parse_args()
-    if a.what == "multi":
+    if a.what == "finalize":
+        finalize_multi(a.out)
+    elif a.what == "multi":
         gen_multi(a.out, a.tag, a.threads, a.seeds, a.first)
     else:
         gen_cdn(a.out, a.threads, "" if a.tag == "a" else "_" + a.tag)
