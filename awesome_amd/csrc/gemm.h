@@ -51,7 +51,7 @@ struct GemmArgs {
     const float* mask;     // MASK: multiply by [mask[m * mask_ld + n] > 0] (mask_act == relu) or by the activation's derivative at it
     int mask_ld, mask_act;
     float omega;
-    int vecA, vecB;        // operands allow 16-byte loads (base and row stride multiples of 4 floats)
+    int vecA, vecB;        // widest aligned load of the operand: 4 floats (base and row stride multiples of 16 bytes), 2, or 1
 };
 
 template <bool TA, bool TB>
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * GM_BM, n0 = blockIdx.y * GM_BN;
+    const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;   // n fastest: the column tiles of one row tile run together and share its A rows in L2
     const int k_lo = blockIdx.z * a.k_per_split;
     const int k_hi = min(a.K, k_lo + a.k_per_split);
     const int steps = (k_hi - k_lo + GM_BK - 1) / GM_BK;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
     // ---- global -> registers: every thread owns 8 consecutive floats of each operand tile -----------------------------------------
     // operand contiguous along k: tile [128 rows][16 k], thread -> row tid >> 1, k offset (tid & 1) * 8
     // operand contiguous along its free index: tile [16 k][128], thread -> k row tid >> 4, offset (tid & 15) * 8
-    auto load8 = [&](const float* base, int ld, bool kcontig, int row0, int rows, int kbase, bool vec, f32x4 (&v)[2]) {
+    auto load8 = [&](const float* base, int ld, bool kcontig, int row0, int rows, int kbase, int vec, f32x4 (&v)[2]) {
         int r, c;          // r: index along the slow (row) dimension of the STORED matrix, c: along its contiguous dimension
         bool rok;
         int cmax;
@@ -88,8 +88,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int cc = c + 4 * h;
-            if (rok && vec && cc + 3 < cmax) {
+            if (rok && vec == 4 && cc + 3 < cmax) {
                 v[h] = *(const f32x4*)(p + 4 * h);
+            } else if (rok && vec == 2 && cc + 3 < cmax) {   // rows on 8-byte boundaries (an even row length, e.g. 350)
+                const f32x2 lo = *(const f32x2*)(p + 4 * h), hi = *(const f32x2*)(p + 4 * h + 2);
+                v[h] = f32x4{lo[0], lo[1], hi[0], hi[1]};
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[h][e] = (rok && cc + e < cmax) ? p[4 * h + e] : 0.f;
@@ -110,8 +113,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
 
     f32x4 ra[2], rb[2];
     if (steps > 0) {
-        load8(a.A, a.lda, !TA, m0, a.M, k_lo, a.vecA != 0, ra);
-        load8(a.B, a.ldb, TB, n0, a.N, k_lo, a.vecB != 0, rb);
+        load8(a.A, a.lda, !TA, m0, a.M, k_lo, a.vecA, ra);
+        load8(a.B, a.ldb, TB, n0, a.N, k_lo, a.vecB, rb);
         store8(As[0], !TA, ra);
         store8(Bs[0], TB, rb);
     }
@@ -119,8 +122,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
     for (int s = 0; s < steps; ++s) {
         const int cur = s & 1;
         if (s + 1 < steps) {   // next step's tiles: in flight while this step multiplies
-            load8(a.A, a.lda, !TA, m0, a.M, k_lo + (s + 1) * GM_BK, a.vecA != 0, ra);
-            load8(a.B, a.ldb, TB, n0, a.N, k_lo + (s + 1) * GM_BK, a.vecB != 0, rb);
+            load8(a.A, a.lda, !TA, m0, a.M, k_lo + (s + 1) * GM_BK, a.vecA, ra);
+            load8(a.B, a.ldb, TB, n0, a.N, k_lo + (s + 1) * GM_BK, a.vecB, rb);
         }
         const float* sa = As[cur];
         const float* sb = Bs[cur];
@@ -229,7 +232,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
     }
 }
 
-inline bool gemm_vec_ok(const float* p, int ld) { return (((size_t)p) & 15) == 0 && (ld & 3) == 0; }
+inline int gemm_vec_width(const float* p, int ld) {
+    if ((((size_t)p) & 15) == 0 && (ld & 3) == 0) return 4;
+    if ((((size_t)p) & 7) == 0 && (ld & 1) == 0) return 2;
+    return 1;
+}
 
 // row-major C[M x N] = op(A) op(B); `splits` > 1 cuts K into that many z-slices of k_per_split (multiple of 16) writing
 // C + z * c_split_stride.  Returns INR_OK / INR_ELAUNCH.
@@ -237,9 +244,9 @@ inline int gemm_launch(hipStream_t s, bool tA, bool tB, GemmArgs g) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return INR_EINVAL;
     if (g.k_per_split <= 0) g.k_per_split = (g.K + GM_BK - 1) / GM_BK * GM_BK;
     const int splits = (g.K + g.k_per_split - 1) / g.k_per_split;
-    g.vecA = gemm_vec_ok(g.A, g.lda) ? 1 : 0;
-    g.vecB = gemm_vec_ok(g.B, g.ldb) ? 1 : 0;
-    const dim3 grid((g.M + GM_BM - 1) / GM_BM, (g.N + GM_BN - 1) / GM_BN, splits);
+    g.vecA = gemm_vec_width(g.A, g.lda);
+    g.vecB = gemm_vec_width(g.B, g.ldb);
+    const dim3 grid((g.N + GM_BN - 1) / GM_BN, (g.M + GM_BM - 1) / GM_BM, splits);
     if (!tA && tB) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, s, g);
     else if (!tA && !tB) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, s, g);
     else if (tA && !tB) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, s, g);

