@@ -387,6 +387,60 @@ class RegularizerLoss:
         return self.name or type(self).__name__
 
 
+class GradientPenaltyLoss:
+    """awesome/measures/gradient_penalty_loss.py:10-118 (the criterion of the CNNNet convexity configs): the inner criterion on the pixels
+    whose target is not `noneclass`, plus - while `apply_gradient_penalty` is on and the step's `_input` = (image, xy / features, ...)
+    is handed in - penalties on the mean absolute gradient of sum(output) w.r.t. the coordinates / semantic features (`xygrad`,
+    `featgrad`, split by `xytype`) and w.r.t. the image (`rgbgrad`), differentiated through (create_graph).  The penalties are
+    second-order autograd through the SEGMENTATION network: torch ops on whatever device the tensors live on, no kernel form (the
+    inputs must require grad, `dataset_args.model_input_requires_grad` in the reference's configs)."""
+
+    def __init__(self, criterion=None, apply_gradient_penalty: bool = False, xygrad: float = 0.0, rgbgrad: float = 0.0,
+                 featgrad: float = 0.0, xytype: str = "xy", noneclass: Optional[float] = None, name: Optional[str] = None, **kwargs):
+        if xytype not in ("xy", "feat", "featxy", "edge"):
+            raise ValueError(f"xytype must be one of [xy, feat, featxy, edge] but is {xytype}")
+        if criterion is None:
+            raise ValueError("criterion must not be None")
+        self.name, self.criterion = name, criterion
+        self.xygrad, self.rgbgrad, self.featgrad, self.xytype = xygrad, rgbgrad, featgrad, xytype
+        self.apply_gradient_penalty, self.noneclass = apply_gradient_penalty, noneclass
+
+    def __call__(self, output: torch.Tensor, target: torch.Tensor, _input=None, **kwargs) -> torch.Tensor:
+        original_output = output
+        if self.noneclass is not None:
+            keep = target != self.noneclass
+            output, target = output[keep], target[keep]
+        takes_kwargs = not isinstance(self.criterion, torch.nn.modules.loss._Loss)
+        loss = self.criterion(output, target, **(kwargs if takes_kwargs else {}))
+        if not self.apply_gradient_penalty:
+            return loss
+        if _input is None:
+            raise ValueError("GradientPenaltyLoss needs _input to apply gradient penalty")
+        img, raw_xy = _input[0], _input[1]
+        output_sum = torch.sum(original_output)
+        if self.xygrad > 0.0 or self.featgrad > 0.0:
+            grad_raw = torch.autograd.grad(output_sum, raw_xy, retain_graph=True, create_graph=True)[0]
+            mean_xy = mean_feat = None
+            if self.xytype == "feat":
+                mean_feat = torch.mean(torch.abs(grad_raw))
+            elif self.xytype == "xy":
+                mean_xy = torch.mean(torch.abs(grad_raw))
+            elif self.xytype == "featxy":
+                mean_xy = torch.mean(torch.abs(grad_raw[:, :2, ...]))
+                mean_feat = torch.mean(torch.abs(grad_raw[:, 2:, ...]))   # semantic features are the last channels
+            if self.xygrad > 0.0 and mean_xy is not None:
+                loss = loss + self.xygrad * mean_xy
+            if self.featgrad > 0.0 and mean_feat is not None:
+                loss = loss + self.featgrad * mean_feat
+        if self.rgbgrad > 0.0:
+            grad_rgb = torch.autograd.grad(output_sum, img, retain_graph=True, create_graph=True)[0]
+            loss = loss + self.rgbgrad * torch.mean(torch.abs(grad_rgb))
+        return loss
+
+    def get_name(self) -> str:
+        return self.name or type(self).__name__
+
+
 class AwesomeImageLossJoint:
     """awesome/measures/awesome_image_loss_joint.py:11-70 (the `segmentation_training_mode: multi` convexity configs): the same data
     terms as AwesomeImageLoss with ONE criterion for both channels; the alignment term is `mean((prior - seg)^2)` - on the soft

@@ -57,6 +57,7 @@ ALIASES: Dict[str, str] = {
     "awesome.measures.awesome_loss_joint.AwesomeLossJoint": "awesome_amd.measures.AwesomeLossJoint",
     "awesome.measures.awesome_image_loss_joint.AwesomeImageLossJoint": "awesome_amd.measures.AwesomeImageLossJoint",
     "awesome.measures.regularizer_loss.RegularizerLoss": "awesome_amd.measures.RegularizerLoss",
+    "awesome.measures.gradient_penalty_loss.GradientPenaltyLoss": "awesome_amd.measures.GradientPenaltyLoss",
     "awesome.measures.tv.TV": "awesome_amd.measures.TV",
     "awesome.measures.miou.MIOU": "awesome_amd.measures.MIOU",
     "awesome.run.awesome_config.AwesomeConfig": "awesome_amd.run.config.AwesomeConfig",

@@ -269,14 +269,14 @@ def main():
     flop_per_launch = STEP_FLOP_PER_POINT * N * B
     achieved = flop_per_launch / (kernel_ms * 1e-3) / 1e12
     # HBM bytes per launch of this kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of
-    # this same command: tools/profile_r03.sh).  A --pmc pass cannot run inside this process, so the figure is read from the
+    # this same command: tools/profile_round.sh).  A --pmc pass cannot run inside this process, so the figure is read from the
     # committed summary of the newest round that has one and only quoted for the configuration it was measured on;
     # `traffic_source` names the file.  `algorithmic_bytes`: SURVEY 8(d)'s 4-12 B per point (targets [+ grid + logits]) PLUS what
     # this design adds on purpose - one gradient slab per workgroup (wgs x PS x 4 B written here, read by the update kernel) and
     # the parameter image every workgroup copies into LDS - so `traffic_over_algorithmic` separates "wasted re-reads" (none: ~1.0)
     # from the slab round trip the design pays for (`traffic_over_survey_bytes`).
     traffic, traffic_source = None, None
-    for tag in ("r03_f", "r03_e", "r02_e"):
+    for tag in ("r04_a", "r03_f", "r03_e", "r02_e"):
         tf = os.path.join(ROOT, "profiles", f"{tag}_pmc_step_kernel.json")
         if B == 1 and S == 256 and os.path.exists(tf):
             with open(tf) as f:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-bench of the fused joint-training step (BASELINE configs[4]): 300 steps over 8 images, convexity prior and the
-path-connected (RealNVP) prior, for rocprofv3 --kernel-trace --stats (tools/profile_r03.sh)."""
+path-connected (RealNVP) prior, for rocprofv3 --kernel-trace --stats (tools/profile_round.sh)."""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

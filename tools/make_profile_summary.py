@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn the on-box summaries of tools/profile_r02.sh / profile_r03.sh (gpurun_out/rNN_prof*/) into the committed profiles/rNN_<tag>_* files.
+"""Turn the on-box summaries of tools/profile_r02.sh / profile_round.sh (gpurun_out/rNN_prof*/) into the committed profiles/rNN_<tag>_* files.
 
     python tools/make_profile_summary.py <tag> [<source dir under gpurun_out> [<round>]]      e.g.  ... e r03_prof_e 3"""
 import csv
@@ -46,7 +46,7 @@ def main():
     R = f"r{rnd:02d}"
     if os.path.exists(os.path.join(SRC, "bench_line.json")):
         shutil.copy(os.path.join(SRC, "bench_line.json"), os.path.join(DST, f"{R}_{tag}_bench_line.json"))
-    for src, name, cmd in (("bench", "bench", "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants --throughput-images 0"),
+    for src, name, cmd in (("bench", "bench", "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --strong-images 0 --no-variants --throughput-images 0"),
                            ("pcn", "pcn_fit", "python3 tools/kbench_pcn.py --steps 200"), ("cdn", "cdn_fit", "python3 tools/kbench_cdn.py"),
                            ("joint", "joint_step", "python3 tools/kbench_joint.py")):
         if not os.path.exists(os.path.join(SRC, f"{src}_kernel_stats.csv")):

@@ -13,6 +13,6 @@ rm -rf $d
 python3 - "$tag" <<'PY'
 import csv, sys
 rows = list(csv.reader(open(f"gpurun_out/{sys.argv[1]}_kernel_stats.csv")))
-for r in rows[:16]:
-    print(f"{r[0][:64]:64s} " + " ".join(f"{c:>12s}" for c in r[1:5]))
+for r in rows[:13]:
+    print(f"{r[0][:64]:64s} " + " ".join(f"{c:>12s}" for c in (r[1], r[3], r[5], r[6]) ))
 PY

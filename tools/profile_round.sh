@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round-3 profile collection on the GPU box (run through gpurun): `tools/profile_r03.sh stats|pmc|pcnpmc [tag]`.  Kernel traces and
+# Profile collection on the GPU box (run through gpurun): `ROUND=r04 tools/profile_round.sh stats|pmc|pcnpmc|wide [tag]`.  Kernel traces and
 # PMC counters are collected in SEPARATE rocprofv3 runs (never --pmc together with a trace domain other than --kernel-trace/--stats);
 # the program follows `--` directly.  Raw traces are summarised on the box and deleted (gpurun copies back at most 64 MiB).
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
 MODE=${1:-stats}
-O=gpurun_out/r03_prof_${2:-a}
+O=gpurun_out/${ROUND:-r04}_prof_${2:-a}
 mkdir -p $O
 summ_stats() {  # dir tag
   local db=$(find $1 -name "*.db" | head -1)
@@ -19,7 +19,7 @@ summ_pmc() {   # dir tag
   if [ -n "$csv" ]; then python3 tools/pmc_summary.py "$csv" > $O/$2.txt; else python3 tools/pmc_summary_db.py "$db" > $O/$2.txt; fi
   rm -rf $1
 }
-B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --strong-images 0"
 if [ "$MODE" = "stats" ] || [ "$MODE" = "all" ]; then
 echo "== kernel stats of the bench command $(date +%T)"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/stats_bench -o bench -- $B --no-variants --throughput-images 0 > $O/stats_bench.log 2>&1 || exit 1
@@ -41,7 +41,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_cdn -o cdn -- pyt
 summ_stats $O/stats_cdn cdn
 fi
 if [ "$MODE" = "pmc" ] || [ "$MODE" = "all" ]; then
-S="python3 bench.py --steps 1 --warmup 0 --epochs 50 --kernel-iters 20 --no-cpu-baseline --throughput-images 0 --no-variants"
+S="python3 bench.py --steps 1 --warmup 0 --epochs 50 --kernel-iters 20 --no-cpu-baseline --throughput-images 0 --no-variants --strong-images 0"
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "== pmc $c (bench) $(date +%T)"; timeout -k 10 300 rocprofv3 --pmc $c -d $O/pmc_$c -o p -- $S > $O/pmc_$c.log 2>&1 || exit 1
   summ_pmc $O/pmc_$c bench_pmc_$c
@@ -70,5 +70,10 @@ for shp in 11 0; do
   timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS -d $O/cdn_sq_$shp -o p -- python3 tools/kbench_cdn.py --steps 30 > $O/cdn_sq_$shp.log 2>&1 || exit 1
   summ_pmc $O/cdn_sq_$shp cdn_pmc_sq_shape$shp
 done
+fi
+if [ "$MODE" = "wide" ] || [ "$MODE" = "all" ]; then
+echo "== kernel stats of the layer-by-layer path $(date +%T)"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_wide -o wide -- python3 tools/kbench_wide.py 256x1 > $O/stats_wide.log 2>&1 || exit 1
+summ_stats $O/stats_wide wide_h256
 fi
 rm -f $O/*.log.tmp; du -sh $O; ls -la $O
