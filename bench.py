@@ -745,7 +745,11 @@ def cpu_baseline(args, flat0, unaries0, spec):
     sweep = {}
     if args.cpu_sweep_steps > 0:
         for t in sorted({t for t in (16, 32, 64, 128, cores) if t <= cores}):
-            sweep[t] = round(leg(t, args.cpu_sweep_steps)[1] * 1e3, 2)
+            probe = leg(t, 3)[1]                    # 3 steps first: an oversubscribed setting (seconds per step) is not run longer
+            if sweep and probe * 1e3 > 2.0 * min(sweep.values()):
+                sweep[t] = round(probe * 1e3, 2)
+            else:
+                sweep[t] = round(leg(t, args.cpu_sweep_steps)[1] * 1e3, 2)
         threads = min(sweep, key=sweep.get)
     else:
         threads = cores
@@ -758,7 +762,8 @@ def cpu_baseline(args, flat0, unaries0, spec):
            "ms_per_optimizer_step": round(s_per_step * 1e3, 2),
            "thread_sweep_ms_per_step": {str(k): v for k, v in sweep.items()},
            "all_threads": ({"cores": cores, "ms_per_optimizer_step": sweep[cores], "value": round(1.0 / (sweep[cores] * 1e-3 * E), 6),
-                            "sample": f"{args.cpu_sweep_steps} optimizer steps"} if cores in sweep else None)}
+                            "sample": "3 to %d optimizer steps (3 when more than 2x slower than the best setting)" % args.cpu_sweep_steps}
+                           if cores in sweep else None)}
     if args.cpu_sample_steps_8 > 0 and cores >= 8:
         dt8, sp8 = leg(8, args.cpu_sample_steps_8)
         out["threads_8"] = {"value": round(1.0 / (sp8 * E), 6), "unit": "fits/s", "cores": 8, "ms_per_optimizer_step": round(sp8 * 1e3, 2),
