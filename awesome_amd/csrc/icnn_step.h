@@ -295,6 +295,12 @@ __device__ __forceinline__ float sum_over_groups(float v) {  // the 4 lanes shar
 #endif
 // Keep successive k-steps of MFMAs in program order (everything else may still move across): without it hipcc regroups
 // the products per accumulator, i.e. into dependent chains that pay the 40-cycle latency instead of the 32-cycle issue.
+#ifndef INR_WO_RELOAD
+#define INR_WO_RELOAD 0
+#endif
+#ifndef INR_STAGE_Z0_EARLY
+#define INR_STAGE_Z0_EARLY 1
+#endif
 #ifndef INR_SLAB_NT
 #define INR_SLAB_NT 1   // the slab tiles are written once and read once by another kernel: non-temporal stores (A/B in DESIGN.md 6)
 #endif
@@ -585,6 +591,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
 #pragma unroll
                 for (int r = 0; r < 4; ++r) z0[tk + 1][r] = act0_f<ACT0>(zn[r], a.act_omega);
             }
+#if INR_STAGE_Z0_EARLY
+            // z0 tile tk has served as this k-group's operand; all that is left for it is to be the dW product's staged operand
+            if (TRAIN && tk < TM) *(f32x4*)(stB + (wave * 16 + l15) * G::SB + 4 * g + 16 * tk) = z0[tk];
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -663,14 +673,21 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
             float* const sb = stB + pl * G::SB + 4 * g;
             // dz1 of tile t (in place over acc), dw_o accumulation, staging of dz1 (A) and z0ext (B)
             auto dz1_tile = [&](int t) {
+#if INR_WO_RELOAD
+                const f32x4 wot = *(const f32x4*)&woT[16 * t + 4 * g];   // re-read: 32 registers less across the backward product
+#else
+                const f32x4 wot = wo[t];
+#endif
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float z1 = acc[t][r];
                     dwo[t][r] = fmaf(dy, z1, dwo[t][r]);
-                    acc[t][r] = z1 > 0.f ? dy * wo[t][r] : 0.f;
+                    acc[t][r] = z1 > 0.f ? dy * wot[r] : 0.f;
                 }
                 *(f32x4*)(sa + 16 * t) = acc[t];
+#if !INR_STAGE_Z0_EARLY
                 *(f32x4*)(sb + 16 * t) = z0[t];
+#endif
             };
             if (HR > 0 && g == 0) {
                 f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
