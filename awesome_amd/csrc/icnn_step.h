@@ -295,9 +295,6 @@ __device__ __forceinline__ float sum_over_groups(float v) {  // the 4 lanes shar
 #endif
 // Keep successive k-steps of MFMAs in program order (everything else may still move across): without it hipcc regroups
 // the products per accumulator, i.e. into dependent chains that pay the 40-cycle latency instead of the 32-cycle issue.
-#ifndef INR_WO_RELOAD
-#define INR_WO_RELOAD 0
-#endif
 #ifndef INR_STAGE_Z0_EARLY
 #define INR_STAGE_Z0_EARLY 1
 #endif
@@ -673,11 +670,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
             float* const sb = stB + pl * G::SB + 4 * g;
             // dz1 of tile t (in place over acc), dw_o accumulation, staging of dz1 (A) and z0ext (B)
             auto dz1_tile = [&](int t) {
-#if INR_WO_RELOAD
-                const f32x4 wot = *(const f32x4*)&woT[16 * t + 4 * g];   // re-read: 32 registers less across the backward product
-#else
                 const f32x4 wot = wo[t];
-#endif
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float z1 = acc[t][r];
