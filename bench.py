@@ -276,7 +276,7 @@ def main():
     # the parameter image every workgroup copies into LDS - so `traffic_over_algorithmic` separates "wasted re-reads" (none: ~1.0)
     # from the slab round trip the design pays for (`traffic_over_survey_bytes`).
     traffic, traffic_source = None, None
-    for tag in ("r04_a", "r03_f", "r03_e", "r02_e"):
+    for tag in ("r04_b", "r03_f", "r03_e", "r02_e"):
         tf = os.path.join(ROOT, "profiles", f"{tag}_pmc_step_kernel.json")
         if B == 1 and S == 256 and os.path.exists(tf):
             with open(tf) as f:
