@@ -28,6 +28,9 @@
 
 namespace {
 
+#ifndef GM_WAVES
+#define GM_WAVES 4   // waves per SIMD the V4 kernels are compiled for (<= 128 VGPRs)
+#endif
 constexpr int GM_BM = 128, GM_BN = 128, GM_BK = 16;
 constexpr int GM_LDK = 20;            // [row][k] layout: floats per row
 constexpr int GM_LDF = GM_BM + 4;     // [k][free] layout: floats per k-row
@@ -52,57 +55,155 @@ struct GemmArgs {
     int mask_ld, mask_act;
     float omega;
     int vecA, vecB;        // widest aligned load of the operand: 4 floats (base and row stride multiples of 16 bytes), 2, or 1
+    float* extsum;         // NN products only, optional: [row tiles][N][1 + C_in] = sum over the tile's 128 rows m of C[m][n] (1, x_m) (x from `ext`)
+    int padA, padB;        // the operand's rows may be READ up to the next multiple of 4 floats past their logical end (finite values
+                           // there: the padded activation rows of wide.h); what is read there is replaced by 0
 };
 
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
+// One thread's share of an operand tile: two chunks of 4 consecutive floats along the operand's contiguous dimension, each at (r, c ..
+// c + 3) of the stored matrix - r below `rmax`, c below `cmax`; everything out of range is to read as 0.  No branch around any load and
+// no use of a loaded value here: addresses are clamped into the matrix and the LDS store (store_tiles) replaces what was out of range
+// by 0 - so all loads of a k-step stay in flight behind the MFMAs of the step before
+// (a guarded load, or a select next to the load, costs a wait for the data in front of the MFMAs).
+//   V = 4 / 2: vector loads; a vector that straddles cmax is loaded whole (the caller guarantees it may: `pad`, or cmax a multiple of V)
+//   V = 1:     four clamped scalar loads
+// Which chunks a thread owns is chosen for coalescing - neighbouring lanes read neighbouring 16 bytes:
+//   operand contiguous along k, tile [128 rows][16 k]: chunk h = row (tid >> 2) + 64 h, k offset 4 (tid & 3)  (4 lanes = a row's 64 bytes)
+//   operand contiguous along its free index, tile [16 k][128]: chunk h = k row tid >> 4, offset 4 (tid & 15) + 64 h  (16 lanes = 256 bytes)
+// (round 4 measured the k-loop of the three products at 73 / 84 / 72.5 us with 8 consecutive floats per thread - neighbouring lanes 32
+// bytes apart, in two instructions - against 62 - 63 us without any global load.)
+#if defined(GM_EXP) && (GM_EXP & 16)   // timing experiment: no LDS reads in the k-loop
+#define GM_LDS_READ(ptr, alt) (alt)
+#else
+#define GM_LDS_READ(ptr, alt) (*(const f32x4*)(ptr))
+#endif
+
+template <int V>
+__device__ __forceinline__ void gemm_load4(const float* __restrict__ base, int ld, int r, int rmax, int c, int cmax, f32x4& v) {
+    const bool rok = r < rmax;
+    const float* row = base + (size_t)(rok ? r : rmax - 1) * ld;
+    if (V == 4) {
+        v = *(const f32x4*)(row + (c < cmax ? c : 0));
+    } else if (V == 2) {
+        const f32x2 lo = *(const f32x2*)(row + (c < cmax ? c : 0)), hi = *(const f32x2*)(row + (c + 2 < cmax ? c + 2 : 0));
+        v = f32x4{lo[0], lo[1], hi[0], hi[1]};
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = row[c + e < cmax ? c + e : cmax - 1];
+    }
+}
+// the load flavour of a tile whose contiguous range is [c0, c0 + len) of cmax: the operand's vector width where no vector straddles
+// cmax (or may be read past it), scalar loads otherwise.  Uniform over the workgroup.
+__device__ __forceinline__ int gemm_flavour(int vec, int pad, int c0, int len, int cmax) {
+    if (vec == 1) return 1;
+    const bool straddle = (cmax % vec) != 0 && c0 < cmax && cmax < c0 + len;
+    return (straddle && !pad) ? 1 : vec;
+}
+__device__ __forceinline__ void gemm_load4_any(int flavour, const float* __restrict__ base, int ld, int r, int rmax, int c, int cmax, f32x4& v) {
+    if (flavour == 4) gemm_load4<4>(base, ld, r, rmax, c, cmax, v);
+    else if (flavour == 2) gemm_load4<2>(base, ld, r, rmax, c, cmax, v);
+    else gemm_load4<1>(base, ld, r, rmax, c, cmax, v);
+}
+
+// V4: both operands take 16-byte loads everywhere (aligned bases and row strides; no vector straddles the end of a row, or it may be
+// read: gemm_all_vec4) - the k-loop then has no branch in it.  The other instantiation picks a load flavour per operand and tile.
+template <bool TA, bool TB, bool V4>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V4 ? GM_WAVES : 2, GM_WAVES))) void gemm_kernel(const GemmArgs a) {
     __shared__ __attribute__((aligned(16))) float As[2][GM_STAGE];
     __shared__ __attribute__((aligned(16))) float Bs[2][GM_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;   // n fastest: the column tiles of one row tile run together and share its A rows in L2
-    const int k_lo = blockIdx.z * a.k_per_split;
-    const int k_hi = min(a.K, k_lo + a.k_per_split);
-    const int steps = (k_hi - k_lo + GM_BK - 1) / GM_BK;
-
-    // ---- global -> registers: every thread owns 8 consecutive floats of each operand tile -----------------------------------------
-    // operand contiguous along k: tile [128 rows][16 k], thread -> row tid >> 1, k offset (tid & 1) * 8
-    // operand contiguous along its free index: tile [16 k][128], thread -> k row tid >> 4, offset (tid & 15) * 8
-    auto load8 = [&](const float* base, int ld, bool kcontig, int row0, int rows, int kbase, int vec, f32x4 (&v)[2]) {
-        int r, c;          // r: index along the slow (row) dimension of the STORED matrix, c: along its contiguous dimension
-        bool rok;
-        int cmax;
-        if (kcontig) {
-            r = row0 + (tid >> 1);
-            c = kbase + (tid & 1) * 8;
-            rok = r < rows;
-            cmax = k_hi;
-        } else {
-            r = kbase + (tid >> 4);
-            c = row0 + (tid & 15) * 8;
-            rok = r < k_hi;
-            cmax = rows;
+#if defined(GM_DEPHASE)
+    {   // which of the (up to 4) workgroups resident on this CU am I: LDS allocation base / size (HW_REG_LDS_ALLOC: base [11:0], size [20:12], 256 B units)
+        const unsigned la = __builtin_amdgcn_s_getreg((31 << 11) | 6);
+        const unsigned sz = (la >> 12) & 0x1ff;
+        const unsigned slot = ((la & 0xfff) / (sz ? sz : 1)) & 3;
+#if GM_DEPHASE == 1
+        if (slot == 0) __builtin_amdgcn_s_setprio(3);
+        else if (slot == 1) __builtin_amdgcn_s_setprio(2);
+        else if (slot == 2) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+#else
+        if (slot == 1) __builtin_amdgcn_s_sleep(GM_DEPHASE);
+        else if (slot == 2) { __builtin_amdgcn_s_sleep(GM_DEPHASE); __builtin_amdgcn_s_sleep(GM_DEPHASE); }
+        else if (slot == 3) { __builtin_amdgcn_s_sleep(GM_DEPHASE); __builtin_amdgcn_s_sleep(GM_DEPHASE); __builtin_amdgcn_s_sleep(GM_DEPHASE); }
+#endif
+    }
+#endif
+    // workgroup -> tile.  n fastest, so that the column tiles of one row tile run together and share its A rows in a cache - and the
+    // hardware deals consecutive workgroups to the 8 XCDs (each with its own L2) in turn, so the launch order is first re-dealt such
+    // that consecutive tiles land on ONE XCD (wg % 8 picks the XCD, wg / 8 the slot on it).
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int gx = gridDim.x, gxy = gx * gridDim.y, total = gxy * gridDim.z;
+        if ((total & 7) == 0 && gxy > 1) {
+            const int wg = bz * gxy + by * gx + bx, t = (wg & 7) * (total >> 3) + (wg >> 3);
+            bz = t / gxy;
+            by = (t - bz * gxy) / gx;
+            bx = t - bz * gxy - by * gx;
         }
-        const float* p = base + (size_t)r * ld + c;
+    }
+    const int m0 = by * GM_BM, n0 = bx * GM_BN;
+    const int k_lo = bz * a.k_per_split;
+    const int k_hi = min(a.K, k_lo + a.k_per_split);
+#if defined(GM_EXP) && (GM_EXP & 2)   // timing experiment: the epilogue alone
+    const int steps = 0;
+#else
+    const int steps = (k_hi - k_lo + GM_BK - 1) / GM_BK;
+#endif
+
+    // ---- global -> registers -> LDS: every thread owns two 16-byte chunks of each operand tile (gemm_load4) ----------------------------
+    // flavours of the operands' interior k-steps (a contiguous-k operand's last, partial step may need another: see load_tiles)
+    const int flA = V4 ? 4 : (TA ? gemm_flavour(a.vecA, a.padA, m0, GM_BM, a.M) : a.vecA);
+    const int flB = V4 ? 4 : (TB ? a.vecB : gemm_flavour(a.vecB, a.padB, n0, GM_BN, a.N));
+    // chunk h of this thread in operand tiles at k = kbase: (row, column) of the stored matrix, and their bounds
+    const int rmaxA = TA ? k_hi : a.M, cmaxA = TA ? a.M : k_hi, rmaxB = TB ? a.N : k_hi, cmaxB = TB ? k_hi : a.N;
+    auto chunkA = [&](int kbase, int h, int& r, int& c) {
+        r = TA ? kbase + (tid >> 4) : m0 + (tid >> 2) + 64 * h;
+        c = TA ? m0 + (tid & 15) * 4 + 64 * h : kbase + (tid & 3) * 4;
+    };
+    auto chunkB = [&](int kbase, int h, int& r, int& c) {
+        r = TB ? n0 + (tid >> 2) + 64 * h : kbase + (tid >> 4);
+        c = TB ? kbase + (tid & 3) * 4 : n0 + (tid & 15) * 4 + 64 * h;
+    };
+    auto load_tiles = [&](int kbase, f32x4 (&ra)[2], f32x4 (&rb)[2]) {
+        const bool tail = kbase + GM_BK > k_hi;
+        const int fa = V4 ? 4 : (!TA && tail ? gemm_flavour(a.vecA, a.padA, kbase, GM_BK, k_hi) : flA);
+        const int fb = V4 ? 4 : (TB && tail ? gemm_flavour(a.vecB, a.padB, kbase, GM_BK, k_hi) : flB);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int cc = c + 4 * h;
-            if (rok && vec == 4 && cc + 3 < cmax) {
-                v[h] = *(const f32x4*)(p + 4 * h);
-            } else if (rok && vec == 2 && cc + 3 < cmax) {   // rows on 8-byte boundaries (an even row length, e.g. 350)
-                const f32x2 lo = *(const f32x2*)(p + 4 * h), hi = *(const f32x2*)(p + 4 * h + 2);
-                v[h] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+            int rA, cA, rB, cB;
+            chunkA(kbase, h, rA, cA);
+            chunkB(kbase, h, rB, cB);
+            if (V4) {
+                gemm_load4<4>(a.A, a.lda, rA, rmaxA, cA, cmaxA, ra[h]);
+                gemm_load4<4>(a.B, a.ldb, rB, rmaxB, cB, cmaxB, rb[h]);
             } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[h][e] = (rok && cc + e < cmax) ? p[4 * h + e] : 0.f;
+                gemm_load4_any(fa, a.A, a.lda, rA, rmaxA, cA, cmaxA, ra[h]);
+                gemm_load4_any(fb, a.B, a.ldb, rB, rmaxB, cB, cmaxB, rb[h]);
             }
         }
     };
-    auto store8 = [&](float* stage, bool kcontig, const f32x4 (&v)[2]) {
-        float* d = kcontig ? stage + (tid >> 1) * GM_LDK + (tid & 1) * 8 : stage + (tid >> 4) * GM_LDF + (tid & 15) * 8;
-        *(f32x4*)d = v[0];
-        *(f32x4*)(d + 4) = v[1];
+    // registers -> LDS, what lies outside the matrix replaced by 0 (element e of a chunk is valid iff its row is and c + e < cmax)
+    auto store_tiles = [&](int kbase, float* sA, float* sB, const f32x4 (&ra)[2], const f32x4 (&rb)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int rA, cA, rB, cB;
+            chunkA(kbase, h, rA, cA);
+            chunkB(kbase, h, rB, cB);
+            const int la = rA < rmaxA ? cmaxA - cA : 0, lb = rB < rmaxB ? cmaxB - cB : 0;
+            float* dA = !TA ? sA + ((tid >> 2) + 64 * h) * GM_LDK + (tid & 3) * 4 : sA + (tid >> 4) * GM_LDF + (tid & 15) * 4 + 64 * h;
+            float* dB = TB ? sB + ((tid >> 2) + 64 * h) * GM_LDK + (tid & 3) * 4 : sB + (tid >> 4) * GM_LDF + (tid & 15) * 4 + 64 * h;
+            f32x4 oa, ob;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                oa[e] = e < la ? ra[h][e] : 0.f;
+                ob[e] = e < lb ? rb[h][e] : 0.f;
+            }
+            *(f32x4*)dA = oa;
+            *(f32x4*)dB = ob;
+        }
     };
 
     f32x4 acc[4][4];
@@ -113,47 +214,45 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
 
     f32x4 ra[2], rb[2];
     if (steps > 0) {
-        load8(a.A, a.lda, !TA, m0, a.M, k_lo, a.vecA, ra);
-        load8(a.B, a.ldb, TB, n0, a.N, k_lo, a.vecB, rb);
-        store8(As[0], !TA, ra);
-        store8(Bs[0], TB, rb);
+        load_tiles(k_lo, ra, rb);
+        store_tiles(k_lo, As[0], Bs[0], ra, rb);
     }
     __syncthreads();
-    for (int s = 0; s < steps; ++s) {
-        const int cur = s & 1;
-        if (s + 1 < steps) {   // next step's tiles: in flight while this step multiplies
-            load8(a.A, a.lda, !TA, m0, a.M, k_lo + (s + 1) * GM_BK, a.vecA, ra);
-            load8(a.B, a.ldb, TB, n0, a.N, k_lo + (s + 1) * GM_BK, a.vecB, rb);
-        }
+    // one k-step of MFMAs on the tiles in LDS buffer `cur`
+    auto multiply = [&](int cur) {
         const float* sa = As[cur];
         const float* sb = Bs[cur];
-        if (!TA && TB) {          // both contiguous along k: one read per tile, then 4 x 16 MFMAs
-            f32x4 av[4], bv[4];
+        if (!TA && TB) {          // both contiguous along k: one read per tile; the B tiles in two halves (24 operand registers, not 32)
+            f32x4 av[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = *(const f32x4*)(sa + (wm * 64 + 16 * i + l15) * GM_LDK + 4 * g);
+            for (int i = 0; i < 4; ++i) av[i] = GM_LDS_READ(sa + (wm * 64 + 16 * i + l15) * GM_LDK + 4 * g, ra[0]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(sb + (wn * 64 + 16 * j + l15) * GM_LDK + 4 * g);
+            for (int jh = 0; jh < 2; ++jh) {
+                f32x4 bv[2];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+                for (int j = 0; j < 2; ++j) bv[j] = GM_LDS_READ(sb + (wn * 64 + 16 * (2 * jh + j) + l15) * GM_LDK + 4 * g, rb[0]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = MFMA16(av[i][kk], bv[j][kk], acc[i][j]);
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][2 * jh + j] = MFMA16(av[i][kk], bv[j][kk], acc[i][2 * jh + j]);
+            }
         } else {
             f32x4 av[4], bv[4];   // k-contiguous operand: [tile]; free-contiguous operand: read per kk
             if (!TA) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) av[i] = *(const f32x4*)(sa + (wm * 64 + 16 * i + l15) * GM_LDK + 4 * g);
+                for (int i = 0; i < 4; ++i) av[i] = GM_LDS_READ(sa + (wm * 64 + 16 * i + l15) * GM_LDK + 4 * g, ra[0]);
             }
             if (TB) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(sb + (wn * 64 + 16 * j + l15) * GM_LDK + 4 * g);
+                for (int j = 0; j < 4; ++j) bv[j] = GM_LDS_READ(sb + (wn * 64 + 16 * j + l15) * GM_LDK + 4 * g, rb[0]);
             }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 f32x4 af, bf;
-                if (TA) af = *(const f32x4*)(sa + (4 * g + kk) * GM_LDF + wm * 64 + 4 * l15);
-                if (!TB) bf = *(const f32x4*)(sb + (4 * g + kk) * GM_LDF + wn * 64 + 4 * l15);
+                if (TA) af = GM_LDS_READ(sa + (4 * g + kk) * GM_LDF + wm * 64 + 4 * l15, ra[0]);
+                if (!TB) bf = GM_LDS_READ(sb + (4 * g + kk) * GM_LDF + wn * 64 + 4 * l15, rb[0]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -161,66 +260,125 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
                         acc[i][j] = MFMA16(TA ? af[i] : av[i][kk], TB ? bv[j][kk] : bf[j], acc[i][j]);
             }
         }
-        if (s + 1 < steps) {
-            store8(As[cur ^ 1], !TA, ra);
-            store8(Bs[cur ^ 1], TB, rb);
-        }
+    };
+    // every step but the last: the next step's tiles are requested, this step multiplies, the tiles are written to the other buffer.
+    // (The last step is peeled so that the loop body has no condition in it: hipcc's wait-count insertion does not correlate "no
+    // loads were issued" with "no stores follow" and puts a vmcnt(0) between the A and the B loads of a conditional version.)
+    for (int s = 0; s + 1 < steps; ++s) {
+        const int cur = s & 1;
+#if !(defined(GM_EXP) && (GM_EXP & 4))
+        load_tiles(k_lo + (s + 1) * GM_BK, ra, rb);
+#endif
+        __builtin_amdgcn_sched_barrier(0);   // the loads are issued in front of the step's MFMAs and waited for behind them (hipcc's
+#ifdef GM_SETPRIO
+        __builtin_amdgcn_s_setprio(GM_SETPRIO);
+#endif
+        multiply(cur);                       // scheduler would move both into the MFMA sequence, half a step apart)
+#ifdef GM_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#if !(defined(GM_EXP) && (GM_EXP & 4))
+        store_tiles(k_lo + (s + 1) * GM_BK, As[cur ^ 1], Bs[cur ^ 1], ra, rb);
+#endif
+#if !(defined(GM_EXP) && (GM_EXP & 8))
         __syncthreads();
+#endif
     }
+    if (steps > 0) multiply((steps - 1) & 1);
 
+#if defined(GM_EXP) && (GM_EXP & 1)   // timing experiment: the k-loop alone (one store keeps it alive)
+    {
+        float t = 0.f;
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j)
+                for (int r = 0; r < 4; ++r) t += acc[i][j][r];
+        if (t != 12345.678f) return;
+    }
+#endif
     // ---- epilogue: acc[i][j][r] = C[m][n] with m = m0 + 64 wm + mrow(i, 4 g + r), n = n0 + 64 wn + ncol(j, l15) ---------------------
-    float* __restrict__ Cz = a.C + (size_t)blockIdx.z * a.c_split_stride;
+    // Whatever the epilogue reads per output row (the point's coordinates; the mask values) is requested for FOUR rows at a time from
+    // clamped addresses, ahead of the arithmetic that uses it: one wait per four rows instead of one per element.
+    float* __restrict__ Cz = a.C + (size_t)bz * a.c_split_stride;
     auto ncol = [&](int j) { return n0 + wn * 64 + (TB ? 16 * j + l15 : 4 * l15 + j); };
-    // HIDDEN: the per-column constants (bias, skip weights) of this lane's four columns once, the point's coordinates once per row
+    auto mrow = [&](int i, int r) { const int q = 4 * g + r; return m0 + wm * 64 + (TA ? 4 * q + i : 16 * i + q); };
+    // HIDDEN: the per-column constants (bias, skip weights) of this lane's four columns once
     float bn[4] = {0.f, 0.f, 0.f, 0.f}, sn[4][3] = {};
     if (a.epi == GEMM_EPI_HIDDEN) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = ncol(j);
-            if (n < a.N) {
-                bn[j] = a.bias[n];
-                for (int c = 0; c < a.C_in; ++c) sn[j][c] = a.skip[n * a.C_in + c];
-            }
+            const int n = min(ncol(j), a.N - 1);
+            bn[j] = a.bias[n];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sn[j][c] = c < a.C_in ? a.skip[n * a.C_in + c] : 0.f;
         }
     }
+    // a lane's four columns are consecutive (operand B contiguous along n) and its row of C / of the mask may be accessed as 16 bytes
+    const bool vec_c = !TB && ncol(0) + 3 < a.N && (a.ldc & 3) == 0 && (((size_t)Cz) & 15) == 0;
+    const bool vec_mask = !TB && a.epi == GEMM_EPI_MASK && ncol(0) + 3 < a.N && (a.mask_ld & 3) == 0 && (((size_t)a.mask) & 15) == 0;
+    float es[4][4] = {};   // NN + extsum: this lane's share of sum_m C[m][n] (1, x_m) for its four columns
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        float xm[4][3] = {};
+        f32x4 zm[4];
+        if (a.epi == GEMM_EPI_HIDDEN) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* xp = a.ext + (size_t)min(mrow(i, r), a.M - 1) * a.ext_ld + 1;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) xm[r][c] = xp[c < a.C_in ? c : 0];
+            }
+        } else if (a.epi == GEMM_EPI_MASK) {
+            if (!TA && !TB && a.extsum) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* xp = a.ext + (size_t)min(mrow(i, r), a.M - 1) * a.ext_ld + 1;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) xm[r][c] = xp[c < a.C_in ? c : 0];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* mp = a.mask + (size_t)min(mrow(i, r), a.M - 1) * a.mask_ld;
+                if (vec_mask) {
+                    zm[r] = *(const f32x4*)(mp + ncol(0));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) zm[r][j] = mp[min(ncol(j), a.N - 1)];
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int q = 4 * g + r;
-            const int m = m0 + wm * 64 + (TA ? 4 * q + i : 16 * i + q);
-            if (m >= a.M) continue;
-            float xm[3] = {0.f, 0.f, 0.f};
-            if (a.epi == GEMM_EPI_HIDDEN)
-                for (int c = 0; c < a.C_in; ++c) xm[c] = a.ext[(size_t)m * a.ext_ld + 1 + c];
+            const int m = mrow(i, r);
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int n = ncol(j);
                 float v = acc[i][j][r];
                 if (a.epi == GEMM_EPI_HIDDEN) {
                     v += bn[j];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) v = fmaf(sn[j][c], xm[c], v);   // (unused channels: 0 * 0)
+                    for (int c = 0; c < 3; ++c) v = fmaf(sn[j][c], xm[r][c], v);   // (unused channels: 0 * x)
                     v = fmaxf(v, 0.f);
-                } else if (a.epi == GEMM_EPI_MASK && n < a.N) {
-                    const float z = a.mask[(size_t)m * a.mask_ld + n];
+                } else if (a.epi == GEMM_EPI_MASK) {
+                    const float z = zm[r][j];
                     if (a.mask_act == INR_ACT_COS) v *= -hw_sin(z);
                     else if (a.mask_act == INR_ACT_SIN) v *= a.omega * hw_cos(a.omega * z);
                     else v = z > 0.f ? v : 0.f;
                 }
                 o[j] = v;
             }
-            if (!TB) {   // a lane's four column tiles are four consecutive columns 4 l15 + j: one 16-byte store where it may
-                const int n = ncol(0);
-                float* dst = Cz + (size_t)m * a.ldc + n;
-                if (n + 3 < a.N && ((a.ldc & 3) == 0) && ((((size_t)Cz) & 15) == 0)) {
-                    *(f32x4*)dst = o;
-                } else {
+            if (!TA && !TB && a.extsum) {   // (rows past M are products of zero-filled operand rows: 0)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (n + j < a.N) dst[j] = o[j];
+                for (int j = 0; j < 4; ++j) {
+                    es[j][0] += o[j];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) es[j][1 + c] = fmaf(o[j], xm[r][c], es[j][1 + c]);
                 }
+            }
+            if (m >= a.M) continue;
+            if (vec_c) {
+                *(f32x4*)(Cz + (size_t)m * a.ldc + ncol(0)) = o;
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -228,6 +386,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
                     if (n < a.N) Cz[(size_t)m * a.ldc + n] = o[j];
                 }
             }
+        }
+    }
+    if (!TA && !TB && a.extsum) {
+        // the column sums of the tile: lanes that share a column (4 row groups g, 2 waves wm) through LDS, added in a fixed order
+        __syncthreads();                      // every wave is past its last read of the operand tiles
+        float* red = &As[0][0];               // [wave][g][l15][j][4]
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *(f32x4*)(red + ((((wave * 4 + g) * 16 + l15) * 4 + j) << 2)) = f32x4{es[j][0], es[j][1], es[j][2], es[j][3]};
+        __syncthreads();
+        if (tid < 128) {
+            const int wn_ = tid >> 6, l = (tid & 63) >> 2, j = tid & 3, n = n0 + wn_ * 64 + 4 * l + j;
+            f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int wm_ = 0; wm_ < 2; ++wm_)
+#pragma unroll
+                for (int g_ = 0; g_ < 4; ++g_) t += *(const f32x4*)(red + (((((wm_ * 2 + wn_) * 4 + g_) * 16 + l) * 4 + j) << 2));
+            if (n < a.N)
+                for (int c = 0; c <= a.C_in; ++c) a.extsum[((size_t)by * a.N + n) * (1 + a.C_in) + c] = t[c];
         }
     }
 }
@@ -247,10 +424,20 @@ inline int gemm_launch(hipStream_t s, bool tA, bool tB, GemmArgs g) {
     g.vecA = gemm_vec_width(g.A, g.lda);
     g.vecB = gemm_vec_width(g.B, g.ldb);
     const dim3 grid((g.N + GM_BN - 1) / GM_BN, (g.M + GM_BM - 1) / GM_BM, splits);
-    if (!tA && tB) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, s, g);
-    else if (!tA && !tB) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, s, g);
-    else if (tA && !tB) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, s, g);
+    // 16-byte loads throughout: aligned operands whose contiguous extent is a multiple of 4 floats or may be read up to the next one
+    // (a split contraction ends inside the rows of an operand contiguous along k: always readable)
+    const int contigA = tA ? g.M : g.K, contigB = tB ? g.K : g.N;
+    const bool v4 = g.vecA == 4 && g.vecB == 4 && ((contigA & 3) == 0 || g.padA) && ((contigB & 3) == 0 || g.padB) && (g.k_per_split & 3) == 0;
+#define GEMM_GO(TA_, TB_)                                                                            \
+    do {                                                                                             \
+        if (v4) hipLaunchKernelGGL((gemm_kernel<TA_, TB_, true>), grid, dim3(256), 0, s, g);         \
+        else hipLaunchKernelGGL((gemm_kernel<TA_, TB_, false>), grid, dim3(256), 0, s, g);           \
+    } while (0)
+    if (!tA && tB) GEMM_GO(false, true);
+    else if (!tA && !tB) GEMM_GO(false, false);
+    else if (tA && !tB) GEMM_GO(true, false);
+    else GEMM_GO(true, true);
+#undef GEMM_GO
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 

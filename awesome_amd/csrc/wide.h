@@ -22,7 +22,10 @@
 namespace {
 
 constexpr int WIDE_CHUNK = 512;      // points per split of the point-contractions (GEMM partials)
-constexpr int WIDE_OUT_CHUNK = 128;  // points per block of wide_out_kernel / wide_extgrad_kernel (their partials)
+#ifndef INR_WIDE_OUT_CHUNK
+#define INR_WIDE_OUT_CHUNK 128
+#endif
+constexpr int WIDE_OUT_CHUNK = INR_WIDE_OUT_CHUNK;  // points per block of wide_out_kernel / wide_extgrad_kernel (their partials)
 inline int splitk_parts(long long N) { return (int)((N + WIDE_CHUNK - 1) / WIDE_CHUNK); }
 inline int out_parts(long long N) { return (int)((N + WIDE_OUT_CHUNK - 1) / WIDE_OUT_CHUNK); }
 
@@ -105,6 +108,16 @@ __global__ __launch_bounds__(256) void wide_copy_ext_kernel(float* __restrict__ 
     z[p * hs + j] = zprev[p * hs + j];
 }
 
+// the hidden layers' weight matrices W_k [h][h] (flat parameters, row stride h: rows on 16-byte boundaries only where h is a multiple
+// of 4) copied into [L][h][hp] with zero padding: every GEMM operand of the path then takes 16-byte loads (gemm.h, V4)
+__global__ __launch_bounds__(256) void wide_pack_weights_kernel(const float* __restrict__ params, WideMap m, int hp, float* __restrict__ wp) {
+    const int per = m.h * hp;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= m.L * per) return;
+    const int k = e / per, r = e - k * per, i = r / hp, j = r - i * hp;
+    wp[e] = j < m.h ? params[m.p_w(k) + i * m.h + j] : 0.f;
+}
+
 // ONE pass over the last layer's activations Z_L [N][hs] (16 lanes per point, 16 points per iteration, WIDE_OUT_CHUNK points per block):
 //   y = w_o . z_L + b_o + s_o . x  -> logits;   TRAIN: sigmoid, data term -> dy, the loss partial of the block;
 //   dZ_L[p][j] = dy w_o[j] [z_L[p][j] > 0]  (the row is still in the cache);
@@ -119,21 +132,28 @@ struct WideOutArgs {
     float* logits;          // [N] or null
     float* dz;              // [N][hp] (train)
     float* part;            // [blocks][hsv] output-layer gradient partials (train)
+    float* part_ext;        // [blocks][h][1 + C] partials of (db | dS) of the last hidden layer = dZ_L^T (1, X) (train, EXT instantiations)
     float* lossp;           // [blocks] loss partials (train)
     long long N;
     int h, C, hs, hp, hsv, loss_kind, train;
 };
 constexpr int WIDE_OUT_MAXQ = (WIDE_MAX_HIDDEN_PAD + 63) / 64;   // f32x4 per lane and row
-template <int WIDE_OUT_NQ>   // 64-column slices a row may have (register budget of the instantiation)
+template <int WIDE_OUT_NQ, bool EXT>   // 64-column slices a row may have (register budget of the instantiation); EXT: also dZ_L^T (1, X)
 __global__ __launch_bounds__(256) void wide_out_kernel(const WideOutArgs a) {
     __shared__ float sm[4];
     __shared__ float colp[16][68];          // per row-group partial column sums of one 64-column slice
+    __shared__ f32x4 colp4[EXT ? 16 : 1][EXT ? 65 : 1];
     const int tid = threadIdx.x, l15 = tid & 15, rg = tid >> 4;      // 16 lanes per point, 16 row groups
     const long long p0 = (long long)blockIdx.x * WIDE_OUT_CHUNK;
     const int nq = (a.hs + 63) / 64;        // 64-column slices of a row (16 lanes x 4 floats)
     f32x4 gacc[WIDE_OUT_NQ];
+    f32x4 eacc[EXT ? WIDE_OUT_NQ : 1][4];   // [slice][column of the lane's four] = sum_p dZ_L[p][j] (1, x_p)
 #pragma unroll
     for (int q = 0; q < WIDE_OUT_NQ; ++q) gacc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < (EXT ? WIDE_OUT_NQ : 1); ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) eacc[q][e] = f32x4{0.f, 0.f, 0.f, 0.f};
     float lsum = 0.f;
     for (int it = 0; it < WIDE_OUT_CHUNK / 16; ++it) {
         const long long p = p0 + it * 16 + rg;
@@ -152,7 +172,11 @@ __global__ __launch_bounds__(256) void wide_out_kernel(const WideOutArgs a) {
         }
         ypart = sum_over_points(ypart);     // over the 16 lanes of the point (one DPP row)
         float y = ypart + a.sc[0];
-        for (int c = 0; c < a.C; ++c) y = fmaf(a.sc[1 + c], zr[a.h + 1 + c], y);
+        f32x4 xe = f32x4{1.f, 0.f, 0.f, 0.f};   // the point's ext inputs (1, x)
+        for (int c = 0; c < a.C; ++c) {
+            xe[1 + c] = zr[a.h + 1 + c];
+            y = fmaf(a.sc[1 + c], xe[1 + c], y);
+        }
         if (a.logits && valid && l15 == 0) a.logits[p] = y;
         if (!a.train) continue;
         float l = 0.f, dy = 0.f;
@@ -188,6 +212,10 @@ __global__ __launch_bounds__(256) void wide_out_kernel(const WideOutArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) d[e] = (j + e < a.h && zq[q][e] > 0.f) ? dy * a.wo[j + e] : 0.f;
                     *(f32x4*)(dr + j) = d;   // hp is a multiple of 4; the padding columns get zeros
+                    if (EXT) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) eacc[q][e] += d[e] * xe;
+                    }
                 }
             }
         }
@@ -214,6 +242,28 @@ __global__ __launch_bounds__(256) void wide_out_kernel(const WideOutArgs a) {
             for (int r = 0; r < 16; ++r) t += colp[r][tid];
             const int j = 64 * q + tid;
             if (j < a.hsv) a.part[(size_t)blockIdx.x * a.hsv + j] = t;
+        }
+    }
+    if (EXT) {   // the same for dZ_L^T (1, X): four values per column
+        for (int q = 0; q < nq; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __syncthreads();
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int qq = 0; qq < WIDE_OUT_NQ; ++qq)
+                    if (qq == q) v = eacc[EXT ? qq : 0][e];
+                colp4[EXT ? rg : 0][EXT ? 4 * l15 + e : 0] = v;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += colp4[EXT ? r : 0][EXT ? tid : 0];
+                const int j = 64 * q + tid;
+                if (j < a.h)
+                    for (int c = 0; c <= a.C; ++c) a.part_ext[((size_t)blockIdx.x * a.h + j) * (1 + a.C) + c] = t[c];
+            }
         }
     }
 }
@@ -302,7 +352,7 @@ __global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restric
 
 // ---- workspace --------------------------------------------------------------------------------------------------------------------------
 struct WideWs {
-    float *z[WIDE_MAX_LAYERS + 1], *pre0, *dza, *dzb, *part, *lossp, *grads, *coef;
+    float *z[WIDE_MAX_LAYERS + 1], *pre0, *dza, *dzb, *part, *part2, *lossp, *grads, *coef, *wp;
     int blocks;            // blocks of wide_out_kernel / wide_l0grad_kernel (WIDE_OUT_CHUNK points each)
     int hs, hp, hsv;       // row length of the activations (multiple of 4), of the dz / pre0 buffers (multiple of 4), h + 1 + C
     long long bytes;
@@ -325,8 +375,13 @@ inline WideWs carve_wide(const WideMap& m, long long N, bool need_pre0, void* ba
     w.dzb = take(N * w.hp * 4);
     const long long part_gemm = (long long)splitk_parts(N) * m.h * m.h, part_out = (long long)w.blocks * (w.hsv > m.h * (1 + m.C) ? w.hsv : m.h * (1 + m.C));
     w.part = take((part_gemm > part_out ? part_gemm : part_out) * 4);
+    {   // (db | dS) partials: one [h][1 + C] block per wide_out_kernel block / per 128-row tile of the backward GEMM
+        const long long tiles = (N + GM_BM - 1) / GM_BM;
+        w.part2 = take((w.blocks > tiles ? w.blocks : tiles) * m.h * (1 + m.C) * 4);
+    }
     w.lossp = take((long long)w.blocks * 4);
     w.grads = take(((long long)m.P + 1 + 31) / 32 * 32 * 4);
+    w.wp = take((long long)m.L * m.h * w.hp * 4);
     w.coef = nullptr;
     w.bytes = off;
     return w;
@@ -343,6 +398,9 @@ inline bool wide_shape_ok(const InrModelDesc* md) {
 
 #define WIDE_EW(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, s
 
+// rows short enough for the wide_out_kernel instantiations that also sum dZ_L^T (1, X) (16 more accumulators per 64-column slice)
+inline bool wide_out_has_ext(int hs) { return hs <= 9 * 64; }
+
 // forward of ONE image; with `train`: also dZ_L (w.dza), the output layer's gradients and the loss (w.grads)
 inline int wide_forward(const WideMap& m, const WideWs& w, const InrModelDesc* md, const float* params, const InrGridDesc* grid, int img,
                         const float* target, int loss_kind, bool train, float* logits, hipStream_t s) {
@@ -350,11 +408,12 @@ inline int wide_forward(const WideMap& m, const WideWs& w, const InrModelDesc* m
     const int h = m.h, C = m.C, hs = w.hs;
     if (C == 2) hipLaunchKernelGGL(wide_layer0_kernel<2>, WIDE_EW(N * (hs / 4)), *grid, img, params + m.p_win(), params + m.p_bin(), N, h, hs, w.hp, md->act0, md->act_omega, w.z[0], w.pre0);
     else hipLaunchKernelGGL(wide_layer0_kernel<3>, WIDE_EW(N * (hs / 4)), *grid, img, params + m.p_win(), params + m.p_bin(), N, h, hs, w.hp, md->act0, md->act_omega, w.z[0], w.pre0);
+    hipLaunchKernelGGL(wide_pack_weights_kernel, WIDE_EW((long long)m.L * h * w.hp), params, m, w.hp, w.wp);
     for (int k = 0; k < m.L; ++k) {
         // z_{k+1} [N x h] = relu(z_k [N x h] . W_k^T + b_k + S_k x)   (W_k stored [h_out][h_in]; bias, skip and relu in the GEMM's epilogue)
         GemmArgs g{};
-        g.A = w.z[k]; g.lda = hs; g.B = params + m.p_w(k); g.ldb = h; g.C = w.z[k + 1]; g.ldc = hs;
-        g.M = (int)N; g.N = h; g.K = h;
+        g.A = w.z[k]; g.lda = hs; g.B = w.wp + (size_t)k * h * w.hp; g.ldb = w.hp; g.C = w.z[k + 1]; g.ldc = hs;
+        g.M = (int)N; g.N = h; g.K = h; g.padA = g.padB = 1;
         g.epi = GEMM_EPI_HIDDEN; g.bias = params + m.p_b(k); g.skip = params + m.p_s(k); g.ext = w.z[k] + h; g.ext_ld = hs; g.C_in = C;
         int rc = gemm_launch(s, false, true, g);
         if (rc) return rc;
@@ -364,12 +423,16 @@ inline int wide_forward(const WideMap& m, const WideWs& w, const InrModelDesc* m
     a.zl = w.z[m.L]; a.wo = params + m.p_wo(); a.sc = params + m.p_bo(); a.target = target; a.coef = w.coef; a.logits = logits;
     a.dz = w.dza; a.part = w.part; a.lossp = w.lossp;
     a.N = N; a.h = h; a.C = C; a.hs = hs; a.hp = w.hp; a.hsv = w.hsv; a.loss_kind = loss_kind; a.train = train ? 1 : 0;
-    if (hs <= 5 * 64) hipLaunchKernelGGL(wide_out_kernel<5>, dim3(w.blocks), dim3(256), 0, s, a);
-    else if (hs <= 9 * 64) hipLaunchKernelGGL(wide_out_kernel<9>, dim3(w.blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(wide_out_kernel<WIDE_OUT_MAXQ>, dim3(w.blocks), dim3(256), 0, s, a);
+    a.part_ext = w.part2;
+    if (hs <= 5 * 64) hipLaunchKernelGGL((wide_out_kernel<5, true>), dim3(w.blocks), dim3(256), 0, s, a);
+    else if (hs <= 7 * 64) hipLaunchKernelGGL((wide_out_kernel<7, true>), dim3(w.blocks), dim3(256), 0, s, a);
+    else if (hs <= 9 * 64) hipLaunchKernelGGL((wide_out_kernel<9, true>), dim3(w.blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wide_out_kernel<WIDE_OUT_MAXQ, false>), dim3(w.blocks), dim3(256), 0, s, a);
     if (train) {
         hipLaunchKernelGGL(wide_loss_finish_kernel, dim3(1), dim3(256), 0, s, w.lossp, w.blocks, w.grads, m.P);
         hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(w.hsv), w.part, w.blocks, 1, w.hsv, 2, m, 0, w.grads);   // (dw_o | db_o | ds_o)
+        if (wide_out_has_ext(hs))   // (db | dS) of the last hidden layer = dZ_L^T (1, X), summed by the same pass
+            hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(h * (1 + C)), w.part2, w.blocks, h, 1 + C, 3, m, m.L - 1, w.grads);
     }
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
@@ -380,32 +443,37 @@ inline int wide_backward(const WideMap& m, const WideWs& w, const InrModelDesc* 
     float* gr = w.grads;
     int rc;
     float *dz = w.dza, *dzn = w.dzb;
+    const int tiles = (int)((N + GM_BM - 1) / GM_BM);
     for (int k = m.L - 1; k >= 0; --k) {
-        {   // dW_k [h x h] = dz^T Z_k: the contraction over the points, split into chunks of WIDE_CHUNK; (db_k | dS_k) = dz^T (1, X)
+        {   // dW_k [h x h] = dz^T Z_k: the contraction over the points, split into chunks of WIDE_CHUNK
             GemmArgs g{};
             g.A = dz; g.lda = hp; g.B = w.z[k]; g.ldb = hs; g.C = w.part; g.ldc = h;
-            g.M = h; g.N = h; g.K = (int)N; g.k_per_split = WIDE_CHUNK; g.c_split_stride = (long long)h * h;
+            g.M = h; g.N = h; g.K = (int)N; g.k_per_split = WIDE_CHUNK; g.c_split_stride = (long long)h * h; g.padA = g.padB = 1;
             if ((rc = gemm_launch(s, true, false, g))) return rc;
             hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(h * h), w.part, parts, h, h, 0, m, k, gr);
-            hipLaunchKernelGGL(wide_extgrad_kernel, dim3(w.blocks), dim3(256), 0, s, dz, hp, w.z[k] + h, hs, N, h, C, w.part);
-            hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(h * (1 + C)), w.part, w.blocks, h, 1 + C, 3, m, k, gr);
+            // (db_k | dS_k) = dz^T (1, X): summed by the kernel that wrote dz (wide_out_kernel for the last layer, the backward GEMM's
+            // epilogue below for the others); only rows too long for wide_out_kernel's accumulators take a pass of their own
+            if (k == m.L - 1 && !wide_out_has_ext(hs)) {
+                hipLaunchKernelGGL(wide_extgrad_kernel, dim3(w.blocks), dim3(256), 0, s, dz, hp, w.z[k] + h, hs, N, h, C, w.part2);
+                hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(h * (1 + C)), w.part2, w.blocks, h, 1 + C, 3, m, k, gr);
+            }
         }
-        {   // dz_k = (dz W_k) (.) act'(layer k)     (the mask in the GEMM's epilogue)
+        {   // dz_k = (dz W_k) (.) act'(layer k)     (the mask in the GEMM's epilogue, and dz_k^T (1, X) per 128-row tile)
             GemmArgs g{};
-            g.A = dz; g.lda = hp; g.B = params + m.p_w(k); g.ldb = h; g.C = dzn; g.ldc = hp;
-            g.M = (int)N; g.N = h; g.K = h;
+            g.A = dz; g.lda = hp; g.B = w.wp + (size_t)k * h * hp; g.ldb = hp; g.C = dzn; g.ldc = hp;   // (the weights wide_forward packed)
+            g.M = (int)N; g.N = h; g.K = h; g.padA = g.padB = 1;
             g.epi = GEMM_EPI_MASK;
             const int act = k == 0 ? md->act0 : INR_ACT_RELU;
             g.mask_act = act; g.omega = md->act_omega;
             if (act == INR_ACT_RELU) { g.mask = w.z[k]; g.mask_ld = hs; }
             else { g.mask = w.pre0; g.mask_ld = hp; }
+            g.extsum = w.part2; g.ext = w.z[k] + h; g.ext_ld = hs; g.C_in = C;
             if ((rc = gemm_launch(s, false, false, g))) return rc;
+            // what the ext inputs multiply in the layer below: (db_{k-1} | dS_{k-1}), or (db_in | dW_in) of layer 0
+            hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(h * (1 + C)), w.part2, tiles, h, 1 + C, k > 0 ? 3 : 1, m, k > 0 ? k - 1 : 0, gr);
         }
         float* t = dz; dz = dzn; dzn = t;
     }
-    // (db_in | dW_in) = dz0^T (1, X)
-    hipLaunchKernelGGL(wide_extgrad_kernel, dim3(w.blocks), dim3(256), 0, s, dz, hp, w.z[0] + h, hs, N, h, C, w.part);
-    hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(h * (1 + C)), w.part, w.blocks, h, 1 + C, 1, m, 0, gr);
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 

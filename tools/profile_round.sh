@@ -73,7 +73,9 @@ done
 fi
 if [ "$MODE" = "wide" ] || [ "$MODE" = "all" ]; then
 echo "== kernel stats of the layer-by-layer path $(date +%T)"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_wide -o wide -- python3 tools/kbench_wide.py 256x1 > $O/stats_wide.log 2>&1 || exit 1
-summ_stats $O/stats_wide wide_h256
+for shp in ${WIDE_SHAPES:-256x1}; do
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_wide -o wide -- python3 tools/kbench_wide.py $shp > $O/stats_wide_$shp.log 2>&1 || exit 1
+summ_stats $O/stats_wide wide_h${shp/x/_L}
+done
 fi
 rm -f $O/*.log.tmp; du -sh $O; ls -la $O
