@@ -51,6 +51,7 @@ struct GemmArgs {
     const float* skip;     // HIDDEN: S [N][C]
     const float* ext;      // HIDDEN: x_c of row m = ext[m * ext_ld + 1 + c] (the ext columns (1, x) of the previous layer's activations)
     int ext_ld, C_in;
+    int ext_copy;          // HIDDEN: also C[m][N .. N + ext_copy) = ext[m][0 .. ext_copy) (the ext columns and padding of the activation rows travel along)
     const float* mask;     // MASK: multiply by [mask[m * mask_ld + n] > 0] (mask_act == relu) or by the activation's derivative at it
     int mask_ld, mask_act;
     float omega;
@@ -387,6 +388,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V4 ? GM_WAV
                 }
             }
         }
+    }
+    if (a.epi == GEMM_EPI_HIDDEN && a.ext_copy > 0 && bx == (int)gridDim.x - 1 && tid < GM_BM && m0 + tid < a.M) {
+        const float* src = a.ext + (size_t)(m0 + tid) * a.ext_ld;
+        float* dst = Cz + (size_t)(m0 + tid) * a.ldc + a.N;
+        for (int c = 0; c < a.ext_copy; ++c) dst[c] = src[c];
     }
     if (!TA && !TB && a.extsum) {
         // the column sums of the tile: lanes that share a column (4 row groups g, 2 waves wm) through LDS, added in a fixed order

@@ -56,20 +56,24 @@ constexpr int WIDE_MAX_HIDDEN_PAD = (WIDE_MAX_HIDDEN + 1 + 3 + 3) / 4 * 4;   // 
 
 // z0[p][j] = act0(W_in[j] . x_p + b_in[j]) for j < h, the ext columns (1, x) for h <= j < h + 1 + C, zeros in the padding; pre0
 // (optional, [N][hp]) keeps the pre-activation for the periodic activations' derivative.  Reads the coordinates from the grid descriptor.
+constexpr int WIDE_L0_POINTS = 64;
 template <int C>
 __global__ __launch_bounds__(256) void wide_layer0_kernel(InrGridDesc gd, int img, const float* __restrict__ win, const float* __restrict__ bin,
                                                           long long N, int h, int hs, int hp, int act0, float omega, float* __restrict__ z0,
                                                           float* __restrict__ pre0) {
-    // a thread writes four consecutive columns of one point's row (hs is a multiple of 4): rows are cut into hs / 4 quads
+    // a thread writes four consecutive columns of one point's row (hs is a multiple of 4): rows are cut into hs / 4 quads; a block
+    // covers WIDE_L0_POINTS points (32-bit index arithmetic inside the block)
     const int nq = hs >> 2;
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= N * nq) return;
-    const long long p = e / nq;
-    const int j0 = 4 * (int)(e - p * nq);
+    const int idx = blockIdx.y * 256 + threadIdx.x;
+    if (idx >= WIDE_L0_POINTS * nq) return;
+    const int pl = idx / nq;
+    const long long p = (long long)blockIdx.x * WIDE_L0_POINTS + pl;
+    if (p >= N) return;
+    const int j0 = 4 * (idx - pl * nq);
     float x[C];
     if (gd.mode == INR_GRID_SEPARABLE) {
-        const int row = (int)(p / gd.width);
-        x[0] = gd.xs[p - (long long)row * gd.width];
+        const unsigned pu = (unsigned)p, row = pu / (unsigned)gd.width;   // (an image of this path has < 2^32 points: 1 KB of activations each)
+        x[0] = gd.xs[pu - row * (unsigned)gd.width];
         x[1] = gd.ys[row];
         if (C > 2) x[C - 1] = gd.ts ? gd.ts[img] : 0.f;
     } else {
@@ -96,16 +100,6 @@ __global__ __launch_bounds__(256) void wide_layer0_kernel(InrGridDesc gd, int im
         out[q] = v;
     }
     *(f32x4*)(z0 + (size_t)p * hs + j0) = out;
-}
-
-// the ext columns (and the zero padding) of a layer's activations are those of the layer below: z[p][h ..hs) = zprev[p][h .. hs)
-__global__ __launch_bounds__(256) void wide_copy_ext_kernel(float* __restrict__ z, const float* __restrict__ zprev, long long N, int h, int hs) {
-    const int ne = hs - h;
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= N * ne) return;
-    const long long p = e / ne;
-    const int j = h + (int)(e - p * ne);
-    z[p * hs + j] = zprev[p * hs + j];
 }
 
 // the hidden layers' weight matrices W_k [h][h] (flat parameters, row stride h: rows on 16-byte boundaries only where h is a multiple
@@ -141,8 +135,7 @@ constexpr int WIDE_OUT_MAXQ = (WIDE_MAX_HIDDEN_PAD + 63) / 64;   // f32x4 per la
 template <int WIDE_OUT_NQ, bool EXT>   // 64-column slices a row may have (register budget of the instantiation); EXT: also dZ_L^T (1, X)
 __global__ __launch_bounds__(256) void wide_out_kernel(const WideOutArgs a) {
     __shared__ float sm[4];
-    __shared__ float colp[16][68];          // per row-group partial column sums of one 64-column slice
-    __shared__ f32x4 colp4[EXT ? 16 : 1][EXT ? 65 : 1];
+    __shared__ float colw[4][5][64];        // per wave: the column sums of one 64-column slice (output layer; (1, x) sums)
     const int tid = threadIdx.x, l15 = tid & 15, rg = tid >> 4;      // 16 lanes per point, 16 row groups
     const long long p0 = (long long)blockIdx.x * WIDE_OUT_CHUNK;
     const int nq = (a.hs + 63) / 64;        // 64-column slices of a row (16 lanes x 4 floats)
@@ -227,43 +220,47 @@ __global__ __launch_bounds__(256) void wide_out_kernel(const WideOutArgs a) {
         __syncthreads();
         if (tid == 0) a.lossp[blockIdx.x] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
     }
-    // column sums over the block's 16 row groups, slice by slice through LDS, row groups added in order
+    // column sums over the block's 16 row groups: the four groups of a wave by lane exchange (every lane group then holds the wave's
+    // totals; group g keeps column 4 l15 + g), the four waves through LDS, added in order
+    const int wv = tid >> 6, gl = (tid >> 4) & 3;
     for (int q = 0; q < nq; ++q) {
-        __syncthreads();
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 gs = f32x4{0.f, 0.f, 0.f, 0.f}, es[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) es[e] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int qq = 0; qq < WIDE_OUT_NQ; ++qq)
-            if (qq == q) v = gacc[qq];
-        *(f32x4*)&colp[rg][4 * l15] = v;
+            if (qq == q) {
+                gs = gacc[qq];
+                if (EXT) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) es[e] = eacc[EXT ? qq : 0][e];
+                }
+            }
+        float mine[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // column 4 l15 + gl: the output-layer sum, then the (1, x) sums
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = sum_over_groups(gs[e]);
+            mine[0] = gl == e ? t : mine[0];
+            if (EXT) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float u = sum_over_groups(es[e][c]);
+                    mine[1 + c] = gl == e ? u : mine[1 + c];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < (EXT ? 5 : 1); ++c) colw[wv][c][4 * l15 + gl] = mine[c];
         __syncthreads();
         if (tid < 64) {
-            float t = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) t += colp[r][tid];
             const int j = 64 * q + tid;
-            if (j < a.hsv) a.part[(size_t)blockIdx.x * a.hsv + j] = t;
-        }
-    }
-    if (EXT) {   // the same for dZ_L^T (1, X): four values per column
-        for (int q = 0; q < nq; ++q) {
+            float t[5];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                __syncthreads();
-                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int qq = 0; qq < WIDE_OUT_NQ; ++qq)
-                    if (qq == q) v = eacc[EXT ? qq : 0][e];
-                colp4[EXT ? rg : 0][EXT ? 4 * l15 + e : 0] = v;
-            }
-            __syncthreads();
-            if (tid < 64) {
-                f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t += colp4[EXT ? r : 0][EXT ? tid : 0];
-                const int j = 64 * q + tid;
-                if (j < a.h)
-                    for (int c = 0; c <= a.C; ++c) a.part_ext[((size_t)blockIdx.x * a.h + j) * (1 + a.C) + c] = t[c];
-            }
+            for (int c = 0; c < (EXT ? 5 : 1); ++c) t[c] = ((colw[0][c][tid] + colw[1][c][tid]) + colw[2][c][tid]) + colw[3][c][tid];
+            if (j < a.hsv) a.part[(size_t)blockIdx.x * a.hsv + j] = t[0];
+            if (EXT && j < a.h)
+                for (int c = 0; c <= a.C; ++c) a.part_ext[((size_t)blockIdx.x * a.h + j) * (1 + a.C) + c] = t[1 + c];
         }
     }
 }
@@ -324,13 +321,13 @@ __global__ __launch_bounds__(256) void wide_extgrad_kernel(const float* __restri
 //   mode 1 (layer 0, B = the ext columns):           column 0 -> b_in[i]; j >= 1 -> W_in[i][j - 1]
 //   mode 3 (hidden layer k, the ext columns only):   column 0 -> b_k[i];  j >= 1 -> S_k[i][j - 1]
 //   mode 2 (output layer, a = 1, b = hs):            column j < h -> w_o[j]; j == h -> b_o; j > h -> s_o[j - h - 1]
-__global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restrict__ part, int parts, int a, int b, int mode, WideMap m, int k,
+__global__ __launch_bounds__(1024) void wide_reduce_kernel(const float* __restrict__ part, int parts, int a, int b, int mode, WideMap m, int k,
                                                           float* __restrict__ grads) {
-    // 64 consecutive elements per block, the partials in four contiguous ranges (one per wave) summed in order, ranges added in order
-    __shared__ float sm[4][64];
+    // 64 consecutive elements per block, the partials in 16 contiguous ranges (one per wave) summed in order, ranges added in order
+    __shared__ float sm[16][64];
     const int el = threadIdx.x & 63, pg = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + el;
-    const int per = (parts + 3) / 4, q0 = pg * per, q1 = q0 + per < parts ? q0 + per : parts;
+    const int per = (parts + 15) / 16, q0 = pg * per, q1 = q0 + per < parts ? q0 + per : parts;
     float v = 0.f;
     if (e < a * b) {
 #pragma unroll 8
@@ -339,7 +336,9 @@ __global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restric
     sm[pg][el] = v;
     __syncthreads();
     if (pg != 0 || e >= a * b) return;
-    v = ((sm[0][el] + sm[1][el]) + sm[2][el]) + sm[3][el];
+    v = sm[0][el];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) v += sm[r][el];
     const int i = e / b, j = e - i * b;
     int dst;
     if (mode == 0) dst = j < m.h ? m.p_w(k) + i * m.h + j : (j == m.h ? m.p_b(k) + i : m.p_s(k) + i * m.C + (j - m.h - 1));
@@ -348,7 +347,7 @@ __global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restric
     else dst = j < m.h ? m.p_wo() + j : (j == m.h ? m.p_bo() : m.p_so() + (j - m.h - 1));
     grads[dst] = v;
 }
-#define WIDE_RED(n) dim3((unsigned)(((n) + 63) / 64)), dim3(256), 0, s
+#define WIDE_RED(n) dim3((unsigned)(((n) + 63) / 64)), dim3(1024), 0, s
 
 // ---- workspace --------------------------------------------------------------------------------------------------------------------------
 struct WideWs {
@@ -406,18 +405,18 @@ inline int wide_forward(const WideMap& m, const WideWs& w, const InrModelDesc* m
                         const float* target, int loss_kind, bool train, float* logits, hipStream_t s) {
     const long long N = grid->n_points;
     const int h = m.h, C = m.C, hs = w.hs;
-    if (C == 2) hipLaunchKernelGGL(wide_layer0_kernel<2>, WIDE_EW(N * (hs / 4)), *grid, img, params + m.p_win(), params + m.p_bin(), N, h, hs, w.hp, md->act0, md->act_omega, w.z[0], w.pre0);
-    else hipLaunchKernelGGL(wide_layer0_kernel<3>, WIDE_EW(N * (hs / 4)), *grid, img, params + m.p_win(), params + m.p_bin(), N, h, hs, w.hp, md->act0, md->act_omega, w.z[0], w.pre0);
+    const dim3 l0grid((unsigned)((N + WIDE_L0_POINTS - 1) / WIDE_L0_POINTS), (unsigned)((WIDE_L0_POINTS * (hs / 4) + 255) / 256));
+    if (C == 2) hipLaunchKernelGGL(wide_layer0_kernel<2>, l0grid, dim3(256), 0, s, *grid, img, params + m.p_win(), params + m.p_bin(), N, h, hs, w.hp, md->act0, md->act_omega, w.z[0], w.pre0);
+    else hipLaunchKernelGGL(wide_layer0_kernel<3>, l0grid, dim3(256), 0, s, *grid, img, params + m.p_win(), params + m.p_bin(), N, h, hs, w.hp, md->act0, md->act_omega, w.z[0], w.pre0);
     hipLaunchKernelGGL(wide_pack_weights_kernel, WIDE_EW((long long)m.L * h * w.hp), params, m, w.hp, w.wp);
     for (int k = 0; k < m.L; ++k) {
         // z_{k+1} [N x h] = relu(z_k [N x h] . W_k^T + b_k + S_k x)   (W_k stored [h_out][h_in]; bias, skip and relu in the GEMM's epilogue)
         GemmArgs g{};
         g.A = w.z[k]; g.lda = hs; g.B = w.wp + (size_t)k * h * w.hp; g.ldb = w.hp; g.C = w.z[k + 1]; g.ldc = hs;
         g.M = (int)N; g.N = h; g.K = h; g.padA = g.padB = 1;
-        g.epi = GEMM_EPI_HIDDEN; g.bias = params + m.p_b(k); g.skip = params + m.p_s(k); g.ext = w.z[k] + h; g.ext_ld = hs; g.C_in = C;
+        g.epi = GEMM_EPI_HIDDEN; g.bias = params + m.p_b(k); g.skip = params + m.p_s(k); g.ext = w.z[k] + h; g.ext_ld = hs; g.C_in = C; g.ext_copy = hs - h;
         int rc = gemm_launch(s, false, true, g);
         if (rc) return rc;
-        hipLaunchKernelGGL(wide_copy_ext_kernel, WIDE_EW(N * (hs - h)), w.z[k + 1], w.z[k], N, h, hs);
     }
     WideOutArgs a{};
     a.zl = w.z[m.L]; a.wo = params + m.p_wo(); a.sc = params + m.p_bo(); a.target = target; a.coef = w.coef; a.logits = logits;
