@@ -56,50 +56,67 @@ constexpr int WIDE_MAX_HIDDEN_PAD = (WIDE_MAX_HIDDEN + 1 + 3 + 3) / 4 * 4;   // 
 
 // z0[p][j] = act0(W_in[j] . x_p + b_in[j]) for j < h, the ext columns (1, x) for h <= j < h + 1 + C, zeros in the padding; pre0
 // (optional, [N][hp]) keeps the pre-activation for the periodic activations' derivative.  Reads the coordinates from the grid descriptor.
-constexpr int WIDE_L0_POINTS = 64;
+constexpr int WIDE_L0_POINTS = 64, WIDE_L0_REP = 4;
 template <int C>
 __global__ __launch_bounds__(256) void wide_layer0_kernel(InrGridDesc gd, int img, const float* __restrict__ win, const float* __restrict__ bin,
                                                           long long N, int h, int hs, int hp, int act0, float omega, float* __restrict__ z0,
                                                           float* __restrict__ pre0) {
-    // a thread writes four consecutive columns of one point's row (hs is a multiple of 4): rows are cut into hs / 4 quads; a block
-    // covers WIDE_L0_POINTS points (32-bit index arithmetic inside the block)
+    // a thread writes four consecutive columns (hs is a multiple of 4: rows are cut into hs / 4 quads) of WIDE_L0_REP points'
+    // rows, WIDE_L0_POINTS apart: its layer-0 weights are read once, the points' coordinates are all requested before the first
+    // row is computed (32-bit index arithmetic inside the block)
     const int nq = hs >> 2;
     const int idx = blockIdx.y * 256 + threadIdx.x;
     if (idx >= WIDE_L0_POINTS * nq) return;
     const int pl = idx / nq;
-    const long long p = (long long)blockIdx.x * WIDE_L0_POINTS + pl;
-    if (p >= N) return;
     const int j0 = 4 * (idx - pl * nq);
-    float x[C];
-    if (gd.mode == INR_GRID_SEPARABLE) {
-        const unsigned pu = (unsigned)p, row = pu / (unsigned)gd.width;   // (an image of this path has < 2^32 points: 1 KB of activations each)
-        x[0] = gd.xs[pu - row * (unsigned)gd.width];
-        x[1] = gd.ys[row];
-        if (C > 2) x[C - 1] = gd.ts ? gd.ts[img] : 0.f;
-    } else {
-        const float* cp = gd.coords + (size_t)img * gd.coords_image_stride;
+    const long long pb = (long long)blockIdx.x * (WIDE_L0_POINTS * WIDE_L0_REP) + pl;
+    float x[WIDE_L0_REP][C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) x[c] = cp[(size_t)c * N + p];
+    for (int r = 0; r < WIDE_L0_REP; ++r) {
+        const long long pv = pb + r * WIDE_L0_POINTS, p = pv < N ? pv : N - 1;
+        if (gd.mode == INR_GRID_SEPARABLE) {
+            const unsigned pu = (unsigned)p, row = pu / (unsigned)gd.width;   // (an image of this path has < 2^32 points: 1 KB of activations each)
+            x[r][0] = gd.xs[pu - row * (unsigned)gd.width];
+            x[r][1] = gd.ys[row];
+            if (C > 2) x[r][C - 1] = gd.ts ? gd.ts[img] : 0.f;
+        } else {
+            const float* cp = gd.coords + (size_t)img * gd.coords_image_stride;
+#pragma unroll
+            for (int c = 0; c < C; ++c) x[r][c] = cp[(size_t)c * N + p];
+        }
     }
-    f32x4 out;
+    float bq[4], wq[4][C];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int j = j0 + q;
-        float v;
-        if (j >= h) {
-            v = j == h ? 1.f : 0.f;
+        const int j = j0 + q < h ? j0 + q : h - 1;
+        bq[q] = bin[j];
 #pragma unroll
-            for (int c = 0; c < C; ++c) v = (j == h + 1 + c) ? x[c] : v;
-        } else {
-            v = bin[j];
-#pragma unroll
-            for (int c = 0; c < C; ++c) v = fmaf(win[j * C + c], x[c], v);
-            if (pre0) pre0[p * hp + j] = v;
-            v = act0 == INR_ACT_COS ? hw_cos(v) : (act0 == INR_ACT_SIN ? hw_sin(omega * v) : fmaxf(v, 0.f));
-        }
-        out[q] = v;
+        for (int c = 0; c < C; ++c) wq[q][c] = win[j * C + c];
     }
-    *(f32x4*)(z0 + (size_t)p * hs + j0) = out;
+#pragma unroll
+    for (int r = 0; r < WIDE_L0_REP; ++r) {
+        const long long p = pb + r * WIDE_L0_POINTS;
+        if (p >= N) break;
+        f32x4 out;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = j0 + q;
+            float v;
+            if (j >= h) {
+                v = j == h ? 1.f : 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) v = (j == h + 1 + c) ? x[r][c] : v;
+            } else {
+                v = bq[q];
+#pragma unroll
+                for (int c = 0; c < C; ++c) v = fmaf(wq[q][c], x[r][c], v);
+                if (pre0) pre0[p * hp + j] = v;
+                v = act0 == INR_ACT_COS ? hw_cos(v) : (act0 == INR_ACT_SIN ? hw_sin(omega * v) : fmaxf(v, 0.f));
+            }
+            out[q] = v;
+        }
+        *(f32x4*)(z0 + (size_t)p * hs + j0) = out;
+    }
 }
 
 // the hidden layers' weight matrices W_k [h][h] (flat parameters, row stride h: rows on 16-byte boundaries only where h is a multiple
@@ -148,6 +165,25 @@ __global__ __launch_bounds__(256) void wide_out_kernel(const WideOutArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) eacc[q][e] = f32x4{0.f, 0.f, 0.f, 0.f};
     float lsum = 0.f;
+    // the lane's columns: 4 l15 .. + 3 of every 64-column slice; their output weights once (0 past h), the rows of the NEXT 16 points
+    // requested (unguarded, from clamped addresses) before this iteration's arithmetic
+    f32x4 wq[WIDE_OUT_NQ];
+    bool cq[WIDE_OUT_NQ];
+#pragma unroll
+    for (int q = 0; q < WIDE_OUT_NQ; ++q) {
+        const int j = 64 * q + 4 * l15;
+        cq[q] = q < nq && j < a.hs;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wq[q][e] = j + e < a.h ? a.wo[j + e] : 0.f;
+    }
+    auto load_row = [&](int it, f32x4 (&z)[WIDE_OUT_NQ]) {
+        const long long p = p0 + it * 16 + rg;
+        const float* zr = a.zl + (size_t)(p < a.N ? p : 0) * a.hs;
+#pragma unroll
+        for (int q = 0; q < WIDE_OUT_NQ; ++q) z[q] = *(const f32x4*)(zr + (cq[q] ? 64 * q + 4 * l15 : 0));
+    };
+    f32x4 zn[WIDE_OUT_NQ];
+    load_row(0, zn);
     for (int it = 0; it < WIDE_OUT_CHUNK / 16; ++it) {
         const long long p = p0 + it * 16 + rg;
         const bool valid = p < a.N;
@@ -156,13 +192,13 @@ __global__ __launch_bounds__(256) void wide_out_kernel(const WideOutArgs a) {
         float ypart = 0.f;
 #pragma unroll
         for (int q = 0; q < WIDE_OUT_NQ; ++q) {
-            const int j = 64 * q + 4 * l15;
-            zq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (q < nq && j < a.hs) zq[q] = *(const f32x4*)(zr + j);          // hs is a multiple of 4: whole vectors
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (j + e < a.h) ypart = fmaf(a.wo[j + e], zq[q][e], ypart);
+            for (int e = 0; e < 4; ++e) {
+                zq[q][e] = cq[q] ? zn[q][e] : 0.f;
+                ypart = fmaf(wq[q][e], zq[q][e], ypart);
+            }
         }
+        if (it + 1 < WIDE_OUT_CHUNK / 16) load_row(it + 1, zn);
         ypart = sum_over_points(ypart);     // over the 16 lanes of the point (one DPP row)
         float y = ypart + a.sc[0];
         f32x4 xe = f32x4{1.f, 0.f, 0.f, 0.f};   // the point's ext inputs (1, x)
@@ -203,7 +239,7 @@ __global__ __launch_bounds__(256) void wide_out_kernel(const WideOutArgs a) {
                 if (valid && j < a.hp) {
                     f32x4 d;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) d[e] = (j + e < a.h && zq[q][e] > 0.f) ? dy * a.wo[j + e] : 0.f;
+                    for (int e = 0; e < 4; ++e) d[e] = zq[q][e] > 0.f ? dy * wq[q][e] : 0.f;   // (w_o = 0 past h)
                     *(f32x4*)(dr + j) = d;   // hp is a multiple of 4; the padding columns get zeros
                     if (EXT) {
 #pragma unroll
@@ -405,7 +441,7 @@ inline int wide_forward(const WideMap& m, const WideWs& w, const InrModelDesc* m
                         const float* target, int loss_kind, bool train, float* logits, hipStream_t s) {
     const long long N = grid->n_points;
     const int h = m.h, C = m.C, hs = w.hs;
-    const dim3 l0grid((unsigned)((N + WIDE_L0_POINTS - 1) / WIDE_L0_POINTS), (unsigned)((WIDE_L0_POINTS * (hs / 4) + 255) / 256));
+    const dim3 l0grid((unsigned)((N + WIDE_L0_POINTS * WIDE_L0_REP - 1) / (WIDE_L0_POINTS * WIDE_L0_REP)), (unsigned)((WIDE_L0_POINTS * (hs / 4) + 255) / 256));
     if (C == 2) hipLaunchKernelGGL(wide_layer0_kernel<2>, l0grid, dim3(256), 0, s, *grid, img, params + m.p_win(), params + m.p_bin(), N, h, hs, w.hp, md->act0, md->act_omega, w.z[0], w.pre0);
     else hipLaunchKernelGGL(wide_layer0_kernel<3>, l0grid, dim3(256), 0, s, *grid, img, params + m.p_win(), params + m.p_bin(), N, h, hs, w.hp, md->act0, md->act_omega, w.z[0], w.pre0);
     hipLaunchKernelGGL(wide_pack_weights_kernel, WIDE_EW((long long)m.L * h * w.hp), params, m, w.hp, w.wp);
