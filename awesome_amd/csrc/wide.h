@@ -60,11 +60,20 @@ constexpr int WIDE_L0_POINTS = 64, WIDE_L0_REP = 4;
 template <int C>
 __global__ __launch_bounds__(256) void wide_layer0_kernel(InrGridDesc gd, int img, const float* __restrict__ win, const float* __restrict__ bin,
                                                           long long N, int h, int hs, int hp, int act0, float omega, float* __restrict__ z0,
-                                                          float* __restrict__ pre0) {
+                                                          float* __restrict__ pre0, int pt_blocks, const float* __restrict__ params, WideMap pk,
+                                                          float* __restrict__ wp) {
     // a thread writes four consecutive columns (hs is a multiple of 4: rows are cut into hs / 4 quads) of WIDE_L0_REP points'
     // rows, WIDE_L0_POINTS apart: its layer-0 weights are read once, the points' coordinates are all requested before the first
     // row is computed (32-bit index arithmetic inside the block)
     const int nq = hs >> 2;
+    if ((int)blockIdx.x >= pt_blocks) {   // the launch's last blocks: hidden-layer weights -> [L][h][hp], zero padded (gemm.h V4 operands)
+        const int per = pk.h * hp, e = (((int)blockIdx.x - pt_blocks) * gridDim.y + blockIdx.y) * 256 + threadIdx.x;
+        if (e < pk.L * per) {
+            const int k = e / per, r = e - k * per, i = r / hp, j = r - i * hp;
+            wp[e] = j < pk.h ? params[pk.p_w(k) + i * pk.h + j] : 0.f;
+        }
+        return;
+    }
     const int idx = blockIdx.y * 256 + threadIdx.x;
     if (idx >= WIDE_L0_POINTS * nq) return;
     const int pl = idx / nq;
@@ -119,16 +128,6 @@ __global__ __launch_bounds__(256) void wide_layer0_kernel(InrGridDesc gd, int im
     }
 }
 
-// the hidden layers' weight matrices W_k [h][h] (flat parameters, row stride h: rows on 16-byte boundaries only where h is a multiple
-// of 4) copied into [L][h][hp] with zero padding: every GEMM operand of the path then takes 16-byte loads (gemm.h, V4)
-__global__ __launch_bounds__(256) void wide_pack_weights_kernel(const float* __restrict__ params, WideMap m, int hp, float* __restrict__ wp) {
-    const int per = m.h * hp;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= m.L * per) return;
-    const int k = e / per, r = e - k * per, i = r / hp, j = r - i * hp;
-    wp[e] = j < m.h ? params[m.p_w(k) + i * m.h + j] : 0.f;
-}
-
 // ONE pass over the last layer's activations Z_L [N][hs] (16 lanes per point, 16 points per iteration, WIDE_OUT_CHUNK points per block):
 //   y = w_o . z_L + b_o + s_o . x  -> logits;   TRAIN: sigmoid, data term -> dy, the loss partial of the block;
 //   dZ_L[p][j] = dy w_o[j] [z_L[p][j] > 0]  (the row is still in the cache);
@@ -142,9 +141,8 @@ struct WideOutArgs {
     const float* coef;      // c_fg, c_bg of this image
     float* logits;          // [N] or null
     float* dz;              // [N][hp] (train)
-    float* part;            // [blocks][hsv] output-layer gradient partials (train)
+    float* part;            // [blocks][hsv + 1] output-layer gradient partials, then the block's loss partial (train)
     float* part_ext;        // [blocks][h][1 + C] partials of (db | dS) of the last hidden layer = dZ_L^T (1, X) (train, EXT instantiations)
-    float* lossp;           // [blocks] loss partials (train)
     long long N;
     int h, C, hs, hp, hsv, loss_kind, train;
 };
@@ -254,7 +252,7 @@ __global__ __launch_bounds__(256) void wide_out_kernel(const WideOutArgs a) {
         const float v = sum_over_groups(sum_over_points(lsum));
         if ((tid & 63) == 0) sm[tid >> 6] = v;
         __syncthreads();
-        if (tid == 0) a.lossp[blockIdx.x] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+        if (tid == 0) a.part[(size_t)blockIdx.x * (a.hsv + 1) + a.hsv] = ((sm[0] + sm[1]) + sm[2]) + sm[3];   // one more column of the partials
     }
     // column sums over the block's 16 row groups: the four groups of a wave by lane exchange (every lane group then holds the wave's
     // totals; group g keeps column 4 l15 + g), the four waves through LDS, added in order
@@ -294,22 +292,11 @@ __global__ __launch_bounds__(256) void wide_out_kernel(const WideOutArgs a) {
             float t[5];
 #pragma unroll
             for (int c = 0; c < (EXT ? 5 : 1); ++c) t[c] = ((colw[0][c][tid] + colw[1][c][tid]) + colw[2][c][tid]) + colw[3][c][tid];
-            if (j < a.hsv) a.part[(size_t)blockIdx.x * a.hsv + j] = t[0];
+            if (j < a.hsv) a.part[(size_t)blockIdx.x * (a.hsv + 1) + j] = t[0];
             if (EXT && j < a.h)
                 for (int c = 0; c <= a.C; ++c) a.part_ext[((size_t)blockIdx.x * a.h + j) * (1 + a.C) + c] = t[1 + c];
         }
     }
-}
-
-// one block: fixed-order total of the loss partials -> grads[P]
-__global__ __launch_bounds__(256) void wide_loss_finish_kernel(const float* __restrict__ part, int blocks, float* __restrict__ grads, int P) {
-    __shared__ float sm[4];
-    float v = 0.f;
-    for (int b = threadIdx.x; b < blocks; b += 256) v += part[b];
-    v = sum_over_groups(sum_over_points(v));
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) grads[P] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
 }
 
 // gradients w.r.t. everything the "ext" inputs (1, x) multiply - (db_k | dS_k) of a hidden layer, (db_in | dW_in) of layer 0:
@@ -356,7 +343,7 @@ __global__ __launch_bounds__(256) void wide_extgrad_kernel(const float* __restri
 //   mode 0 (hidden layer k): row i = unit, column j < h -> W_k[i][j]; j == h -> b_k[i]; j > h -> S_k[i][j - h - 1]
 //   mode 1 (layer 0, B = the ext columns):           column 0 -> b_in[i]; j >= 1 -> W_in[i][j - 1]
 //   mode 3 (hidden layer k, the ext columns only):   column 0 -> b_k[i];  j >= 1 -> S_k[i][j - 1]
-//   mode 2 (output layer, a = 1, b = hs):            column j < h -> w_o[j]; j == h -> b_o; j > h -> s_o[j - h - 1]
+//   mode 2 (output layer, a = 1, b = hsv + 1):       column j < h -> w_o[j]; j == h -> b_o; h < j <= h + C -> s_o[j - h - 1]; the last -> the loss
 __global__ __launch_bounds__(1024) void wide_reduce_kernel(const float* __restrict__ part, int parts, int a, int b, int mode, WideMap m, int k,
                                                           float* __restrict__ grads) {
     // 64 consecutive elements per block, the partials in 16 contiguous ranges (one per wave) summed in order, ranges added in order
@@ -380,14 +367,14 @@ __global__ __launch_bounds__(1024) void wide_reduce_kernel(const float* __restri
     if (mode == 0) dst = j < m.h ? m.p_w(k) + i * m.h + j : (j == m.h ? m.p_b(k) + i : m.p_s(k) + i * m.C + (j - m.h - 1));
     else if (mode == 3) dst = j == 0 ? m.p_b(k) + i : m.p_s(k) + i * m.C + (j - 1);
     else if (mode == 1) dst = j == 0 ? m.p_bin() + i : m.p_win() + i * m.C + (j - 1);
-    else dst = j < m.h ? m.p_wo() + j : (j == m.h ? m.p_bo() : m.p_so() + (j - m.h - 1));
+    else dst = j < m.h ? m.p_wo() + j : (j == m.h ? m.p_bo() : (j <= m.h + m.C ? m.p_so() + (j - m.h - 1) : m.P));   // (last column: the loss)
     grads[dst] = v;
 }
 #define WIDE_RED(n) dim3((unsigned)(((n) + 63) / 64)), dim3(1024), 0, s
 
 // ---- workspace --------------------------------------------------------------------------------------------------------------------------
 struct WideWs {
-    float *z[WIDE_MAX_LAYERS + 1], *pre0, *dza, *dzb, *part, *part2, *lossp, *grads, *coef, *wp;
+    float *z[WIDE_MAX_LAYERS + 1], *pre0, *dza, *dzb, *part, *part2, *grads, *coef, *wp;
     int blocks;            // blocks of wide_out_kernel / wide_l0grad_kernel (WIDE_OUT_CHUNK points each)
     int hs, hp, hsv;       // row length of the activations (multiple of 4), of the dz / pre0 buffers (multiple of 4), h + 1 + C
     long long bytes;
@@ -408,13 +395,12 @@ inline WideWs carve_wide(const WideMap& m, long long N, bool need_pre0, void* ba
     w.pre0 = need_pre0 ? take(N * w.hp * 4) : nullptr;
     w.dza = take(N * w.hp * 4);
     w.dzb = take(N * w.hp * 4);
-    const long long part_gemm = (long long)splitk_parts(N) * m.h * m.h, part_out = (long long)w.blocks * (w.hsv > m.h * (1 + m.C) ? w.hsv : m.h * (1 + m.C));
+    const long long part_gemm = (long long)splitk_parts(N) * m.h * m.h, part_out = (long long)w.blocks * (w.hsv + 1 > m.h * (1 + m.C) ? w.hsv + 1 : m.h * (1 + m.C));
     w.part = take((part_gemm > part_out ? part_gemm : part_out) * 4);
     {   // (db | dS) partials: one [h][1 + C] block per wide_out_kernel block / per 128-row tile of the backward GEMM
         const long long tiles = (N + GM_BM - 1) / GM_BM;
         w.part2 = take((w.blocks > tiles ? w.blocks : tiles) * m.h * (1 + m.C) * 4);
     }
-    w.lossp = take((long long)w.blocks * 4);
     w.grads = take(((long long)m.P + 1 + 31) / 32 * 32 * 4);
     w.wp = take((long long)m.L * m.h * w.hp * 4);
     w.coef = nullptr;
@@ -441,10 +427,13 @@ inline int wide_forward(const WideMap& m, const WideWs& w, const InrModelDesc* m
                         const float* target, int loss_kind, bool train, float* logits, hipStream_t s) {
     const long long N = grid->n_points;
     const int h = m.h, C = m.C, hs = w.hs;
-    const dim3 l0grid((unsigned)((N + WIDE_L0_POINTS * WIDE_L0_REP - 1) / (WIDE_L0_POINTS * WIDE_L0_REP)), (unsigned)((WIDE_L0_POINTS * (hs / 4) + 255) / 256));
-    if (C == 2) hipLaunchKernelGGL(wide_layer0_kernel<2>, l0grid, dim3(256), 0, s, *grid, img, params + m.p_win(), params + m.p_bin(), N, h, hs, w.hp, md->act0, md->act_omega, w.z[0], w.pre0);
-    else hipLaunchKernelGGL(wide_layer0_kernel<3>, l0grid, dim3(256), 0, s, *grid, img, params + m.p_win(), params + m.p_bin(), N, h, hs, w.hp, md->act0, md->act_omega, w.z[0], w.pre0);
-    hipLaunchKernelGGL(wide_pack_weights_kernel, WIDE_EW((long long)m.L * h * w.hp), params, m, w.hp, w.wp);
+    // layer 0 (+ in the launch's last blocks: the padded copy of the hidden layers' weights)
+    const int pt_blocks = (int)((N + WIDE_L0_POINTS * WIDE_L0_REP - 1) / (WIDE_L0_POINTS * WIDE_L0_REP));
+    const unsigned l0y = (unsigned)((WIDE_L0_POINTS * (hs / 4) + 255) / 256);
+    const int pk_blocks = (int)(((long long)m.L * h * w.hp + 256ll * l0y - 1) / (256ll * l0y));
+    const dim3 l0grid((unsigned)(pt_blocks + pk_blocks), l0y);
+    if (C == 2) hipLaunchKernelGGL(wide_layer0_kernel<2>, l0grid, dim3(256), 0, s, *grid, img, params + m.p_win(), params + m.p_bin(), N, h, hs, w.hp, md->act0, md->act_omega, w.z[0], w.pre0, pt_blocks, params, m, w.wp);
+    else hipLaunchKernelGGL(wide_layer0_kernel<3>, l0grid, dim3(256), 0, s, *grid, img, params + m.p_win(), params + m.p_bin(), N, h, hs, w.hp, md->act0, md->act_omega, w.z[0], w.pre0, pt_blocks, params, m, w.wp);
     for (int k = 0; k < m.L; ++k) {
         // z_{k+1} [N x h] = relu(z_k [N x h] . W_k^T + b_k + S_k x)   (W_k stored [h_out][h_in]; bias, skip and relu in the GEMM's epilogue)
         GemmArgs g{};
@@ -456,7 +445,7 @@ inline int wide_forward(const WideMap& m, const WideWs& w, const InrModelDesc* m
     }
     WideOutArgs a{};
     a.zl = w.z[m.L]; a.wo = params + m.p_wo(); a.sc = params + m.p_bo(); a.target = target; a.coef = w.coef; a.logits = logits;
-    a.dz = w.dza; a.part = w.part; a.lossp = w.lossp;
+    a.dz = w.dza; a.part = w.part;
     a.N = N; a.h = h; a.C = C; a.hs = hs; a.hp = w.hp; a.hsv = w.hsv; a.loss_kind = loss_kind; a.train = train ? 1 : 0;
     a.part_ext = w.part2;
     if (hs <= 5 * 64) hipLaunchKernelGGL((wide_out_kernel<5, true>), dim3(w.blocks), dim3(256), 0, s, a);
@@ -464,8 +453,7 @@ inline int wide_forward(const WideMap& m, const WideWs& w, const InrModelDesc* m
     else if (hs <= 9 * 64) hipLaunchKernelGGL((wide_out_kernel<9, true>), dim3(w.blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wide_out_kernel<WIDE_OUT_MAXQ, false>), dim3(w.blocks), dim3(256), 0, s, a);
     if (train) {
-        hipLaunchKernelGGL(wide_loss_finish_kernel, dim3(1), dim3(256), 0, s, w.lossp, w.blocks, w.grads, m.P);
-        hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(w.hsv), w.part, w.blocks, 1, w.hsv, 2, m, 0, w.grads);   // (dw_o | db_o | ds_o)
+        hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(w.hsv + 1), w.part, w.blocks, 1, w.hsv + 1, 2, m, 0, w.grads);   // (dw_o | db_o | ds_o | loss)
         if (wide_out_has_ext(hs))   // (db | dS) of the last hidden layer = dZ_L^T (1, X), summed by the same pass
             hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(h * (1 + C)), w.part2, w.blocks, h, 1 + C, 3, m, m.L - 1, w.grads);
     }
