@@ -2,19 +2,26 @@
 //
 //     C [M x N] = op(A) . op(B)        op(A) = A [M][K] or A^T with A stored [K][M];   op(B) = B^T with B stored [N][K], or B [K][N]
 //
-// row-major operands with arbitrary row strides, any M, N, K (edges are guarded, never padded in memory), optional split of the
+// row-major operands with arbitrary row strides, any M, N, K (at the edges addresses are clamped into the matrix and what lies outside
+// is replaced by 0 on the way into LDS - nothing is padded in memory and no load sits behind a branch), optional split of the
 // contraction over blockIdx.z (every z writes its own [M x N] partial: the weight gradients contract over the 65 536 points of an
 // image and are added up in chunk order by a second kernel - no atomics, reproducible), and an epilogue functor applied to every
 // output element in registers (bias + skip + relu of a hidden layer; the relu / periodic-activation mask of the backward pass), so
-// the activations make one trip to HBM per layer and direction instead of three.
+// the activations make one trip to HBM per layer and direction instead of three.  The NN product can also leave the column sums of its
+// output tile against the points' (1, x) (`extsum`: the bias / skip-weight gradients of the layer below), the HIDDEN epilogue copies the
+// ext columns of the activation rows along.
 //
 // Shape of the kernel (gfx950): 256 threads = 4 waves, a 128 x 128 output tile per workgroup, 64 x 64 per wave = 4 x 4 accumulator
 // tiles of v_mfma_f32_16x16x4_f32 (64 accumulator registers), K in steps of 16 through LDS, global loads of step s + 1 in flight
-// while step s multiplies (register-staged double buffer: two 20 KB LDS buffers, one barrier per step).
+// while step s multiplies (register-staged double buffer: two 20 KB LDS buffers, one barrier per step; <= 128 VGPRs: four workgroups
+// per CU).  Two instantiations per operand form: V4 (every load 16 bytes wide, no branch in the k-loop; what wide.h launches) and a
+// general one that picks 16- / 8- / 4-byte loads per operand and tile (odd strides, unaligned bases: star.h's shapes).  Workgroups are
+// dealt to tiles XCD by XCD (consecutive tiles share an L2).  Measured (h = 256, N = 65 536, one launch): the MFMAs alone 58 us (54.6 at
+// the pipe's peak), the k-loop 71 - 79, with epilogue 83 - 99; the ablation table is in profiles/NOTES.md.
 //
 // How the operands reach the matrix pipe with ONE ds_read_b128 per operand tile and 16 k (8 LDS reads per 64 MFMAs):
 //   * an operand that is contiguous along k (A [M][K], B [N][K]) sits in LDS as [row][16 k] (row stride 20 floats: 16-byte aligned,
-//     conflict-free); lane (g, l15) reads row 16 i + l15, k = 4 g .. 4 g + 3.  MFMA number kk of the step takes element kk of that
+//     two-way conflicts in three of sixteen slots); lane (g, l15) reads row 16 i + l15, k = 4 g .. 4 g + 3.  MFMA number kk of the step takes element kk of that
 //     vector from every lane group, i.e. it contracts k in {kk, 4 + kk, 8 + kk, 12 + kk} - any partition of the 16 k will do as long
 //     as both operands use the same one;
 //   * an operand that is contiguous along its free index (A^T stored [K][M], B [K][N]) sits in LDS as [k][128 (+4)]; lane (g, l15)
@@ -115,23 +122,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V4 ? GM_WAV
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
-#if defined(GM_DEPHASE)
-    {   // which of the (up to 4) workgroups resident on this CU am I: LDS allocation base / size (HW_REG_LDS_ALLOC: base [11:0], size [20:12], 256 B units)
-        const unsigned la = __builtin_amdgcn_s_getreg((31 << 11) | 6);
-        const unsigned sz = (la >> 12) & 0x1ff;
-        const unsigned slot = ((la & 0xfff) / (sz ? sz : 1)) & 3;
-#if GM_DEPHASE == 1
-        if (slot == 0) __builtin_amdgcn_s_setprio(3);
-        else if (slot == 1) __builtin_amdgcn_s_setprio(2);
-        else if (slot == 2) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-#else
-        if (slot == 1) __builtin_amdgcn_s_sleep(GM_DEPHASE);
-        else if (slot == 2) { __builtin_amdgcn_s_sleep(GM_DEPHASE); __builtin_amdgcn_s_sleep(GM_DEPHASE); }
-        else if (slot == 3) { __builtin_amdgcn_s_sleep(GM_DEPHASE); __builtin_amdgcn_s_sleep(GM_DEPHASE); __builtin_amdgcn_s_sleep(GM_DEPHASE); }
-#endif
-    }
-#endif
     // workgroup -> tile.  n fastest, so that the column tiles of one row tile run together and share its A rows in a cache - and the
     // hardware deals consecutive workgroups to the 8 XCDs (each with its own L2) in turn, so the launch order is first re-dealt such
     // that consecutive tiles land on ONE XCD (wg % 8 picks the XCD, wg / 8 the slot on it).
@@ -271,13 +261,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V4 ? GM_WAV
         load_tiles(k_lo + (s + 1) * GM_BK, ra, rb);
 #endif
         __builtin_amdgcn_sched_barrier(0);   // the loads are issued in front of the step's MFMAs and waited for behind them (hipcc's
-#ifdef GM_SETPRIO
-        __builtin_amdgcn_s_setprio(GM_SETPRIO);
-#endif
         multiply(cur);                       // scheduler would move both into the MFMA sequence, half a step apart)
-#ifdef GM_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         __builtin_amdgcn_sched_barrier(0);
 #if !(defined(GM_EXP) && (GM_EXP & 4))
         store_tiles(k_lo + (s + 1) * GM_BK, As[cur ^ 1], Bs[cur ^ 1], ra, rb);

@@ -7,7 +7,9 @@
 // layer and direction, and the h x h contractions as tiled fp32-MFMA GEMMs - csrc/gemm.h, hand-written for gfx950 (round 4; rounds
 // 2-3 called rocBLAS here).  What used to be separate element-wise passes over the activations rides in the GEMMs' epilogues (bias +
 // skip + relu of a hidden layer; the relu / periodic-activation mask of the backward pass) or in the one pass over Z_L that computes
-// the output layer, the data term, dL/dlogit, dZ_L and the output layer's weight gradients (wide_out_kernel).  The contractions over the
+// the output layer, the data term, dL/dlogit, dZ_L and the output layer's weight gradients (wide_out_kernel); the gradients of what the
+// ext inputs (1, x) multiply - (db_k | dS_k), (db_in | dW_in) = dz^T (1, X) - are summed by the kernel that writes dz (wide_out_kernel
+// for the last layer, the backward GEMM's epilogue for the others).  The contractions over the
 // points (weight gradients, K = n_points) are split over blockIdx.z into chunks of WIDE_CHUNK points whose partial products
 // wide_reduce_kernel adds in chunk order: no atomics, reproducible.  The optimizer step is icnn_update_kernel itself on a one-"slab"
 // view of the gradient vector.
@@ -15,7 +17,8 @@
 // Same arithmetic as the reference (awesome/model/convex_net.py:205-214): z0 = act0(W_in x + b_in); z_{k+1} = relu(W_k z_k + b_k + S_k x);
 // y = w_o . z_L + b_o + s_o . x.  Layout: activations row-major [N][hs] (a point's h units, then the "ext" inputs (1, x), then zeros up
 // to a multiple of 4 floats so that rows start on 16-byte boundaries), parameters in the flat order of include/inrfit.h (torch's
-// row-major [out][in] Linear weights): every GEMM reads the parameters where they lie.
+// row-major [out][in] Linear weights); the hidden layers' weight matrices are copied once per step into [L][h][hp] with zero padding
+// (0.25 - 1.5 MB, by the last blocks of the layer-0 launch) so that every GEMM operand loads 16 bytes per lane.
 #pragma once
 #include "gemm.h"
 
