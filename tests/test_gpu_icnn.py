@@ -450,21 +450,24 @@ def test_any_hidden_width_up_to_130_runs_zero_padded(amd, h, C, L):
         np.testing.assert_allclose(gotp[k].numpy(), pf[k].numpy(), rtol=5e-4, atol=2e-6, err_msg=k)
 
 
-@pytest.mark.parametrize("h,C,L,act0", [(256, 2, 1, "relu"), (350, 2, 3, "relu"), (160, 3, 2, "relu"), (64, 2, 4, "relu"), (200, 2, 2, "cos")])
-def test_wide_and_deep_shapes_on_the_layer_by_layer_path(amd, h, C, L, act0):
+@pytest.mark.parametrize("h,C,L,act0,hw", [(256, 2, 1, "relu", (20, 24)), (350, 2, 3, "relu", (20, 24)), (160, 3, 2, "relu", (20, 24)),
+                                           (64, 2, 4, "relu", (20, 24)), (200, 2, 2, "cos", (20, 24)), (131, 2, 3, "relu", (40, 50)),
+                                           (256, 3, 2, "relu", (33, 47))])
+def test_wide_and_deep_shapes_on_the_layer_by_layer_path(amd, h, C, L, act0, hw):
     """n_hidden > 130 (and more than two hidden layers) have no fused kernel - the weight image of such a layer does
     not fit the LDS - and run layer by layer (awesome_amd/csrc/wide.h: activations in HBM, plain GEMMs, the same update kernel).  Forward,
     loss, every gradient and a 12-step Adam + clamp trajectory against the oracle; 350 x 3 is the relu stack of
-    notebooks/imageRepresentationTest.ipynb cell 5."""
+    notebooks/imageRepresentationTest.ipynb cell 5.  The two larger grids (2000 / 1551 points) have several chunks of the weight
+    gradients' split contraction, enough tiles for the XCD-aware tile order, a ragged last row tile and an odd width (131)."""
     A, dev = amd, torch.device("cuda:0")
     torch.manual_seed(h + L)
     spec = A.IcnnSpec(n_hidden=h, in_features=C, n_layers=L, act0=act0) if act0 != "relu" else A.IcnnSpec(n_hidden=h, in_features=C, n_layers=L)
     assert spec.supported()
     p = {k: (torch.rand(shp) - 0.45) * (0.6 / np.sqrt(h)) for k, shp in spec.keys_shapes()}
-    H, W = 20, 24
+    H, W = hw
     grid_t = O.positional_grid(W, H) if C == 2 else O.positional_grid(W, H, 2.0, 5.0)
     yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
-    un = (((yy - 9) ** 2 + (xx - 11) ** 2) > 30).float()
+    un = (((yy - 0.45 * H) ** 2 + (xx - 0.46 * W) ** 2) > 0.0625 * H * W).float()
     flat = A.pack_state_dict(spec, p, dev)[None].contiguous()
     grid = A.Grid.from_image_grid(grid_t[None].to(dev)) if C == 3 else A.Grid.linspace(W, H, dev)
     logits = A.forward(spec, flat, grid)

@@ -332,9 +332,10 @@ def test_star_fused_fit_of_the_notebook_loop_is_star_shaped(dev):
         assert float(reenter) <= 0.05, f"{float(reenter):.3f} of the rays re-enter the region: not star-shaped"
 
 
-@pytest.mark.parametrize("h,n,batch", [(1, 1, 1), (7, 5, 3), (64, 19, 19), (257, 9, 4)])
+@pytest.mark.parametrize("h,n,batch", [(1, 1, 1), (6, 9, 5), (7, 5, 3), (64, 19, 19), (257, 9, 4), (350, 40, 16)])
 def test_star_fused_edge_sizes(dev, h, n, batch):
-    """Tiny and odd sizes (one hidden unit, one pixel, batches that fill no block, a width past 256): forward, loss and gradients
+    """Tiny and odd sizes (one hidden unit, one pixel, batches that fill no block, a width past 256; rows on 4- / 8- / 16-byte
+    boundaries: the three load widths of gemm.h's general kernel): forward, loss and gradients
     against the oracle's restatement of the notebook class, and a 3-epoch fit that stays finite."""
     from awesome_amd import star as S
     from awesome_amd.model import StarShapedNet
