@@ -295,6 +295,9 @@ __device__ __forceinline__ float sum_over_groups(float v) {  // the 4 lanes shar
 #endif
 // Keep successive k-steps of MFMAs in program order (everything else may still move across): without it hipcc regroups
 // the products per accumulator, i.e. into dependent chains that pay the 40-cycle latency instead of the 32-cycle issue.
+#ifndef INR_BWD_B128
+#define INR_BWD_B128 0   // 1: the backward product reads the weight operand of a k-step as TM / 4 16-byte LDS reads (column-permuted tiles) instead of TM 4-byte ones: 343 fewer instructions per chunk, bit-identical, NOT faster (profiles/r04_issue_slot_budget.md section 5)
+#endif
 #ifndef INR_STAGE_Z0_EARLY
 #define INR_STAGE_Z0_EARLY 1
 #endif
@@ -342,6 +345,12 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
     static_assert(!DX || ACT0 == INR_ACT_RELU, "the coordinate-gradient kernels are built for relu networks only");
     using G = Cfg<H, C>;
     constexpr int TM = G::TM, KG = G::KG, HM = G::HM, HR = G::HR, S = G::S, PT = G::PT, RPW = G::RPW, NEXT = G::NEXT;
+    // Backward product dZ0 = dZ1 . W1: with B128 a lane reads the weight row of a k-step as 16-byte vectors, columns 4 l15 .. 4 l15 + 3 of
+    // every 64-column block - element j of block u is the operand of tile 4 u + j, which therefore holds hidden unit 64 u + 4 l15 + j where
+    // the 4-byte reads' tile t holds 16 t + l15.  Everything dZ0 meets afterwards (the layer-0 relu mask, the layer-0 gradient's rows,
+    // W_in for the coordinate gradients) is indexed through bcol; each output element is the same sum in the same order.
+    constexpr bool B128 = INR_BWD_B128 && (TM % 4 == 0);
+    auto bcol = [](int t, int l) { return B128 ? 64 * (t >> 2) + 4 * l + (t & 3) : 16 * t + l; };
     constexpr int HRA = HR > 0 ? HR : 1;  // array extent (zero-length arrays are not allowed)
     static_assert(TM % RPW == 0, "row tiles must split evenly over the waves that own rows");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -603,7 +612,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
         if (TRAIN) {
             float wie[TM];
 #pragma unroll
-            for (int t = 0; t < TM; ++t) wie[t] = WinE[g * PT + 16 * t + l15];
+            for (int t = 0; t < TM; ++t) wie[t] = WinE[g * PT + bcol(t, l15)];   // (the columns the backward product's tile t holds)
             OPERAND_FENCE();
 #pragma unroll
             for (int t = 0; t < TM; ++t) z0p[t] = MFMA16(xe, wie[t], (f32x4{0.f, 0.f, 0.f, 0.f}));
@@ -615,7 +624,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
         for (int t = 0; t < TM; ++t) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+#if !(defined(INR_EXP_NOVALU) && (INR_EXP_NOVALU & 1))   // (timing experiment: wrong results)
                 acc[t][r] = relu0(acc[t][r]);  // z1
+#endif
                 ypart = fmaf(wo[t][r], acc[t][r], ypart);
             }
         }
@@ -675,7 +686,11 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 for (int r = 0; r < 4; ++r) {
                     const float z1 = acc[t][r];
                     dwo[t][r] = fmaf(dy, z1, dwo[t][r]);
+#if defined(INR_EXP_NOVALU) && (INR_EXP_NOVALU & 2)
+                    acc[t][r] = dy * wot[r];
+#else
                     acc[t][r] = z1 > 0.f ? dy * wot[r] : 0.f;
+#endif
                 }
                 *(f32x4*)(sa + 16 * t) = acc[t];
 #if !INR_STAGE_Z0_EARLY
@@ -702,18 +717,25 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
 #pragma unroll
             for (int u = 0; u < HRA; ++u) dz0l[u] = 0.f;
             constexpr int KS = 4 * TM + HR;  // k-steps over the hidden outputs
-            float bq[2][TM];      // B operands (weights): row o of this k-step, columns 16t + l15
+            float bq[2][B128 ? 1 : TM];          // B operands (weights): row o of this k-step, columns 16t + l15
+            f32x4 bq4[2][B128 ? TM / 4 : 1];     // B128: the same row as 16-byte reads, columns 64 u + 4 l15 .. + 3
             f32x4 wcq[2][HRA];    // leftover input columns W1[o][HM+u] at this lane's positions of a tile
             auto b_row = [&](int ks) -> const float* {  // LDS row of the weight operand for k-step ks
                 const int tk = ks >> 2, r = ks & 3;
                 if (tk < TM) return wb + (16 * tk + 4 * g + r) * S;
                 return wb + (g == 0 ? (HM + r) * S : 0);  // leftover outputs live in lane group 0 (others: A = 0)
             };
+            auto b_vec = [&](int ks, int u) { return *(const f32x4*)(b_row(ks) + 3 * l15 + 64 * u); };   // (wb = Wimg + l15)
             dz1_tile(0);
             {
                 const float* br = b_row(0);
+                if constexpr (B128) {
 #pragma unroll
-                for (int t = 0; t < TM; ++t) bq[0][t] = br[16 * t];
+                    for (int u = 0; u < TM / 4; ++u) bq4[0][u] = b_vec(0, u);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) bq[0][t] = br[16 * t];
+                }
                 if (DX) bqx[0] = br[16 * TM];
 #pragma unroll
                 for (int u = 0; u < HR; ++u) wcq[0][u] = *(const f32x4*)(WcT + u * PT + 4 * g);
@@ -733,8 +755,13 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 const float bop = tk < TM ? acc[tk < TM ? tk : 0][r] : (g == 0 ? dzl[r < HRA ? r : 0] : 0.f);
 #pragma unroll
                 for (int t = 0; t < TM; ++t) {  // D = dZ0 with POINTS on the rows; next k-step's operand reads one per product
-                    dz0[t] = MFMA16(bop, bq[ks & 1][t], ks == 0 ? (f32x4{0.f, 0.f, 0.f, 0.f}) : dz0[t]);
-                    if (ks + 1 < KS) bq[(ks + 1) & 1][t] = b_row(ks + 1)[16 * t];
+                    if constexpr (B128) {
+                        dz0[t] = MFMA16(bop, bq4[ks & 1][t >> 2][t & 3], ks == 0 ? (f32x4{0.f, 0.f, 0.f, 0.f}) : dz0[t]);
+                        if (ks + 1 < KS && (t & 3) == 0) bq4[(ks + 1) & 1][t >> 2] = b_vec(ks + 1, t >> 2);
+                    } else {
+                        dz0[t] = MFMA16(bop, bq[ks & 1][t], ks == 0 ? (f32x4{0.f, 0.f, 0.f, 0.f}) : dz0[t]);
+                        if (ks + 1 < KS) bq[(ks + 1) & 1][t] = b_row(ks + 1)[16 * t];
+                    }
                     OPERAND_FENCE();
                 }
                 if (DX) dzx = MFMA16(bop, bqx[ks & 1], dzx);
@@ -760,8 +787,12 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 for (int t = 0; t < TM; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+#if defined(INR_EXP_NOVALU) && (INR_EXP_NOVALU & 4)
+                        asm volatile("" ::"v"(z0p[t][r]));
+#else
                         if constexpr (ACT0 == INR_ACT_RELU) dz0[t][r] = z0p[t][r] > 0.f ? dz0[t][r] : 0.f;
                         else dz0[t][r] *= dact0_f<ACT0>(z0p[t][r], a.act_omega);
+#endif
                     }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -804,7 +835,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 for (int t = 0; t < TM; ++t)
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
-                        const float w = WinE[c * PT + 16 * t + l15];
+                        const float w = WinE[c * PT + bcol(t, l15)];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) part[r][c] = fmaf(w, dz0[t][r], part[r][c]);
                     }
@@ -947,7 +978,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
                 if (lane == 0) scr[SC_L0L + u * 4 + e] = w;
             }
         }
-        {   // dL0 tiles: row 16t + 4g + r = hidden unit, column l15 = slot of k-group TM; keep the ext-input columns
+        {   // dL0 tiles: row 4g + r of tile t = hidden unit bcol(t, 4g + r), column l15 = slot of k-group TM; keep the ext-input columns
             int e = -1;
 #pragma unroll
             for (int k = 0; k < NEXT; ++k)
@@ -956,7 +987,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void icnn_step_kernel(const StepArgs
 #pragma unroll
                 for (int t = 0; t < TM; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) scr[SC_L0 + (16 * t + 4 * g + r) * 4 + e] = dL0[t][r];
+                    for (int r = 0; r < 4; ++r) scr[SC_L0 + bcol(t, 4 * g + r) * 4 + e] = dL0[t][r];
             }
         }
         {
