@@ -567,6 +567,12 @@ def path_variants(dev, S, steps=300, cpu_legs=True):
     us, h = timed(lambda n: A.fit(m2.spec, p2.clone(), grid, un, n, lr=2e-3, record_loss=True, want_logits=False))
     out[f"ConvexNextNet_L2_{S}x{S}"] = entry(us, N, icnn_fwd_flop(130, 2, 2), 0, h,
                                              lambda n: O.fit_icnn(sd2, grid_t, un_img, n, lr=2e-3)[1], 20)
+    # shapes without a fused kernel: the layer-by-layer path (csrc/wide.h + csrc/gemm.h; parity: tests/test_gpu_icnn.py)
+    for hw_, lw_ in ((256, 1), (350, 3)):
+        mw = ConvexNextNet(n_hidden=hw_, n_hidden_layers=lw_, in_features=2)
+        pw = mw.flat_parameters()[None].to(dev)
+        us, h = timed(lambda n: A.fit(mw.spec, pw.clone(), grid, un, n, lr=2e-3, record_loss=True, want_logits=False))
+        out[f"ConvexNextNet_h{hw_}_L{lw_}_layer_by_layer_{S}x{S}"] = entry(us, N, icnn_fwd_flop(hw_, 2, lw_), 0, h)
     cdn = ConvexDiffeomorphismNet(n_hidden=130, n_hidden_layers=2, nf_layers=6, nf_hidden=130,
                                   diffeo_args=dict(backbone="normal_block")).to(dev)   # the reference configs' form
     sdc = {k: v.detach().cpu().clone() for k, v in cdn.state_dict().items()}
