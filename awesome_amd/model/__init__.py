@@ -1,5 +1,5 @@
 from .convex_net import ConvexNet, ConvexNextNet  # noqa: F401
-from .diffeomorphism_net import (ConvexDiffeomorphismNet, NormalBlock, NormalizingFlow1D, SimpleBackbone, WNLinear,  # noqa: F401
+from .diffeomorphism_net import (ConvexDiffeomorphismNet, NormalBlock, NormalizingFlow1D, ResidualBlock1D, SimpleBackbone, SimpleResnet, WNLinear,  # noqa: F401
                                  WNScale)
 from .pretrainable_module import PretrainableModule  # noqa: F401
 from .wrapper_module import ConvSegStandIn, ForwardModule, WrapperModule  # noqa: F401

@@ -141,6 +141,82 @@ class SimpleBackbone(nn.Module):
         return torch.tanh(self.linear2(F.relu(self.linear1(x))))
 
 
+def _apply_normal(module: nn.Module, activation: str) -> None:
+    # weights_init_normal under .apply() (resnet_1d.py:9-22): as with _apply_uniform only the inner nn.Linear is touched; its `.weight`
+    # is the tensor weight_norm derives from (g, v) - the normal draws are consumed (seeded construction stays in step with the
+    # reference) and overwritten by the next forward; the bias is what moves.
+    for m in module.modules():
+        if isinstance(m, nn.Linear):
+            with torch.no_grad():
+                nn.init.kaiming_normal_(m.weight, mode="fan_in", nonlinearity=activation)
+                if m.bias is not None:
+                    std = nn.init.calculate_gain(activation, 0) / math.sqrt(m.weight.shape[1])
+                    m.bias.uniform_(-std, std)
+
+
+class ResidualBlock1D(nn.Module):
+    """x + WN2(relu(BN2(WN1(relu(BN1 x)))))  (real_nvp/resnet_1d.py:66-95); the batch norms use the statistics of the rows they are
+    given (track_running_stats=False): the block couples all points of an image."""
+
+    def __init__(self, in_channels: int = 1, out_channels: int = 1, **kwargs):
+        super().__init__()
+        self.in_norm = nn.BatchNorm1d(in_channels, track_running_stats=False)
+        self.in_linear = WNLinear(in_channels, out_channels, bias=False)
+        self.out_norm = nn.BatchNorm1d(out_channels, track_running_stats=False)
+        self.out_linear = WNLinear(out_channels, out_channels, bias=True)
+        _apply_normal(self.in_linear, "relu")
+        _apply_normal(self.out_linear, "relu")
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y = self.in_linear(F.relu(self.in_norm(x)))
+        return self.out_linear(F.relu(self.out_norm(y))) + x
+
+
+class SimpleResnet(nn.Module):
+    """NormalizingFlow1D's 'resnet' backbone (diffeomorphism_net.py:107-166): batch-normed input, (x, -x) -> relu -> WN linear, a sum of
+    weight-normed skips over `num_blocks` residual blocks, batch norm, relu, WN linear, tanh.  Batch statistics over the points of an
+    image make it a whole-image function: it has no per-point kernel and runs as torch operations on the device (forward and
+    autograd); no reference config selects it."""
+
+    def __init__(self, in_channels: int = 2, mid_channels: int = 128, out_channels: int = 2, num_blocks: int = 1,
+                 double_after_norm: bool = False):
+        super().__init__()
+        self.in_norm = nn.BatchNorm1d(in_channels, track_running_stats=False)
+        self.double_after_norm = double_after_norm
+        self.in_linear = WNLinear(2 * in_channels, mid_channels, bias=True)
+        self.in_skip = WNLinear(mid_channels, mid_channels, bias=True)
+        self.blocks = nn.ModuleList([ResidualBlock1D(mid_channels, mid_channels) for _ in range(num_blocks)])
+        self.skips = nn.ModuleList([WNLinear(mid_channels, mid_channels, bias=True) for _ in range(num_blocks)])
+        self.out_norm = nn.BatchNorm1d(mid_channels, track_running_stats=False)
+        self.out_linear = WNLinear(mid_channels, out_channels, bias=True)
+        self._init()
+
+    def _init(self) -> None:
+        _apply_normal(self.in_linear, "relu")
+        _apply_normal(self.in_skip, "relu")
+        _apply_normal(self.skips, "relu")
+        _apply_normal(self.out_linear, "tanh")
+
+    def reset_parameters(self) -> None:
+        """(The reference class has no reset_parameters - NormalizingFlow1D.reset_parameters raises on this backbone there; here the
+        constructor's initialisation is applied again.)"""
+        for blk in self.blocks:
+            _apply_normal(blk.in_linear, "relu")
+            _apply_normal(blk.out_linear, "relu")
+        self._init()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = self.in_norm(x)
+        if self.double_after_norm:
+            x = x * 2.0
+        x = self.in_linear(F.relu(torch.cat((x, -x), dim=1)))
+        acc = self.in_skip(x)
+        for blk, skip in zip(self.blocks, self.skips):
+            x = blk(x)
+            acc = acc + skip(x)
+        return torch.tanh(self.out_linear(F.relu(self.out_norm(acc))))
+
+
 class WNScale(nn.Module):
     """Learnable scalar through a weight-normed 1x1 linear (diffeomorphism_net.py:208-232)."""
 
@@ -166,21 +242,23 @@ class WNScale(nn.Module):
 class NormalizingFlow1D(nn.Module):
     """Alternating affine couplings on the two coordinates (diffeomorphism_net.py:235-302).  Backbones as in the reference:
     'default' = SimpleBackbone (relu; what a bare ConvexDiffeomorphismNet() builds), 'normal_block' / 'residual_block' =
-    NormalBlock (leaky_relu; every reference config).  'resnet' (SimpleResnet, no config uses it) has no fused form."""
+    NormalBlock (leaky_relu; every reference config) - both on the HIP flow kernels.  'resnet' = SimpleResnet (no config uses it): batch
+    norms over the points, so the couplings are evaluated as torch operations on the device (with autograd) and the fused entry points
+    (`_spec`, `pretrain`'s device-resident loop) do not exist for it."""
 
     def __init__(self, num_coupling: int = 4, width: int = 130, num_blocks: int = 1, in_features: int = 2,
                  backbone: str = "default", **kwargs):
         super().__init__()
         if num_coupling % in_features != 0:
             raise ValueError(f"Number of coupling layers should be divisible by in_features ({in_features})")
-        if backbone == "resnet":
-            raise NotImplementedError("the 'resnet' backbone (SimpleResnet) is not on the HIP path; no reference config uses it")
-        if backbone not in ("default", "normal_block", "residual_block"):
+        if backbone not in ("default", "normal_block", "residual_block", "resnet"):
             raise ValueError(f"Unknown backbone: {backbone}")
         self.num_coupling, self.in_features = num_coupling, in_features
-        self.backbone = "default" if backbone == "default" else "normal_block"
+        self.backbone = backbone if backbone in ("default", "resnet") else "normal_block"
         if backbone == "default":
             mk = lambda: SimpleBackbone(in_channels=1, network_width=width)  # noqa: E731
+        elif backbone == "resnet":
+            mk = lambda: SimpleResnet(in_channels=1, mid_channels=width, out_channels=1, num_blocks=num_blocks)  # noqa: E731
         else:
             mk = lambda: NormalBlock(in_channels=1, mid_channels=width, out_channels=1)  # noqa: E731
         self.s = nn.ModuleList([mk() for _ in range(num_coupling)])
@@ -195,6 +273,8 @@ class NormalizingFlow1D(nn.Module):
         return True
 
     def _spec(self) -> "FL.FlowSpec":
+        if self.backbone == "resnet":
+            raise NotImplementedError("the 'resnet' backbone (SimpleResnet: batch norms over the points) has no fused flow kernel")
         first = self.s[0].linear1 if self.backbone == "default" else self.s[0].in_linear
         return FL.FlowSpec(first.linear.weight_v.shape[0], self.num_coupling, self.backbone)
 
@@ -205,6 +285,14 @@ class NormalizingFlow1D(nn.Module):
             raise RuntimeError("awesome_amd modules run on the MI355X only (no CPU fallback); move module and input to cuda")
         if self.in_features != 2 or x.dim() != 2 or x.shape[1] != 2:
             raise ValueError("the coupling flow maps (N, 2) rows (2-D only, like the reference, diffeomorphism_net.py:288)")
+        if self.backbone == "resnet":   # whole-image backbones: the couplings as device-side torch operations (:283-300)
+            x1, x2 = x[:, :1], x[:, 1:]
+            for i in range(self.num_coupling):
+                if i % 2 == 0:
+                    x2 = torch.exp(self.scale[i]() * self.s[i](x1)) * x2 + self.t[i](x1)
+                else:
+                    x1 = torch.exp(self.scale[i]() * self.s[i](x2)) * x1 + self.t[i](x2)
+            return torch.cat([x1, x2], 1)
         fspec = self._spec()
         sd = dict(self.named_parameters())
         own = [sd[k] for k, _ in fspec.keys_shapes(prefix="") if not k.startswith("linear.")]
@@ -327,6 +415,13 @@ class ConvexDiffeomorphismNet(nn.Module, PriorFitMixin):
         `inrfit_flow_forward`; no autograd (it is an inspection output)."""
         if not x.is_cuda:
             raise RuntimeError("awesome_amd modules run on the MI355X only (no CPU fallback); move module and input to cuda")
+        if self.diffeo_net.backbone == "resnet":
+            with torch.no_grad():
+                if x.dim() == 4:
+                    b, c, h, w = x.shape
+                    rows = x.permute(0, 2, 3, 1).reshape(b, h * w, c)
+                    return torch.stack([self.diffeo_net(self.linear(rows[i])) for i in range(b)], 0).reshape(b, h, w, c).permute(0, 3, 1, 2)
+                return self.diffeo_net(self.linear(x))
         _, fspec, _, flow = self._ordered_params()
         fp = torch.cat([p.detach().reshape(-1) for p in flow]).to(torch.float32)[None].contiguous()
         if x.dim() == 4:
@@ -352,6 +447,14 @@ class ConvexDiffeomorphismNet(nn.Module, PriorFitMixin):
             raise RuntimeError("awesome_amd modules run on the MI355X only (no CPU fallback); move module and input to cuda")
         if self.in_features != 2:
             raise ValueError("the coupling flow is 2-D only (like the reference, diffeomorphism_net.py:288)")
+        if self.diffeo_net.backbone == "resnet":
+            # no fused composite for the whole-image backbone: deformation in torch on the device, the ICNN on its kernels (forward,
+            # parameter gradients and dL/dcoords for the flow's backward: convex_net._IcnnFunction)
+            if x.dim() == 4:
+                b, c, h, w = x.shape
+                rows = x.permute(0, 2, 3, 1).reshape(b, h * w, c)
+                return torch.stack([self.convex_net(self.diffeo_net(self.linear(rows[i]))).reshape(1, h, w) for i in range(b)], 0)
+            return self.convex_net(self.diffeo_net(self.linear(x)))
         ispec, fspec, icnn, flow = self._ordered_params()
         run = lambda coords: _CdnFunction.apply(coords, ispec, fspec, len(icnn), *icnn, *flow)  # noqa: E731
         if x.dim() == 4:

@@ -279,3 +279,24 @@ def test_weighted_loss_on_class_labels_with_noneclass_matches_reference(golden_d
         lm.backward()
         assert float(lm.detach()) == pytest.approx(float(z[f"fbms{case}.loss"]), rel=1e-6)
         np.testing.assert_allclose(o2.grad.numpy(), z[f"fbms{case}.grad"], rtol=1e-5, atol=1e-9)
+
+
+def test_simple_resnet_backbone_is_constructed_like_the_reference_class(golden_dir):
+    """NormalizingFlow1D's 'resnet' backbone (SimpleResnet / ResidualBlock1D, diffeomorphism_net.py:107-166; real_nvp/resnet_1d.py:66-95):
+    the same parameter names in the same order as the class, and - from the same seed - the same initial values (creation order and the
+    random draws of the initialisers, including the ones weights_init_normal spends on the derived `.weight`)."""
+    import json
+    import random
+    from awesome_amd.model import ConvexDiffeomorphismNet
+    z = _z(golden_dir, "cdn_class_resnet.npz")
+    random.seed(23)
+    np.random.seed(23)
+    torch.manual_seed(23)
+    m = ConvexDiffeomorphismNet(**json.loads(str(z["kwargs"])))
+    sd = m.state_dict()
+    ref = {k[3:]: z[k] for k in z.files if k.startswith("sd.")}
+    assert list(sd.keys()) == list(ref.keys())
+    for k, v in sd.items():
+        np.testing.assert_array_equal(v.numpy(), ref[k].reshape(v.shape), err_msg=k)
+    with pytest.raises(NotImplementedError):
+        m._specs()                       # no fused flow kernel for a backbone that normalises over the points

@@ -119,6 +119,31 @@ def test_convex_diffeomorphism_net_class_fixture(dev, golden_dir, tag):
         np.testing.assert_allclose(m(grid).cpu().numpy(), z["tr_logits_after"], atol=5e-5, rtol=1e-4)
 
 
+def test_convex_diffeomorphism_net_with_the_resnet_backbone(dev, golden_dir):
+    """The 'resnet' flow backbone (SimpleResnet: batch norms over the points - torch operations on the device) in front of the ICNN
+    kernels: forward, deformation and the BCE gradients of every parameter (the flow's through the ICNN kernel's dL/dcoords) vs the
+    reference class."""
+    from awesome_amd.model import ConvexDiffeomorphismNet
+    z = _z(golden_dir, "cdn_class_resnet.npz")
+    m = ConvexDiffeomorphismNet(**json.loads(str(z["kwargs"])))
+    m.load_state_dict(O.load_npz_state(z, "sd."))
+    m.to(dev)
+    grid, un = torch.from_numpy(z["grid"]).to(dev), torch.from_numpy(z["unaries"]).to(dev)
+    logits = m(grid)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), z["logits"], atol=3e-5, rtol=1e-4)
+    # (four couplings x two nets x five batch norms over 120 points: the device's and the CPU's fp32 reductions differ by ~1e-4)
+    np.testing.assert_allclose(m.get_deformation(grid).cpu().numpy(), z["deformation"], atol=3e-4, rtol=1e-3)
+    loss = torch.nn.BCELoss()(torch.sigmoid(logits), un)
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(z["loss"]), rel=1e-5)
+    # gradients against the SCALE of the whole gradient (max |g| over all parameters): biases in front of a batch norm have an
+    # analytically zero gradient (1e-8 of rounding on both sides), and the norm chain amplifies fp32 rounding to ~2e-3 of that scale
+    gmax = max(float(np.abs(z["grad." + k]).max()) for k, _ in m.named_parameters())
+    for k, p in m.named_parameters():
+        ref = z["grad." + k]
+        np.testing.assert_allclose(p.grad.cpu().numpy().reshape(ref.shape), ref, rtol=1e-2, atol=5e-3 * gmax, err_msg=k)
+
+
 def test_normalizing_flow_module_on_hip(dev, golden_dir):
     """NormalizingFlow1D.forward + autograd on inrfit_flow_forward / inrfit_flow_backward vs the reference module's fixture."""
     from awesome_amd.model import NormalizingFlow1D

@@ -107,6 +107,27 @@ def gen_cdn_class(ref, out):
         print("cdn_class", tag, float(loss))
 
 
+def gen_cdn_class_resnet(ref, out):
+    """ConvexDiffeomorphismNet with NormalizingFlow1D's 'resnet' backbone (SimpleResnet: diffeomorphism_net.py:107-166, 256-260; no
+    config selects it): forward on a (1,2,H,W) grid, the deformation, BCE(sigmoid) loss gradients w.r.t. every parameter."""
+    import copy
+    kw = dict(n_hidden=32, n_hidden_layers=1, nf_layers=4, nf_hidden=16, diffeo_args=dict(backbone="resnet", num_blocks=2))
+    seed_all(23)
+    m = ref.cdn.ConvexDiffeomorphismNet(**copy.deepcopy(kw))
+    hw = (12, 10)
+    grid = linspace_grid(*hw)
+    un = torch.from_numpy(blob_unaries(hw[0], hw[1], 3))[None, None]
+    logits = m(grid)
+    loss = torch.nn.BCELoss()(torch.sigmoid(logits), un)
+    loss.backward()
+    rec = dict(grid=grid.numpy(), unaries=un.numpy(), logits=logits.detach().numpy(), loss=np.float32(loss.item()),
+               deformation=m.get_deformation(grid).detach().numpy(), kwargs=json.dumps(kw))
+    rec.update(sd_np(m))
+    rec.update(grads_np(m))
+    np.savez_compressed(os.path.join(out, "cdn_class_resnet.npz"), **rec)
+    print("cdn_class_resnet", float(loss), len([k for k in rec if k.startswith("sd.")]))
+
+
 def gen_fbms_joint_loss(ref, out):
     """FBMSJointLoss (fixture 4): output (B, 2, H, W) = [seg, prior]; both clip branches, loss value and gradient w.r.t. the
     output."""
@@ -420,6 +441,8 @@ def main():
         return gen_wrapper_pixel(ref, args.out)
     if args.only == "weighted_loss_noneclass":
         return gen_weighted_loss_noneclass(ref, args.out)
+    if args.only == "cdn_resnet":
+        return gen_cdn_class_resnet(ref, args.out)
     gen_weighted_loss_noneclass(ref, args.out)
     gen_wrapper_pixel(ref, args.out)
     gen_encode_notebooks(args.out)
@@ -429,6 +452,7 @@ def main():
     gen_wrapper(ref, args.out)
     gen_prior_cache(ref, args.out)
     gen_cdn_class(ref, args.out)
+    gen_cdn_class_resnet(ref, args.out)
 
 
 if __name__ == "__main__":
