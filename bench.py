@@ -571,8 +571,10 @@ def path_variants(dev, S, steps=300, cpu_legs=True):
     for hw_, lw_ in ((256, 1), (350, 3)):
         mw = ConvexNextNet(n_hidden=hw_, n_hidden_layers=lw_, in_features=2)
         pw = mw.flat_parameters()[None].to(dev)
+        sdw = {k: v.detach().clone() for k, v in mw.state_dict().items()}
         us, h = timed(lambda n: A.fit(mw.spec, pw.clone(), grid, un, n, lr=2e-3, record_loss=True, want_logits=False))
-        out[f"ConvexNextNet_h{hw_}_L{lw_}_layer_by_layer_{S}x{S}"] = entry(us, N, icnn_fwd_flop(hw_, 2, lw_), 0, h)
+        out[f"ConvexNextNet_h{hw_}_L{lw_}_layer_by_layer_{S}x{S}"] = entry(us, N, icnn_fwd_flop(hw_, 2, lw_), 0, h,
+                                                                         lambda n, sdw=sdw: O.fit_icnn(sdw, grid_t, un_img, n, lr=2e-3)[1], 6 if lw_ == 1 else 3)
     cdn = ConvexDiffeomorphismNet(n_hidden=130, n_hidden_layers=2, nf_layers=6, nf_hidden=130,
                                   diffeo_args=dict(backbone="normal_block")).to(dev)   # the reference configs' form
     sdc = {k: v.detach().cpu().clone() for k, v in cdn.state_dict().items()}
