@@ -14,7 +14,7 @@ un = convex_blob_unaries(S, 0).reshape(1, -1).to(dev)
 grid = A.Grid.linspace(S, S, dev)
 
 
-def check(name, run):
+def check(name, run, n_steps=None):
     ref, t0 = None, time.time()
     for r in range(reps):
         out = run()
@@ -23,7 +23,7 @@ def check(name, run):
             ref = [o.clone() for o in out]
         else:
             assert all(torch.equal(a, b) for a, b in zip(ref, out)), f"{name}: repeat {r} differs"
-    print(f"{name}: {reps} x {steps} steps bitwise identical ({time.time() - t0:.1f} s)", flush=True)
+    print(f"{name}: {reps} x {n_steps or steps} steps bitwise identical ({time.time() - t0:.1f} s)", flush=True)
 
 
 for L in (1, 2):
@@ -36,6 +36,17 @@ for L in (1, 2):
         assert int(res.status.sum()) == 0
         return [res.params, res.loss_hist, res.logits]
     check(f"ConvexNextNet L={L}", run)
+
+for h, L in ((256, 1), (350, 3), (131, 3)):   # the layer-by-layer path (csrc/wide.h + gemm.h: split contractions added in a fixed order)
+    torch.manual_seed(0)
+    m = ConvexNextNet(n_hidden=h, n_hidden_layers=L)
+    p0 = m.flat_parameters()[None].to(dev)
+
+    def run(p0=p0, spec=m.spec):
+        res = A.fit(spec, p0.clone(), grid, un, 100, lr=2e-3)
+        assert int(res.status.sum()) == 0
+        return [res.params, res.loss_hist, res.logits]
+    check(f"ConvexNextNet h={h} L={L} (layer by layer)", run, 100)
 
 torch.manual_seed(0)
 cdn = ConvexDiffeomorphismNet(n_hidden=130, n_hidden_layers=2, nf_layers=6, nf_hidden=130, diffeo_args=dict(backbone="normal_block")).to(dev)
