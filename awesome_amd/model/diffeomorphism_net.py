@@ -243,8 +243,8 @@ class NormalizingFlow1D(nn.Module):
     """Alternating affine couplings on the two coordinates (diffeomorphism_net.py:235-302).  Backbones as in the reference:
     'default' = SimpleBackbone (relu; what a bare ConvexDiffeomorphismNet() builds), 'normal_block' / 'residual_block' =
     NormalBlock (leaky_relu; every reference config) - both on the HIP flow kernels.  'resnet' = SimpleResnet (no config uses it): batch
-    norms over the points, so the couplings are evaluated as torch operations on the device (with autograd) and the fused entry points
-    (`_spec`, `pretrain`'s device-resident loop) do not exist for it."""
+    norms over the points, so the couplings are evaluated as torch operations on the device (with autograd); `_spec` (the fused flow
+    kernels) does not exist for it and ConvexDiffeomorphismNet.pretrain runs the reference's loop as device-side autograd."""
 
     def __init__(self, num_coupling: int = 4, width: int = 130, num_blocks: int = 1, in_features: int = 2,
                  backbone: str = "default", **kwargs):
@@ -349,12 +349,72 @@ class ConvexDiffeomorphismNet(nn.Module, PriorFitMixin):
         return dict(num_epochs=2000, lr=0.003, reuse_state=True, reuse_state_epochs=200, proper_prior_fit_threshold=0.5,
                     proper_prior_fit_retrys=1, weight_decay_on_weight_g=5e-5, weight_decay_on_convex_weight=False)
 
+    # -- the 'resnet' flow backbone: no fused fit; the reference's loop (:376-421) as device-side autograd ---------------------------
+    def _generic(self) -> bool:
+        return self.diffeo_net.backbone == "resnet"
+
+    def _generic_fit(self, grid, unaries, flat, epochs, opts):
+        """Adam (weight decay on the weight_g group only) + ReduceLROnPlateau(patience 200, factor 0.5) + enforce_convexity per step,
+        one image after the other, each from its row of `flat` (named_parameters order); returns what the fused engines return: the
+        fitted rows, the logits of the LAST forward (the IoU gate looks at those, :424) and a status per image."""
+        names = [k for k, _ in self.named_parameters()]
+        prm = dict(self.named_parameters())
+        keep = [p.detach().clone() for p in prm.values()]
+        crit = opts.get("criterion")
+        lr, wd = float(opts.get("lr", 0.003)), float(opts.get("weight_decay_on_weight_g", 5e-5))
+        out_flat, out_logits, status = [], [], []
+        for i in range(flat.shape[0]):
+            with torch.no_grad():
+                off = 0
+                for k in names:
+                    n = prm[k].numel()
+                    prm[k].copy_(flat[i, off:off + n].reshape(prm[k].shape))
+                    off += n
+            rows = (grid.coords if grid.coords.dim() == 2 else grid.coords[i]).t().contiguous()
+            groups = [dict(params=[prm[k] for k in names if k.endswith("weight_g")], weight_decay=wd),
+                      dict(params=[prm[k] for k in names if not k.endswith("weight_g")], weight_decay=0.0)]
+            opt = torch.optim.Adam(groups, lr=lr)
+            sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, patience=200, factor=0.5) if opts.get("use_plateau", True) else None
+            tgt, logits, bad = unaries[i].reshape(1, 1, -1), None, 0
+            with torch.enable_grad():
+                for _ in range(int(epochs)):
+                    opt.zero_grad()
+                    logits = self(rows)[:, 0]
+                    prob = torch.sigmoid(logits).reshape(1, 1, -1)
+                    loss = crit(prob, tgt) if crit is not None else F.binary_cross_entropy(prob, tgt)
+                    if not bool(torch.isfinite(loss)):
+                        bad = 1
+                        break
+                    loss.backward()
+                    opt.step()
+                    if sched is not None:
+                        sched.step(loss.detach())
+                    self.enforce_convexity()
+            if logits is None:
+                with torch.no_grad():
+                    logits = self(rows)[:, 0]
+            out_flat.append(torch.cat([prm[k].detach().reshape(-1) for k in names]))
+            out_logits.append(logits.detach())
+            status.append(bad)
+        with torch.no_grad():
+            for p_, k_ in zip(prm.values(), keep):
+                p_.copy_(k_)
+        return torch.stack(out_flat), torch.stack(out_logits), torch.tensor(status, dtype=torch.int32, device=flat.device)
+
     def _engine_pack(self, sd):
+        if self._generic():
+            return torch.cat([sd[k].detach().reshape(-1).to(torch.float32).cpu() for k, _ in self.named_parameters()])
         ispec, fspec = self._specs()
         i, f = FL.split_cdn_state_dict(ispec, fspec, sd)
         return torch.cat([i.cpu(), f.cpu()])
 
     def _engine_unpack(self, flat):
+        if self._generic():
+            out, off = {}, 0
+            for k, p_ in self.named_parameters():
+                out[k] = flat[off:off + p_.numel()].reshape(p_.shape).clone()
+                off += p_.numel()
+            return out
         ispec, fspec = self._specs()
         return FL.merge_cdn_state_dict(ispec, fspec, flat[:ispec.n_params], flat[ispec.n_params:])
 
@@ -362,6 +422,8 @@ class ConvexDiffeomorphismNet(nn.Module, PriorFitMixin):
         from ..measures import criterion_to_desc
         if opts.get("weight_decay_on_convex_weight", False):
             raise NotImplementedError("weight_decay_on_convex_weight=True (no reference config sets it) has no fused form")
+        if self._generic():
+            return self._generic_fit(grid, unaries, flat, epochs, opts)
         ispec, fspec = self._specs()
         P = ispec.n_params
         crit = opts.get("criterion")
@@ -376,6 +438,16 @@ class ConvexDiffeomorphismNet(nn.Module, PriorFitMixin):
     def _engine_warm_start(self, flat, ctx, image, opts):
         """:337-348: shift the previous frame's prior to this frame's centre of mass before the short refit."""
         com = center_of_mass(image.unaries)
+        if ctx is not None and self._generic():   # the same translate on this layout's `linear.weight` / `linear.bias` slices
+            off, where = 0, {}
+            for k, p_ in self.named_parameters():
+                where[k] = (off, p_.numel())
+                off += p_.numel()
+            (ow, nw), (ob, nb) = where["linear.weight"], where["linear.bias"]
+            pts = translate_only_point_args(ctx.flip(dims=(-1,)), com.flip(dims=(-1,)), image.grid.squeeze(), self.in_features)
+            w, b = translate_linear(flat[ow:ow + nw].reshape(2, 2).clone(), flat[ob:ob + nb].clone(), *pts)
+            flat[ow:ow + nw], flat[ob:ob + nb] = w.reshape(-1), b
+            return flat, com
         if ctx is not None:
             P = self._specs()[0].n_params
             w, b = flat[P:P + 4].reshape(2, 2).clone(), flat[P + 4:P + 6].clone()

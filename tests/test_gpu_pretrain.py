@@ -345,6 +345,35 @@ def test_pretrain_convex_diffeomorphism_net_warm_start_chain(dev):
         np.testing.assert_allclose(got.numpy(), prev.cpu().numpy(), rtol=2e-5, atol=1e-7, err_msg=f"frame {i}")
 
 
+def test_pretrain_convex_diffeomorphism_net_with_the_resnet_backbone(dev):
+    """`pretrain` with the 'resnet' flow backbone: no fused fit exists (batch norms over the points), the reference's loop runs as
+    device-side autograd (Adam with weight decay on the weight_g group, ReduceLROnPlateau, enforce_convexity per step) behind the same
+    entry point - cold fit of frame 0, centre-of-mass warm starts for the later frames, states into the PriorCache."""
+    from awesome_amd.dataset import convex_blob_unaries
+    from awesome_amd.model import ConvexDiffeomorphismNet
+    args = dict(n_hidden=32, n_hidden_layers=1, nf_layers=2, nf_hidden=8, diffeo_args=dict(backbone="resnet", num_blocks=1))
+    torch.manual_seed(5)
+    ds, wrapper, agent = _setup(dev, ConvexDiffeomorphismNet, args, n=2, size=32)
+    base = (convex_blob_unaries(256, 2).reshape(256, 256)[::8, ::8] > 0.5).float()
+    frames = [torch.roll(base, shifts=(0, 2 * k), dims=(0, 1)) for k in range(2)]
+    ds._inner.unaries = lambda i: frames[i]
+    before = {k: v.detach().clone() for k, v in wrapper.prior_module.state_dict().items()}
+    state = wrapper.pretrain(train_set=ds, test_set=None, device=dev, agent=agent, use_progress_bar=False, num_epochs=150, lr=3e-3,
+                             reuse_state=True, reuse_state_epochs=30)
+    rep = wrapper.prior_module.pretrain_report
+    assert len(rep) == 2 and all(np.isfinite(r["iou"]) for r in rep) and rep[0]["iou"] > 0.5, rep
+    m = wrapper.prior_module
+    for i in range(2):
+        sd = state["cache"][str(i)]
+        assert list(sd.keys()) == list(m.state_dict().keys())
+        assert all(bool(torch.isfinite(v).all()) for v in sd.values())
+        assert float((sd["convex_net.linear_out.weight"] if "convex_net.linear_out.weight" in sd else next(iter(sd.values()))).abs().sum()) > 0
+    moved = sum(float((state["cache"]["0"][k].cpu() - before[k].cpu()).abs().max()) > 0 for k in before)
+    assert moved > len(before) // 2                      # the fit trained the flow and the ICNN
+    for k, v in m.state_dict().items():                   # ... and left the module's own parameters where they were
+        assert torch.equal(v.cpu(), before[k].cpu()), k
+
+
 def test_pretrain_path_connected_net_warm_start_chain_keeps_actnorm(dev):
     """with reuse_state (the default) frame k starts from frame k-1's fitted state, loaded in the reference with
     load_state_dict (path_connected_net.py:867-870) - data_dep_init_done = 1 included - so ActNorm is NOT re-initialised from the
