@@ -452,13 +452,14 @@ def test_any_hidden_width_up_to_130_runs_zero_padded(amd, h, C, L):
 
 @pytest.mark.parametrize("h,C,L,act0,hw", [(256, 2, 1, "relu", (20, 24)), (350, 2, 3, "relu", (20, 24)), (160, 3, 2, "relu", (20, 24)),
                                            (64, 2, 4, "relu", (20, 24)), (200, 2, 2, "cos", (20, 24)), (131, 2, 3, "relu", (40, 50)),
-                                           (256, 3, 2, "relu", (33, 47))])
+                                           (256, 3, 2, "relu", (33, 47)), (600, 2, 1, "relu", (20, 24))])
 def test_wide_and_deep_shapes_on_the_layer_by_layer_path(amd, h, C, L, act0, hw):
     """n_hidden > 130 (and more than two hidden layers) have no fused kernel - the weight image of such a layer does
     not fit the LDS - and run layer by layer (awesome_amd/csrc/wide.h: activations in HBM, plain GEMMs, the same update kernel).  Forward,
     loss, every gradient and a 12-step Adam + clamp trajectory against the oracle; 350 x 3 is the relu stack of
     notebooks/imageRepresentationTest.ipynb cell 5.  The two larger grids (2000 / 1551 points) have several chunks of the weight
-    gradients' split contraction, enough tiles for the XCD-aware tile order, a ragged last row tile and an odd width (131)."""
+    gradients' split contraction, enough tiles for the XCD-aware tile order, a ragged last row tile and an odd width (131); width 600
+    has rows too long for wide_out_kernel's (1, x) accumulators: the last layer's (db | dS) take wide_extgrad_kernel's pass."""
     A, dev = amd, torch.device("cuda:0")
     torch.manual_seed(h + L)
     spec = A.IcnnSpec(n_hidden=h, in_features=C, n_layers=L, act0=act0) if act0 != "relu" else A.IcnnSpec(n_hidden=h, in_features=C, n_layers=L)
