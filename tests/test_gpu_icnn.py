@@ -475,6 +475,14 @@ def test_wide_and_deep_shapes_on_the_layer_by_layer_path(amd, h, C, L, act0, hw)
     ref = O.icnn_forward_image(p, grid_t[None], act0=act0)
     np.testing.assert_allclose(logits[0].cpu().numpy(), ref.reshape(-1).numpy(), atol=2e-5, rtol=2e-5)
     if act0 != "relu":
+        # a periodic layer 0: the backward GEMM's mask epilogue multiplies by the activation's derivative at the kept pre-activation
+        dl = torch.randn(1, H * W)
+        gb = A.icnn.backward(spec, flat, grid, dl.to(dev))
+        pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        (O.icnn_forward_image(pr, grid_t[None], act0=act0).reshape(-1) * dl[0]).sum().backward()
+        gotb = A.unpack_params(spec, gb[0].cpu())
+        for k in pr:
+            np.testing.assert_allclose(gotb[k].numpy(), pr[k].grad.numpy(), rtol=1e-3, atol=2e-5 * float(pr[k].grad.abs().max()) + 1e-10, err_msg=k)
         return
     loss, grads = A.loss_grad(spec, flat, grid, un.reshape(1, -1).to(dev), loss="se")
     lo, go = O.loss_and_grads(p, grid_t[None], un[None, None], "se")
