@@ -452,7 +452,7 @@ def test_any_hidden_width_up_to_130_runs_zero_padded(amd, h, C, L):
 
 @pytest.mark.parametrize("h,C,L,act0,hw", [(256, 2, 1, "relu", (20, 24)), (350, 2, 3, "relu", (20, 24)), (160, 3, 2, "relu", (20, 24)),
                                            (64, 2, 4, "relu", (20, 24)), (200, 2, 2, "cos", (20, 24)), (131, 2, 3, "relu", (40, 50)),
-                                           (256, 3, 2, "relu", (33, 47)), (600, 2, 1, "relu", (20, 24))])
+                                           (256, 3, 2, "relu", (33, 47)), (600, 2, 1, "relu", (20, 24)), (72, 2, 3, "sin", (20, 24))])
 def test_wide_and_deep_shapes_on_the_layer_by_layer_path(amd, h, C, L, act0, hw):
     """n_hidden > 130 (and more than two hidden layers) have no fused kernel - the weight image of such a layer does
     not fit the LDS - and run layer by layer (awesome_amd/csrc/wide.h: activations in HBM, plain GEMMs, the same update kernel).  Forward,
@@ -462,7 +462,8 @@ def test_wide_and_deep_shapes_on_the_layer_by_layer_path(amd, h, C, L, act0, hw)
     has rows too long for wide_out_kernel's (1, x) accumulators: the last layer's (db | dS) take wide_extgrad_kernel's pass."""
     A, dev = amd, torch.device("cuda:0")
     torch.manual_seed(h + L)
-    spec = A.IcnnSpec(n_hidden=h, in_features=C, n_layers=L, act0=act0) if act0 != "relu" else A.IcnnSpec(n_hidden=h, in_features=C, n_layers=L)
+    omega = 3.0 if act0 == "sin" else 1.0
+    spec = A.IcnnSpec(n_hidden=h, in_features=C, n_layers=L, act0=act0, omega=omega) if act0 != "relu" else A.IcnnSpec(n_hidden=h, in_features=C, n_layers=L)
     assert spec.supported()
     p = {k: (torch.rand(shp) - 0.45) * (0.6 / np.sqrt(h)) for k, shp in spec.keys_shapes()}
     H, W = hw
@@ -472,14 +473,14 @@ def test_wide_and_deep_shapes_on_the_layer_by_layer_path(amd, h, C, L, act0, hw)
     flat = A.pack_state_dict(spec, p, dev)[None].contiguous()
     grid = A.Grid.from_image_grid(grid_t[None].to(dev)) if C == 3 else A.Grid.linspace(W, H, dev)
     logits = A.forward(spec, flat, grid)
-    ref = O.icnn_forward_image(p, grid_t[None], act0=act0)
+    ref = O.icnn_forward_image(p, grid_t[None], act0=act0, omega=omega)
     np.testing.assert_allclose(logits[0].cpu().numpy(), ref.reshape(-1).numpy(), atol=2e-5, rtol=2e-5)
     if act0 != "relu":
         # a periodic layer 0: the backward GEMM's mask epilogue multiplies by the activation's derivative at the kept pre-activation
         dl = torch.randn(1, H * W)
         gb = A.icnn.backward(spec, flat, grid, dl.to(dev))
         pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
-        (O.icnn_forward_image(pr, grid_t[None], act0=act0).reshape(-1) * dl[0]).sum().backward()
+        (O.icnn_forward_image(pr, grid_t[None], act0=act0, omega=omega).reshape(-1) * dl[0]).sum().backward()
         gotb = A.unpack_params(spec, gb[0].cpu())
         for k in pr:
             np.testing.assert_allclose(gotb[k].numpy(), pr[k].grad.numpy(), rtol=1e-3, atol=2e-5 * float(pr[k].grad.abs().max()) + 1e-10, err_msg=k)
