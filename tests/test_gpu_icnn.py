@@ -505,3 +505,28 @@ def test_wide_and_deep_shapes_on_the_layer_by_layer_path(amd, h, C, L, act0, hw)
     for k in pf:
         np.testing.assert_allclose(gotp[k].numpy(), pf[k].numpy(), rtol=1e-3, atol=5e-6, err_msg=k)
     np.testing.assert_allclose(res.logits[0].cpu().numpy(), O.icnn_forward_image(pf, grid_t[None]).reshape(-1).numpy(), atol=1e-4, rtol=1e-4)
+
+
+def test_wide_path_fits_several_images_per_call(amd):
+    """The layer-by-layer path with n_images = 3 in one C-ABI call (own parameters, targets and optimizer state per image, one shared
+    workspace): every image's loss curve and final parameters equal its own single-image oracle fit."""
+    A, dev = amd, torch.device("cuda:0")
+    h, L, H, W, n = 160, 2, 20, 24, 3
+    spec = A.IcnnSpec(n_hidden=h, in_features=2, n_layers=L)
+    grid_t = O.positional_grid(W, H)
+    grid = A.Grid.linspace(W, H, dev)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    ps, uns = [], []
+    for i in range(n):
+        torch.manual_seed(40 + i)
+        ps.append({k: (torch.rand(shp) - 0.45) * (0.6 / np.sqrt(h)) for k, shp in spec.keys_shapes()})
+        uns.append((((yy - 7 - 2 * i) ** 2 + (xx - 9 - 3 * i) ** 2) > 25 + 5 * i).float())
+    flat = torch.stack([A.pack_state_dict(spec, p, dev) for p in ps]).contiguous()
+    un = torch.stack([u.reshape(-1) for u in uns]).to(dev)
+    res = A.fit(spec, flat.clone(), grid, un, 10, lr=2e-3)
+    for i in range(n):
+        pf, losses, _ = O.fit_icnn(ps[i], grid_t[None], uns[i][None, None], 10, lr=2e-3)
+        np.testing.assert_allclose(res.loss_hist[i].cpu().numpy(), np.asarray(losses, np.float32), rtol=3e-4, err_msg=f"image {i}")
+        got = A.unpack_params(spec, res.params[i].cpu())
+        for k in pf:
+            np.testing.assert_allclose(got[k].numpy(), pf[k].numpy(), rtol=1e-3, atol=5e-6, err_msg=f"image {i} {k}")
