@@ -168,8 +168,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V4 ? GM_WAV
             chunkA(kbase, h, rA, cA);
             chunkB(kbase, h, rB, cB);
             if (V4) {
+#if !(defined(GM_EXP) && (GM_EXP & 256))   // (timing experiment: the A tiles of the k-loop are not loaded)
                 gemm_load4<4>(a.A, a.lda, rA, rmaxA, cA, cmaxA, ra[h]);
+#endif
+#if !(defined(GM_EXP) && (GM_EXP & 512))   // (... the B tiles)
                 gemm_load4<4>(a.B, a.ldb, rB, rmaxB, cB, cmaxB, rb[h]);
+#endif
             } else {
                 gemm_load4_any(fa, a.A, a.lda, rA, rmaxA, cA, cmaxA, ra[h]);
                 gemm_load4_any(fb, a.B, a.ldb, rB, rmaxB, cB, cmaxB, rb[h]);
