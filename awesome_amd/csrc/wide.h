@@ -452,6 +452,7 @@ inline int wide_forward(const WideMap& m, const WideWs& w, const InrModelDesc* m
     a.N = N; a.h = h; a.C = C; a.hs = hs; a.hp = w.hp; a.hsv = w.hsv; a.loss_kind = loss_kind; a.train = train ? 1 : 0;
     a.part_ext = w.part2;
     if (hs <= 5 * 64) hipLaunchKernelGGL((wide_out_kernel<5, true>), dim3(w.blocks), dim3(256), 0, s, a);
+    else if (hs <= 6 * 64) hipLaunchKernelGGL((wide_out_kernel<6, true>), dim3(w.blocks), dim3(256), 0, s, a);   // (h = 350: no AGPR spills)
     else if (hs <= 7 * 64) hipLaunchKernelGGL((wide_out_kernel<7, true>), dim3(w.blocks), dim3(256), 0, s, a);
     else if (hs <= 9 * 64) hipLaunchKernelGGL((wide_out_kernel<9, true>), dim3(w.blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wide_out_kernel<WIDE_OUT_MAXQ, false>), dim3(w.blocks), dim3(256), 0, s, a);
