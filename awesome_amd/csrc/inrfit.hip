@@ -862,7 +862,7 @@ static int wide_forward_all(const InrModelDesc* model, const float* params, cons
 // loss + gradients (loss->kind may be INR_LOSS_EXTERNAL: `targets` = dL/dlogits) of every image into grads_out / loss_out
 static int wide_loss_grad_all(const InrModelDesc* model, const float* params, const InrGridDesc* grid, const float* targets,
                               const InrLossDesc* loss, int n_images, float* loss_out, float* grads_out, void* workspace,
-                              int64_t workspace_bytes, hipStream_t s) {
+                              int64_t workspace_bytes, hipStream_t s, float* dcoords = nullptr) {
     WideMap m;
     WideWs w;
     float* coef;
@@ -875,7 +875,7 @@ static int wide_loss_grad_all(const InrModelDesc* model, const float* params, co
         w.coef = coef + 2 * img;
         const float* p = params + (size_t)img * m.P;
         if ((rc = wide_forward(m, w, model, p, grid, img, targets + (size_t)img * N, loss->kind, true, nullptr, s))) return rc;
-        if ((rc = wide_backward(m, w, model, p, N, s))) return rc;
+        if ((rc = wide_backward(m, w, model, p, N, s, targets + (size_t)img * N, dcoords ? dcoords + (size_t)img * m.C * N : nullptr))) return rc;
         if (hipMemcpyAsync(grads_out + (size_t)img * m.P, w.grads, sizeof(float) * m.P, hipMemcpyDeviceToDevice, s) != hipSuccess) return INR_ELAUNCH;
         if (loss_out && hipMemcpyAsync(loss_out + img, w.grads + m.P, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return INR_ELAUNCH;
     }
@@ -981,9 +981,9 @@ int inrfit_backward(const InrModelDesc* model, const float* params, const InrGri
     Workspace w;
     if (!params || !dlogits || !grads) return INR_EINVAL;
     if (use_wide(model)) {
-        if (dcoords) return INR_EUNSUPPORTED;   // coordinate gradients (ICNN behind a deformation): fused shapes only
         const InrLossDesc ext{INR_LOSS_EXTERNAL, INR_WEIGHT_NONE, 1.f, 0.f, 0.f};
-        return wide_loss_grad_all(model, params, grid, dlogits, &ext, n_images, nullptr, grads, workspace, workspace_bytes, (hipStream_t)stream);
+        return wide_loss_grad_all(model, params, grid, dlogits, &ext, n_images, nullptr, grads, workspace, workspace_bytes, (hipStream_t)stream,
+                                  dcoords);
     }
     int rc = prepare(model, grid, n_images, workspace, workspace_bytes, &e, &w);
     if (rc) return rc;

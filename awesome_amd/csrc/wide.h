@@ -302,6 +302,34 @@ __global__ __launch_bounds__(256) void wide_out_kernel(const WideOutArgs a) {
     }
 }
 
+// dL/dcoords (an ICNN behind a learned deformation: convex_diffeomorphism_net.py:170-177): every pre-activation gradient dz [N][hp] the
+// backward pass produces contributes dz . Wx with Wx [h][C] = the weights the coordinates enter that layer with (S_k of a hidden layer,
+// W_in of layer 0); the output layer contributes s_o dL/dlogit (`init`: dx is started from it).  One pass over dz per layer, 16 lanes per
+// point; dx is planar [C][N] like the fused kernels' (icnn_step.h, DX).  Only the autograd bridge asks for it.
+__global__ __launch_bounds__(256) void wide_dx_kernel(const float* __restrict__ dz, int hp, const float* __restrict__ wx, int h, int C, long long N,
+                                                      const float* __restrict__ dlogits, const float* __restrict__ so, float* __restrict__ dx,
+                                                      int init) {
+    const int l15 = threadIdx.x & 15;
+    const long long p = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool valid = p < N;
+    const float* row = dz + (size_t)(valid ? p : 0) * hp;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int j = 4 * l15; j < h; j += 64) {
+        const f32x4 d = *(const f32x4*)(row + j);      // hp is a multiple of 4; the padding columns hold zeros
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (j + e < h)
+                for (int c = 0; c < C; ++c) acc[c] = fmaf(d[e], wx[(j + e) * C + c], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] = sum_over_points(acc[c]);
+    if (valid && l15 < C) {
+        const float a = l15 == 0 ? acc[0] : (l15 == 1 ? acc[1] : acc[2]);
+        float* o = dx + (size_t)l15 * N + p;
+        *o = (init ? so[l15] * dlogits[p] : *o) + a;
+    }
+}
+
 // gradients w.r.t. everything the "ext" inputs (1, x) multiply - (db_k | dS_k) of a hidden layer, (db_in | dW_in) of layer 0:
 //   part[block][i][c] = sum over the block's WIDE_OUT_CHUNK points of dz[p][i] ext_c[p],  ext = (1, x_0 ..)
 // A thread owns four consecutive units (one 16-byte load per point), 256 / (hp / 4) points are in flight per block and four loads per
@@ -465,12 +493,16 @@ inline int wide_forward(const WideMap& m, const WideWs& w, const InrModelDesc* m
 }
 
 // backward of ONE image from dZ_L (w.dza, written by wide_forward): every remaining parameter gradient into w.grads (flat order)
-inline int wide_backward(const WideMap& m, const WideWs& w, const InrModelDesc* md, const float* params, long long N, hipStream_t s) {
+inline int wide_backward(const WideMap& m, const WideWs& w, const InrModelDesc* md, const float* params, long long N, hipStream_t s,
+                         const float* dlogits = nullptr, float* dcoords = nullptr) {   // dcoords [C][N] (with dlogits = dL/dlogits): also dL/dcoords
     const int h = m.h, C = m.C, hs = w.hs, hp = w.hp, parts = splitk_parts(N);
     float* gr = w.grads;
     int rc;
     float *dz = w.dza, *dzn = w.dzb;
     const int tiles = (int)((N + GM_BM - 1) / GM_BM);
+    const dim3 dxgrid((unsigned)((N + 15) / 16));
+    if (dcoords)   // s_o dL/dlogit + dZ_L . S_{L-1}
+        hipLaunchKernelGGL(wide_dx_kernel, dxgrid, dim3(256), 0, s, dz, hp, params + m.p_s(m.L - 1), h, C, N, dlogits, params + m.p_so(), dcoords, 1);
     for (int k = m.L - 1; k >= 0; --k) {
         {   // dW_k [h x h] = dz^T Z_k: the contraction over the points, split into chunks of WIDE_CHUNK
             GemmArgs g{};
@@ -497,7 +529,9 @@ inline int wide_backward(const WideMap& m, const WideWs& w, const InrModelDesc* 
             g.extsum = w.part2; g.ext = w.z[k] + h; g.ext_ld = hs; g.C_in = C;
             if ((rc = gemm_launch(s, false, false, g))) return rc;
             // what the ext inputs multiply in the layer below: (db_{k-1} | dS_{k-1}), or (db_in | dW_in) of layer 0
-            hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(h * (1 + C)), w.part2, tiles, h, 1 + C, k > 0 ? 3 : 1, m, k > 0 ? k - 1 : 0, gr);
+            hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(h * (1 + C)), w.part2, tiles, h, 1 + C, k > 0 ? 3 : 1, m, k > 0 ? k - 1 : 0, gr);            if (dcoords)   // ... and what the coordinates multiply there: S_{k-1}, or W_in
+                hipLaunchKernelGGL(wide_dx_kernel, dxgrid, dim3(256), 0, s, dzn, hp, params + (k > 0 ? m.p_s(k - 1) : m.p_win()), h, C, N, dlogits,
+                                   params + m.p_so(), dcoords, 0);
         }
         float* t = dz; dz = dzn; dzn = t;
     }

@@ -173,7 +173,8 @@ int inrfit_loss_grad(const InrModelDesc* model, const float* params, const InrGr
  * arbitrary downstream criterion (AwesomeImageLoss, FBMSJointLoss, ... - awesome/agent/torch_agent.py:478-491).
  * dcoords (optional, may be NULL) [n_images][C][n_points]: dlogits[p] * d logit_p / d coords_p - the gradient that flows
  * on into a learned deformation of the grid (ConvexDiffeomorphismNet.forward, awesome/model/convex_diffeomorphism_net.py:
- * 173-178: ICNN(flow(Ax+b))). */
+ * 173-178: ICNN(flow(Ax+b))).  Shapes with a fused kernel: relu layer 0 only; the layer-by-layer shapes (n_hidden > 130 or more than
+ * two hidden layers): any layer-0 activation. */
 int inrfit_backward(const InrModelDesc* model, const float* params, const InrGridDesc* grid, const float* dlogits,
                     int n_images, float* grads, float* dcoords, void* workspace, int64_t workspace_bytes, void* stream);
 

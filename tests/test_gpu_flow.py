@@ -16,8 +16,10 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("h,c,l", [(130, 2, 1), (130, 3, 1), (130, 2, 2), (64, 3, 2), (32, 2, 1)])
+@pytest.mark.parametrize("h,c,l", [(130, 2, 1), (130, 3, 1), (130, 2, 2), (64, 3, 2), (32, 2, 1), (256, 2, 1), (150, 3, 3), (350, 2, 2)])
 def test_coordinate_gradient(dev, h, c, l):
+    """dL/dcoords (the ICNN behind a learned deformation) and the parameter gradients for an external dL/dlogits; the last three shapes
+    have no fused kernel: the layer-by-layer path adds dz . (S_k | W_in) per layer (csrc/wide.h, wide_dx_kernel)."""
     import awesome_amd as A
     torch.manual_seed(3)
     spec = A.IcnnSpec(h, c, l)
