@@ -351,7 +351,10 @@ class ConvexDiffeomorphismNet(nn.Module, PriorFitMixin):
 
     # -- the 'resnet' flow backbone: no fused fit; the reference's loop (:376-421) as device-side autograd ---------------------------
     def _generic(self) -> bool:
-        return self.diffeo_net.backbone == "resnet"
+        """No fused composite for this module: a whole-image flow backbone, or an ICNN shape without a fused kernel (n_hidden > 130 or more
+        than two hidden layers: the layer-by-layer path) - forward / backward compose the flow and ICNN kernels through autograd (the
+        ICNN's dL/dcoords feeds the flow's backward), `pretrain` runs the reference's loop on that."""
+        return self.diffeo_net.backbone == "resnet" or not self.convex_net.spec.fused()
 
     def _generic_fit(self, grid, unaries, flat, epochs, opts):
         """Adam (weight decay on the weight_g group only) + ReduceLROnPlateau(patience 200, factor 0.5) + enforce_convexity per step,
@@ -528,7 +531,11 @@ class ConvexDiffeomorphismNet(nn.Module, PriorFitMixin):
                 return torch.stack([self.convex_net(self.diffeo_net(self.linear(rows[i]))).reshape(1, h, w) for i in range(b)], 0)
             return self.convex_net(self.diffeo_net(self.linear(x)))
         ispec, fspec, icnn, flow = self._ordered_params()
-        run = lambda coords: _CdnFunction.apply(coords, ispec, fspec, len(icnn), *icnn, *flow)  # noqa: E731
+        if not ispec.fused():   # flow kernels, then the layer-by-layer ICNN: two autograd bridges instead of the fused composite
+            from .convex_net import _IcnnFunction
+            run = lambda coords: _IcnnFunction.apply(_FlowFunction.apply(coords, fspec, *flow), ispec, *icnn)  # noqa: E731
+        else:
+            run = lambda coords: _CdnFunction.apply(coords, ispec, fspec, len(icnn), *icnn, *flow)  # noqa: E731
         if x.dim() == 4:
             b, c, h, w = x.shape
             return torch.stack([run(x[i].reshape(c, h * w)).reshape(1, h, w) for i in range(b)], 0)

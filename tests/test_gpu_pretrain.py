@@ -374,6 +374,54 @@ def test_pretrain_convex_diffeomorphism_net_with_the_resnet_backbone(dev):
         assert torch.equal(v.cpu(), before[k].cpu()), k
 
 
+def test_convex_diffeomorphism_net_with_an_icnn_shape_without_a_fused_kernel(dev):
+    """ConvexDiffeomorphismNet(n_hidden=160, n_hidden_layers=3): no fused composite exists for that ICNN - forward and backward
+    compose the flow kernels and the layer-by-layer ICNN through two autograd bridges (the ICNN's dL/dcoords feeds the flow's backward).
+    Forward and the BCE gradients of every parameter vs autograd through the oracle; `pretrain` runs the reference's loop on it."""
+    from awesome_amd.dataset import convex_blob_unaries
+    from awesome_amd.model import ConvexDiffeomorphismNet
+    args = dict(n_hidden=160, n_hidden_layers=3, nf_layers=4, nf_hidden=24, diffeo_args=dict(backbone="normal_block"))
+    torch.manual_seed(17)
+    m = ConvexDiffeomorphismNet(**args)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    m.to(dev)
+    H = W = 24
+    xs = torch.linspace(0, 1, W)
+    grid = torch.stack([xs[None, :].expand(H, W), xs[:, None].expand(H, W)], 0)[None].contiguous()
+    un = (convex_blob_unaries(256, 1).reshape(256, 256)[::11, ::11][:H, :W] > 0.5).float()[None, None]
+    logits = m(grid.to(dev))
+    ref = O.convex_diffeo_forward(sd, grid[0].reshape(2, -1).t(), 4)
+    np.testing.assert_allclose(logits.detach().cpu().numpy().reshape(-1), ref.detach().numpy().reshape(-1), atol=3e-5, rtol=1e-4)
+    torch.nn.BCELoss()(torch.sigmoid(logits), un.to(dev)).backward()
+    torch.nn.BCELoss()(torch.sigmoid(ref).reshape(un.shape), un).backward()
+    gmax = max(float(v.grad.abs().max()) for v in sd.values())
+    for k, p in m.named_parameters():
+        r = sd[k].grad.numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy().reshape(r.shape), r, rtol=2e-3, atol=2e-5 * gmax, err_msg=k)
+    # the pretrain entry point on the same kind of module (generic engine: the reference's loop as device-side autograd) against the
+    # oracle's restatement of that loop from the same state (a 3 x 160 ICNN leaves the reference's lr = 3e-3 after a few steps - on
+    # the CPU oracle as on the device, to the same logits - hence the smaller rate; the gate is not what this checks)
+    torch.manual_seed(17)
+    ds, wrapper, agent = _setup(dev, ConvexDiffeomorphismNet, args, n=1, size=32)
+    base = (convex_blob_unaries(256, 2).reshape(256, 256)[::8, ::8] > 0.5).float()
+    ds._inner.unaries = lambda i: base
+    state0, un0 = _item(ds, 0, dev)
+    state = wrapper.pretrain(train_set=ds, test_set=None, device=dev, agent=agent, use_progress_bar=False, num_epochs=25, lr=5e-4,
+                             proper_prior_fit_threshold=0.0)
+    rep = wrapper.prior_module.pretrain_report
+    assert len(rep) == 1 and rep[0]["retries"] == 0, rep
+    got = state["cache"]["0"]
+    sd0 = {k: v.detach().cpu().clone() for k, v in state0.items()}
+    pf, losses, _ = O.fit_convex_diffeo(sd0, ds._xy[None].cpu(), un0.reshape(1, 1, 32, 32).cpu(), 25, 4, lr=5e-4, loss_kind="bce",
+                                        weight_decay_on_weight_g=5e-5, plateau=dict(patience=200, factor=0.5))
+    assert losses[-1] < losses[0]
+    for k in pf:
+        # (weight_v of a weight-normed 1x1 layer has an analytically zero gradient: Adam turns its rounding noise into +- lr steps, a
+        # walk of at most 25 lr on either side)
+        tol = dict(rtol=0, atol=2 * 25 * 5e-4) if k.endswith("scale.weight_v") else dict(rtol=2e-3, atol=2e-5)
+        np.testing.assert_allclose(got[k].cpu().numpy(), pf[k].numpy(), err_msg=k, **tol)
+
+
 def test_pretrain_path_connected_net_warm_start_chain_keeps_actnorm(dev):
     """with reuse_state (the default) frame k starts from frame k-1's fitted state, loaded in the reference with
     load_state_dict (path_connected_net.py:867-870) - data_dep_init_done = 1 included - so ActNorm is NOT re-initialised from the
