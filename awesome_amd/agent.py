@@ -224,7 +224,12 @@ class JointTrainer:
         if not pids <= {id(p) for p in groups[0]["params"]}:
             return None
         if hasattr(prior, "_specs"):
-            ispec, dspec = prior._specs()
+            try:
+                ispec, dspec = prior._specs()
+            except NotImplementedError:   # no fused form of this composite at all ('resnet' flow backbone): autograd step
+                return None
+            if not ispec.fused():         # its ICNN runs layer by layer: the composite's autograd bridges, no fused joint step
+                return None
             family = "pcn" if type(dspec).__name__ == "RnvpSpec" else "cdn"
             if kind != "adam" and family == "cdn":
                 return None

@@ -24,7 +24,10 @@ from . import icnn as K
 def _ordered_parameters(model: torch.nn.Module) -> List[torch.nn.Parameter]:
     """The model's parameters in the order of its flat vector."""
     if hasattr(model, "_ordered_params"):
-        op = model._ordered_params()
+        try:
+            op = model._ordered_params()
+        except NotImplementedError:   # a composite without a fused form (ConvexDiffeomorphismNet with the 'resnet' flow backbone)
+            return list(model.parameters())
         if isinstance(op, tuple) and len(op) == 4:   # PathConnectedNet / ConvexDiffeomorphismNet: (ispec, fspec, icnn, flow)
             return list(op[2]) + list(op[3])
         return list(op)

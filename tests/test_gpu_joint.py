@@ -542,6 +542,32 @@ def test_joint_trainer_takes_the_autograd_step_for_shapes_without_a_fused_kernel
     assert torch.isfinite(l0) and torch.isfinite(l1) and float(l1) != float(l0) and not torch.equal(bank.params[0], before[0])
 
 
+@pytest.mark.parametrize("kind", ["resnet_flow", "wide_icnn"])
+def test_joint_trainer_with_composites_that_have_no_fused_form(dev, kind):
+    """ConvexDiffeomorphismNet with the 'resnet' flow backbone, or with an ICNN of the layer-by-layer shapes: PriorBank rows, the
+    planned autograd step (the module's composed bridges) and the optimizer all work; nothing reaches a fused entry point."""
+    from awesome_amd.agent import JointTrainer
+    from awesome_amd.measures import FBMSJointLoss
+    from awesome_amd.model import ConvexDiffeomorphismNet
+    from awesome_amd.prior_bank import _ordered_parameters
+    if kind == "resnet_flow":
+        factory = lambda: ConvexDiffeomorphismNet(n_hidden=32, n_hidden_layers=1, nf_layers=2, nf_hidden=8,   # noqa: E731
+                                                  diffeo_args=dict(backbone="resnet", num_blocks=1))
+    else:
+        factory = lambda: ConvexDiffeomorphismNet(n_hidden=136, n_hidden_layers=3, nf_layers=2, nf_hidden=16,   # noqa: E731
+                                                  diffeo_args=dict(backbone="normal_block"))
+    items, seg, wrapper, bank = _joint_setup(dev, factory, S=32)
+    opt = torch.optim.Adam(list(seg.parameters()) + list(_ordered_parameters(wrapper.prior_module)), lr=2e-4)
+    tr = JointTrainer(wrapper, bank, FBMSJointLoss(alpha=1.0, beta=2.0), opt)
+    assert tr.fused is False
+    before = bank.params.detach().clone()
+    (image, _, xy), target = items[0]
+    args = (image[None].to(dev), torch.zeros(1, 1, 1, 1, device=dev), xy[None].to(dev))
+    l0, _ = tr.perform_step(0, args, target[None].to(dev))
+    l1, _ = tr.perform_step(0, args, target[None].to(dev))
+    assert torch.isfinite(l0) and torch.isfinite(l1) and float(l1) != float(l0) and not torch.equal(bank.params[0], before[0])
+
+
 def test_nonfinite_segmentation_output_freezes_row_and_backbone(dev):
     """a NaN in the segmentation output.  AWESOME_IMAGE form: the prior's own loss column does not contain `seg`, the
     COMPOSITE loss does - the row freezes (status 1) all the same; the trainer hands the backbone a zero gradient instead of NaN and
