@@ -82,3 +82,22 @@ def test_point_kernels_use_no_scratch_memory():
         assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, k
     step = [k for k in stats if "icnn_step_kernelILi130ELi2ELb1ELb0ELi0E" in k["name"]]
     assert step and step[0]["vgpr_spill_count"] == 0, step
+
+
+def test_gemm_kernels_keep_four_workgroups_per_cu():
+    """csrc/gemm.h: the 16-byte-load instantiations (what the layer-by-layer path launches) are compiled for four waves per SIMD -
+    at most 128 VGPRs, 40 KB of LDS per workgroup - and the forward / weight-gradient forms spill nothing (the backward form's
+    epilogue, which also sums dz^T (1, x), spills a few registers once per workgroup)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_stats
+    from awesome_amd import build
+    stats = kernel_stats.kernel_stats(build.build(force=False, verbose=False))
+    if stats is None:
+        pytest.skip("llvm-readelf / clang-offload-bundler not available")
+    v4 = [k for k in stats if "gemm_kernelILb" in k["name"] and "ELb1EEEv" in k["name"]]   # <TA, TB, V4 = true>
+    assert len(v4) == 4, [k["name"] for k in stats if "gemm_kernel" in k["name"]]
+    for k in v4:
+        assert k["vgpr_count"] <= 128 and k["group_segment_fixed_size"] <= 40960, k
+        if "ILb0ELb1ELb1" in k["name"] or "ILb1ELb0ELb1" in k["name"]:
+            assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
