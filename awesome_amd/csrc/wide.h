@@ -375,12 +375,24 @@ __global__ __launch_bounds__(256) void wide_extgrad_kernel(const float* __restri
 //   mode 1 (layer 0, B = the ext columns):           column 0 -> b_in[i]; j >= 1 -> W_in[i][j - 1]
 //   mode 3 (hidden layer k, the ext columns only):   column 0 -> b_k[i];  j >= 1 -> S_k[i][j - 1]
 //   mode 2 (output layer, a = 1, b = hsv + 1):       column j < h -> w_o[j]; j == h -> b_o; h < j <= h + C -> s_o[j - h - 1]; the last -> the loss
-__global__ __launch_bounds__(1024) void wide_reduce_kernel(const float* __restrict__ part, int parts, int a, int b, int mode, WideMap m, int k,
-                                                          float* __restrict__ grads) {
+// (one launch takes up to two such reductions - e.g. a layer's weight-gradient partials and the (db | dS) partials its backward GEMM
+// left: the first j0.nblocks blocks serve the first)
+struct WideRedJob {
+    const float* part;
+    int parts, a, b, mode, k, nblocks;
+};
+inline WideRedJob wide_red_job(const float* part, int parts, int a, int b, int mode, int k) {
+    return WideRedJob{part, parts, a, b, mode, k, (a * b + 63) / 64};
+}
+__global__ __launch_bounds__(1024) void wide_reduce_kernel(const WideRedJob j0, const WideRedJob j1, WideMap m, float* __restrict__ grads) {
     // 64 consecutive elements per block, the partials in 16 contiguous ranges (one per wave) summed in order, ranges added in order
     __shared__ float sm[16][64];
+    const bool first = (int)blockIdx.x < j0.nblocks;
+    const WideRedJob& jb = first ? j0 : j1;
+    const float* __restrict__ part = jb.part;
+    const int parts = jb.parts, a = jb.a, b = jb.b, mode = jb.mode, k = jb.k;
     const int el = threadIdx.x & 63, pg = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + el;
+    const int e = ((int)blockIdx.x - (first ? 0 : j0.nblocks)) * 64 + el;
     const int per = (parts + 15) / 16, q0 = pg * per, q1 = q0 + per < parts ? q0 + per : parts;
     float v = 0.f;
     if (e < a * b) {
@@ -401,7 +413,9 @@ __global__ __launch_bounds__(1024) void wide_reduce_kernel(const float* __restri
     else dst = j < m.h ? m.p_wo() + j : (j == m.h ? m.p_bo() : (j <= m.h + m.C ? m.p_so() + (j - m.h - 1) : m.P));   // (last column: the loss)
     grads[dst] = v;
 }
-#define WIDE_RED(n) dim3((unsigned)(((n) + 63) / 64)), dim3(1024), 0, s
+inline void wide_reduce(hipStream_t s, const WideMap& m, float* grads, WideRedJob j0, WideRedJob j1 = WideRedJob{nullptr, 0, 0, 0, 0, 0, 0}) {
+    hipLaunchKernelGGL(wide_reduce_kernel, dim3((unsigned)(j0.nblocks + j1.nblocks)), dim3(1024), 0, s, j0, j1, m, grads);
+}
 
 // ---- workspace --------------------------------------------------------------------------------------------------------------------------
 struct WideWs {
@@ -485,9 +499,10 @@ inline int wide_forward(const WideMap& m, const WideWs& w, const InrModelDesc* m
     else if (hs <= 9 * 64) hipLaunchKernelGGL((wide_out_kernel<9, true>), dim3(w.blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wide_out_kernel<WIDE_OUT_MAXQ, false>), dim3(w.blocks), dim3(256), 0, s, a);
     if (train) {
-        hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(w.hsv + 1), w.part, w.blocks, 1, w.hsv + 1, 2, m, 0, w.grads);   // (dw_o | db_o | ds_o | loss)
-        if (wide_out_has_ext(hs))   // (db | dS) of the last hidden layer = dZ_L^T (1, X), summed by the same pass
-            hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(h * (1 + C)), w.part2, w.blocks, h, 1 + C, 3, m, m.L - 1, w.grads);
+        // (dw_o | db_o | ds_o | loss), and (db | dS) of the last hidden layer = dZ_L^T (1, X) where the same pass summed it
+        const WideRedJob jo = wide_red_job(w.part, w.blocks, 1, w.hsv + 1, 2, 0);
+        if (wide_out_has_ext(hs)) wide_reduce(s, m, w.grads, jo, wide_red_job(w.part2, w.blocks, h, 1 + C, 3, m.L - 1));
+        else wide_reduce(s, m, w.grads, jo);
     }
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
@@ -508,13 +523,12 @@ inline int wide_backward(const WideMap& m, const WideWs& w, const InrModelDesc* 
             GemmArgs g{};
             g.A = dz; g.lda = hp; g.B = w.z[k]; g.ldb = hs; g.C = w.part; g.ldc = h;
             g.M = h; g.N = h; g.K = (int)N; g.k_per_split = WIDE_CHUNK; g.c_split_stride = (long long)h * h; g.padA = g.padB = 1;
-            if ((rc = gemm_launch(s, true, false, g))) return rc;
-            hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(h * h), w.part, parts, h, h, 0, m, k, gr);
+            if ((rc = gemm_launch(s, true, false, g))) return rc;   // (its partials are added up with the (1, x) sums below: one launch)
             // (db_k | dS_k) = dz^T (1, X): summed by the kernel that wrote dz (wide_out_kernel for the last layer, the backward GEMM's
             // epilogue below for the others); only rows too long for wide_out_kernel's accumulators take a pass of their own
             if (k == m.L - 1 && !wide_out_has_ext(hs)) {
                 hipLaunchKernelGGL(wide_extgrad_kernel, dim3(w.blocks), dim3(256), 0, s, dz, hp, w.z[k] + h, hs, N, h, C, w.part2);
-                hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(h * (1 + C)), w.part2, w.blocks, h, 1 + C, 3, m, k, gr);
+                wide_reduce(s, m, gr, wide_red_job(w.part2, w.blocks, h, 1 + C, 3, k));
             }
         }
         {   // dz_k = (dz W_k) (.) act'(layer k)     (the mask in the GEMM's epilogue, and dz_k^T (1, X) per 128-row tile)
@@ -529,7 +543,7 @@ inline int wide_backward(const WideMap& m, const WideWs& w, const InrModelDesc* 
             g.extsum = w.part2; g.ext = w.z[k] + h; g.ext_ld = hs; g.C_in = C;
             if ((rc = gemm_launch(s, false, false, g))) return rc;
             // what the ext inputs multiply in the layer below: (db_{k-1} | dS_{k-1}), or (db_in | dW_in) of layer 0
-            hipLaunchKernelGGL(wide_reduce_kernel, WIDE_RED(h * (1 + C)), w.part2, tiles, h, 1 + C, k > 0 ? 3 : 1, m, k > 0 ? k - 1 : 0, gr);            if (dcoords)   // ... and what the coordinates multiply there: S_{k-1}, or W_in
+            wide_reduce(s, m, gr, wide_red_job(w.part, parts, h, h, 0, k), wide_red_job(w.part2, tiles, h, 1 + C, k > 0 ? 3 : 1, k > 0 ? k - 1 : 0));            if (dcoords)   // ... and what the coordinates multiply there: S_{k-1}, or W_in
                 hipLaunchKernelGGL(wide_dx_kernel, dxgrid, dim3(256), 0, s, dzn, hp, params + (k > 0 ? m.p_s(k - 1) : m.p_win()), h, C, N, dlogits,
                                    params + m.p_so(), dcoords, 0);
         }
