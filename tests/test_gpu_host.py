@@ -198,6 +198,7 @@ def test_run_py_reads_a_reference_schema_yaml(tmp_path):
     ("c4_sequence128x16.yaml", {"dataset_args": {"size": 32, "frames": 4}, "agent_args": {"pretrain_args": {"num_epochs": 60}}}, dict(images=1)),
     ("c1_disc64_siren.yaml", {}, dict(images=1)),
     ("c1_disc64_no_prior.yaml", {}, dict(images=1)),
+    ("c2_blob256_wide256.yaml", {"dataset_args": {"size": 64}, "agent_args": {"pretrain_args": {"num_epochs": 300}}}, dict(images=1)),   # layer-by-layer path
 ])
 def test_run_py_configs_of_the_flow_priors(tmp_path, config, override, checks):
     """The configs of BASELINE configs[4] (noisy pseudo-labels: per-image pre-fit, then joint epochs with FBMSJointLoss through
