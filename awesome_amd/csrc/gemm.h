@@ -63,6 +63,11 @@ struct GemmArgs {
     int mask_ld, mask_act;
     float omega;
     int vecA, vecB;        // widest aligned load of the operand: 4 floats (base and row stride multiples of 16 bytes), 2, or 1
+    int buf;               // V4 operands may be read through buffer descriptors: rows past an operand's last row read as 0 in hardware, and
+                           // whatever else lies outside op(A) / op(B) (a k past K inside a padded row, a free index past M / N) is FINITE
+                           // and either multiplied by a zero of the other operand or lands in rows / columns of C that are not stored -
+                           // no address clamp, no select (wide.h: zero-padded weight copy, zeroed padding columns)
+    int c_zero_to;         // MASK: columns [N, c_zero_to) of every stored row get zeros (the padding of a [.][ldc] activation buffer)
     float* extsum;         // NN products only, optional: [row tiles][N][1 + C_in] = sum over the tile's 128 rows m of C[m][n] (1, x_m) (x from `ext`)
     int padA, padB;        // the operand's rows may be READ up to the next multiple of 4 floats past their logical end (finite values
                            // there: the padded activation rows of wide.h); what is read there is replaced by 0
@@ -115,8 +120,9 @@ __device__ __forceinline__ void gemm_load4_any(int flavour, const float* __restr
 
 // V4: both operands take 16-byte loads everywhere (aligned bases and row strides; no vector straddles the end of a row, or it may be
 // read: gemm_all_vec4) - the k-loop then has no branch in it.  The other instantiation picks a load flavour per operand and tile.
-template <bool TA, bool TB, bool V4>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V4 ? GM_WAVES : 2, GM_WAVES))) void gemm_kernel(const GemmArgs a) {
+template <bool TA, bool TB, int MODE>   // MODE 0: general, 1: V4, 2: V4 through buffer loads (GemmArgs::buf)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? GM_WAVES : 2, GM_WAVES))) void gemm_kernel(const GemmArgs a) {
+    constexpr bool V4 = MODE >= 1, BUF = MODE == 2;
     __shared__ __attribute__((aligned(16))) float As[2][GM_STAGE];
     __shared__ __attribute__((aligned(16))) float Bs[2][GM_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -158,6 +164,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V4 ? GM_WAV
         r = TB ? n0 + (tid >> 2) + 64 * h : kbase + (tid >> 4);
         c = TB ? kbase + (tid & 3) * 4 : n0 + (tid & 15) * 4 + 64 * h;
     };
+    // BUF: raw buffer descriptors over the stored operands (stride 0, num_records = rows x row stride in bytes: an offset past it reads 0)
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, BUF ? (TA ? a.K : a.M) * a.lda * 4 : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, BUF ? (TB ? a.N : a.K) * a.ldb * 4 : 0, 0x00020000);
     auto load_tiles = [&](int kbase, f32x4 (&ra)[2], f32x4 (&rb)[2]) {
         const bool tail = kbase + GM_BK > k_hi;
         const int fa = V4 ? 4 : (!TA && tail ? gemm_flavour(a.vecA, a.padA, kbase, GM_BK, k_hi) : flA);
@@ -167,7 +176,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V4 ? GM_WAV
             int rA, cA, rB, cB;
             chunkA(kbase, h, rA, cA);
             chunkB(kbase, h, rB, cB);
-            if (V4) {
+            if (BUF) {   // one 32-bit offset per chunk; the descriptor's range check is the only bound
+                ra[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (unsigned)(rA * a.lda + cA) * 4u, 0, 0));
+                rb[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)(rB * a.ldb + cB) * 4u, 0, 0));
+            } else if (V4) {
 #if !(defined(GM_EXP) && (GM_EXP & 256))   // (timing experiment: the A tiles of the k-loop are not loaded)
                 gemm_load4<4>(a.A, a.lda, rA, rmaxA, cA, cmaxA, ra[h]);
 #endif
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V4 ? GM_WAV
             int rA, cA, rB, cB;
             chunkA(kbase, h, rA, cA);
             chunkB(kbase, h, rB, cB);
-            const int la = rA < rmaxA ? cmaxA - cA : 0, lb = rB < rmaxB ? cmaxB - cB : 0;
+            const int la = BUF ? 4 : (rA < rmaxA ? cmaxA - cA : 0), lb = BUF ? 4 : (rB < rmaxB ? cmaxB - cB : 0);
             float* dA = !TA ? sA + ((tid >> 2) + 64 * h) * GM_LDK + (tid & 3) * 4 : sA + (tid >> 4) * GM_LDF + (tid & 15) * 4 + 64 * h;
             float* dB = TB ? sB + ((tid >> 2) + 64 * h) * GM_LDK + (tid & 3) * 4 : sB + (tid >> 4) * GM_LDF + (tid & 15) * 4 + 64 * h;
             f32x4 oa, ob;
@@ -373,6 +385,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V4 ? GM_WAV
                 for (int j = 0; j < 4; ++j) {
                     const int n = ncol(j);
                     if (n < a.N) Cz[(size_t)m * a.ldc + n] = o[j];
+                    else if (a.epi == GEMM_EPI_MASK && n < a.c_zero_to) Cz[(size_t)m * a.ldc + n] = 0.f;
                 }
             }
         }
@@ -421,11 +434,13 @@ inline int gemm_launch(hipStream_t s, bool tA, bool tB, GemmArgs g) {
     // 16-byte loads throughout: aligned operands whose contiguous extent is a multiple of 4 floats or may be read up to the next one
     // (a split contraction ends inside the rows of an operand contiguous along k: always readable)
     const int contigA = tA ? g.M : g.K, contigB = tB ? g.K : g.N;
+    if (g.buf && ((long long)(tA ? g.K : g.M) * g.lda * 4 >= (1ll << 31) || (long long)(tB ? g.N : g.K) * g.ldb * 4 >= (1ll << 31))) g.buf = 0;   // (32-bit byte offsets)
     const bool v4 = g.vecA == 4 && g.vecB == 4 && ((contigA & 3) == 0 || g.padA) && ((contigB & 3) == 0 || g.padB) && (g.k_per_split & 3) == 0;
 #define GEMM_GO(TA_, TB_)                                                                            \
     do {                                                                                             \
-        if (v4) hipLaunchKernelGGL((gemm_kernel<TA_, TB_, true>), grid, dim3(256), 0, s, g);         \
-        else hipLaunchKernelGGL((gemm_kernel<TA_, TB_, false>), grid, dim3(256), 0, s, g);           \
+        if (v4 && g.buf) hipLaunchKernelGGL((gemm_kernel<TA_, TB_, 2>), grid, dim3(256), 0, s, g);   \
+        else if (v4) hipLaunchKernelGGL((gemm_kernel<TA_, TB_, 1>), grid, dim3(256), 0, s, g);       \
+        else hipLaunchKernelGGL((gemm_kernel<TA_, TB_, 0>), grid, dim3(256), 0, s, g);               \
     } while (0)
     if (!tA && tB) GEMM_GO(false, true);
     else if (!tA && !tB) GEMM_GO(false, false);

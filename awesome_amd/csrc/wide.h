@@ -69,11 +69,12 @@ __global__ __launch_bounds__(256) void wide_layer0_kernel(InrGridDesc gd, int im
     // rows, WIDE_L0_POINTS apart: its layer-0 weights are read once, the points' coordinates are all requested before the first
     // row is computed (32-bit index arithmetic inside the block)
     const int nq = hs >> 2;
-    if ((int)blockIdx.x >= pt_blocks) {   // the launch's last blocks: hidden-layer weights -> [L][h][hp], zero padded (gemm.h V4 operands)
-        const int per = pk.h * hp, e = (((int)blockIdx.x - pt_blocks) * gridDim.y + blockIdx.y) * 256 + threadIdx.x;
+    if ((int)blockIdx.x >= pt_blocks) {   // the launch's last blocks: hidden-layer weights -> [L][hq][hq], hq = h rounded up to 16, zero padded:
+                                          // whatever a k-step reads past h of the other operand meets a zero here (gemm.h, GemmArgs::buf)
+        const int hq = (pk.h + 15) / 16 * 16, per = hq * hq, e = (((int)blockIdx.x - pt_blocks) * gridDim.y + blockIdx.y) * 256 + threadIdx.x;
         if (e < pk.L * per) {
-            const int k = e / per, r = e - k * per, i = r / hp, j = r - i * hp;
-            wp[e] = j < pk.h ? params[pk.p_w(k) + i * pk.h + j] : 0.f;
+            const int k = e / per, r = e - k * per, i = r / hq, j = r - i * hq;
+            wp[e] = i < pk.h && j < pk.h ? params[pk.p_w(k) + i * pk.h + j] : 0.f;
         }
         return;
     }
@@ -447,7 +448,10 @@ inline WideWs carve_wide(const WideMap& m, long long N, bool need_pre0, void* ba
         w.part2 = take((w.blocks > tiles ? w.blocks : tiles) * m.h * (1 + m.C) * 4);
     }
     w.grads = take(((long long)m.P + 1 + 31) / 32 * 32 * 4);
-    w.wp = take((long long)m.L * m.h * w.hp * 4);
+    {
+        const long long hq = (m.h + 15) / 16 * 16;
+        w.wp = take((long long)m.L * hq * hq * 4);
+    }
     w.coef = nullptr;
     w.bytes = off;
     return w;
@@ -475,15 +479,16 @@ inline int wide_forward(const WideMap& m, const WideWs& w, const InrModelDesc* m
     // layer 0 (+ in the launch's last blocks: the padded copy of the hidden layers' weights)
     const int pt_blocks = (int)((N + WIDE_L0_POINTS * WIDE_L0_REP - 1) / (WIDE_L0_POINTS * WIDE_L0_REP));
     const unsigned l0y = (unsigned)((WIDE_L0_POINTS * (hs / 4) + 255) / 256);
-    const int pk_blocks = (int)(((long long)m.L * h * w.hp + 256ll * l0y - 1) / (256ll * l0y));
+    const int hq = (h + 15) / 16 * 16;   // row / column count of a packed weight matrix
+    const int pk_blocks = (int)(((long long)m.L * hq * hq + 256ll * l0y - 1) / (256ll * l0y));
     const dim3 l0grid((unsigned)(pt_blocks + pk_blocks), l0y);
     if (C == 2) hipLaunchKernelGGL(wide_layer0_kernel<2>, l0grid, dim3(256), 0, s, *grid, img, params + m.p_win(), params + m.p_bin(), N, h, hs, w.hp, md->act0, md->act_omega, w.z[0], w.pre0, pt_blocks, params, m, w.wp);
     else hipLaunchKernelGGL(wide_layer0_kernel<3>, l0grid, dim3(256), 0, s, *grid, img, params + m.p_win(), params + m.p_bin(), N, h, hs, w.hp, md->act0, md->act_omega, w.z[0], w.pre0, pt_blocks, params, m, w.wp);
     for (int k = 0; k < m.L; ++k) {
         // z_{k+1} [N x h] = relu(z_k [N x h] . W_k^T + b_k + S_k x)   (W_k stored [h_out][h_in]; bias, skip and relu in the GEMM's epilogue)
         GemmArgs g{};
-        g.A = w.z[k]; g.lda = hs; g.B = w.wp + (size_t)k * h * w.hp; g.ldb = w.hp; g.C = w.z[k + 1]; g.ldc = hs;
-        g.M = (int)N; g.N = h; g.K = h; g.padA = g.padB = 1;
+        g.A = w.z[k]; g.lda = hs; g.B = w.wp + (size_t)k * hq * hq; g.ldb = hq; g.C = w.z[k + 1]; g.ldc = hs;
+        g.M = (int)N; g.N = h; g.K = h; g.padA = g.padB = 1; g.buf = 1;
         g.epi = GEMM_EPI_HIDDEN; g.bias = params + m.p_b(k); g.skip = params + m.p_s(k); g.ext = w.z[k] + h; g.ext_ld = hs; g.C_in = C; g.ext_copy = hs - h;
         int rc = gemm_launch(s, false, true, g);
         if (rc) return rc;
@@ -514,7 +519,7 @@ inline int wide_backward(const WideMap& m, const WideWs& w, const InrModelDesc* 
     float* gr = w.grads;
     int rc;
     float *dz = w.dza, *dzn = w.dzb;
-    const int tiles = (int)((N + GM_BM - 1) / GM_BM);
+    const int tiles = (int)((N + GM_BM - 1) / GM_BM), hq = (h + 15) / 16 * 16;
     const dim3 dxgrid((unsigned)((N + 15) / 16));
     if (dcoords)   // s_o dL/dlogit + dZ_L . S_{L-1}
         hipLaunchKernelGGL(wide_dx_kernel, dxgrid, dim3(256), 0, s, dz, hp, params + m.p_s(m.L - 1), h, C, N, dlogits, params + m.p_so(), dcoords, 1);
@@ -522,7 +527,7 @@ inline int wide_backward(const WideMap& m, const WideWs& w, const InrModelDesc* 
         {   // dW_k [h x h] = dz^T Z_k: the contraction over the points, split into chunks of WIDE_CHUNK
             GemmArgs g{};
             g.A = dz; g.lda = hp; g.B = w.z[k]; g.ldb = hs; g.C = w.part; g.ldc = h;
-            g.M = h; g.N = h; g.K = (int)N; g.k_per_split = WIDE_CHUNK; g.c_split_stride = (long long)h * h; g.padA = g.padB = 1;
+            g.M = h; g.N = h; g.K = (int)N; g.k_per_split = WIDE_CHUNK; g.c_split_stride = (long long)h * h; g.padA = g.padB = 1; g.buf = 1;
             if ((rc = gemm_launch(s, true, false, g))) return rc;   // (its partials are added up with the (1, x) sums below: one launch)
             // (db_k | dS_k) = dz^T (1, X): summed by the kernel that wrote dz (wide_out_kernel for the last layer, the backward GEMM's
             // epilogue below for the others); only rows too long for wide_out_kernel's accumulators take a pass of their own
@@ -533,8 +538,8 @@ inline int wide_backward(const WideMap& m, const WideWs& w, const InrModelDesc* 
         }
         {   // dz_k = (dz W_k) (.) act'(layer k)     (the mask in the GEMM's epilogue, and dz_k^T (1, X) per 128-row tile)
             GemmArgs g{};
-            g.A = dz; g.lda = hp; g.B = w.wp + (size_t)k * h * hp; g.ldb = hp; g.C = dzn; g.ldc = hp;   // (the weights wide_forward packed)
-            g.M = (int)N; g.N = h; g.K = h; g.padA = g.padB = 1;
+            g.A = dz; g.lda = hp; g.B = w.wp + (size_t)k * hq * hq; g.ldb = hq; g.C = dzn; g.ldc = hp;   // (the weights wide_forward packed)
+            g.M = (int)N; g.N = h; g.K = h; g.padA = g.padB = 1; g.buf = 1; g.c_zero_to = hp;
             g.epi = GEMM_EPI_MASK;
             const int act = k == 0 ? md->act0 : INR_ACT_RELU;
             g.mask_act = act; g.omega = md->act_omega;

@@ -95,9 +95,9 @@ def test_gemm_kernels_keep_four_workgroups_per_cu():
     stats = kernel_stats.kernel_stats(build.build(force=False, verbose=False))
     if stats is None:
         pytest.skip("llvm-readelf / clang-offload-bundler not available")
-    v4 = [k for k in stats if "gemm_kernelILb" in k["name"] and "ELb1EEEv" in k["name"]]   # <TA, TB, V4 = true>
+    v4 = [k for k in stats if "gemm_kernelILb" in k["name"] and "ELi2EEEv" in k["name"]]   # <TA, TB, MODE = 2>: buffer-descriptor loads
     assert len(v4) == 4, [k["name"] for k in stats if "gemm_kernel" in k["name"]]
     for k in v4:
         assert k["vgpr_count"] <= 128 and k["group_segment_fixed_size"] <= 40960, k
-        if "ILb0ELb1ELb1" in k["name"] or "ILb1ELb0ELb1" in k["name"]:
+        if "ILb0ELb1ELi2" in k["name"] or "ILb1ELb0ELi2" in k["name"]:
             assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
