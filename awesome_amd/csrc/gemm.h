@@ -177,8 +177,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? GM_W
             chunkA(kbase, h, rA, cA);
             chunkB(kbase, h, rB, cB);
             if (BUF) {   // one 32-bit offset per chunk; the descriptor's range check is the only bound
-                ra[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (unsigned)(rA * a.lda + cA) * 4u, 0, 0));
-                rb[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)(rB * a.ldb + cB) * 4u, 0, 0));
+                // (a chunk past the free extent of an operand stored along its free index is sent out of range too: it reads 0 without
+                // touching the next row's cache lines - at h = 350 a ninth of the column chunks)
+                const unsigned oa = TA && cA >= cmaxA ? 0xfffffff0u : (unsigned)(rA * a.lda + cA) * 4u;
+                const unsigned ob = !TB && cB >= cmaxB ? 0xfffffff0u : (unsigned)(rB * a.ldb + cB) * 4u;
+                ra[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, oa, 0, 0));
+                rb[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, ob, 0, 0));
             } else if (V4) {
 #if !(defined(GM_EXP) && (GM_EXP & 256))   // (timing experiment: the A tiles of the k-loop are not loaded)
                 gemm_load4<4>(a.A, a.lda, rA, rmaxA, cA, cmaxA, ra[h]);
