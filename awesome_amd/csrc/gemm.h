@@ -14,10 +14,12 @@
 // Shape of the kernel (gfx950): 256 threads = 4 waves, a 128 x 128 output tile per workgroup, 64 x 64 per wave = 4 x 4 accumulator
 // tiles of v_mfma_f32_16x16x4_f32 (64 accumulator registers), K in steps of 16 through LDS, global loads of step s + 1 in flight
 // while step s multiplies (register-staged double buffer: two 20 KB LDS buffers, one barrier per step; <= 128 VGPRs: four workgroups
-// per CU).  Two instantiations per operand form: V4 (every load 16 bytes wide, no branch in the k-loop; what wide.h launches) and a
-// general one that picks 16- / 8- / 4-byte loads per operand and tile (odd strides, unaligned bases: star.h's shapes).  Workgroups are
+// per CU).  Three instantiations per operand form: the general one picks 16- / 8- / 4-byte loads per operand and tile (odd strides,
+// unaligned bases: star.h's shapes); V4 loads 16 bytes everywhere from clamped addresses; the buffer mode (GemmArgs::buf, what wide.h
+// launches) reads the operands through buffer descriptors - the hardware's range check is the only bound, no clamp and no select is
+// left in the k-loop (64 MFMAs, 8 LDS reads, 4 loads, 4 LDS writes, ~15 others).  Workgroups are
 // dealt to tiles XCD by XCD (consecutive tiles share an L2).  Measured (h = 256, N = 65 536, one launch): the MFMAs alone 58 us (54.6 at
-// the pipe's peak), the k-loop 71 - 79, with epilogue 83 - 99; the ablation table is in profiles/NOTES.md.
+// the pipe's peak), the k-loop 71 - 79 and 83 - 99 with epilogue for V4, 77 - 94 with epilogue in buffer mode; the ablation table is in profiles/NOTES.md.
 //
 // How the operands reach the matrix pipe with ONE ds_read_b128 per operand tile and 16 k (8 LDS reads per 64 MFMAs):
 //   * an operand that is contiguous along k (A [M][K], B [N][K]) sits in LDS as [row][16 k] (row stride 20 floats: 16-byte aligned,
