@@ -24,12 +24,19 @@
 
 namespace {
 
-constexpr int WIDE_CHUNK = 512;      // points per split of the point-contractions (GEMM partials)
+constexpr int WIDE_CHUNK = 512;      // points per split of the point-contractions (GEMM partials): at least; see wide_chunk
 #ifndef INR_WIDE_OUT_CHUNK
 #define INR_WIDE_OUT_CHUNK 128
 #endif
 constexpr int WIDE_OUT_CHUNK = INR_WIDE_OUT_CHUNK;  // points per block of wide_out_kernel / wide_extgrad_kernel (their partials)
-inline int splitk_parts(long long N) { return (int)((N + WIDE_CHUNK - 1) / WIDE_CHUNK); }
+// a weight gradient's contraction over the points: 512 points per slice up to 3 x 3 tiles of 128, 1024 from 4 x 4 on (the launch keeps >= 1024
+// workgroups at 65 536 points; half the partial-product bytes to write and to add up: h = 512 L = 2 1 879 -> 1 849 us; at 3 x 3 tiles the 576
+// workgroups of 1024-point slices were 1 % slower)
+inline int wide_chunk(int h) {
+    const int t = (h + GM_BM - 1) / GM_BM;
+    return t >= 4 ? 2 * WIDE_CHUNK : WIDE_CHUNK;
+}
+inline int splitk_parts(long long N, int h) { return (int)((N + wide_chunk(h) - 1) / wide_chunk(h)); }
 inline int out_parts(long long N) { return (int)((N + WIDE_OUT_CHUNK - 1) / WIDE_OUT_CHUNK); }
 
 // ---- flat parameter offsets for any (h, C, L) ---------------------------------------------------------------------------------------------
@@ -441,7 +448,7 @@ inline WideWs carve_wide(const WideMap& m, long long N, bool need_pre0, void* ba
     w.pre0 = need_pre0 ? take(N * w.hp * 4) : nullptr;
     w.dza = take(N * w.hp * 4);
     w.dzb = take(N * w.hp * 4);
-    const long long part_gemm = (long long)splitk_parts(N) * m.h * m.h, part_out = (long long)w.blocks * (w.hsv + 1 > m.h * (1 + m.C) ? w.hsv + 1 : m.h * (1 + m.C));
+    const long long part_gemm = (long long)splitk_parts(N, m.h) * m.h * m.h, part_out = (long long)w.blocks * (w.hsv + 1 > m.h * (1 + m.C) ? w.hsv + 1 : m.h * (1 + m.C));
     w.part = take((part_gemm > part_out ? part_gemm : part_out) * 4);
     {   // (db | dS) partials: one [h][1 + C] block per wide_out_kernel block / per 128-row tile of the backward GEMM
         const long long tiles = (N + GM_BM - 1) / GM_BM;
@@ -515,7 +522,7 @@ inline int wide_forward(const WideMap& m, const WideWs& w, const InrModelDesc* m
 // backward of ONE image from dZ_L (w.dza, written by wide_forward): every remaining parameter gradient into w.grads (flat order)
 inline int wide_backward(const WideMap& m, const WideWs& w, const InrModelDesc* md, const float* params, long long N, hipStream_t s,
                          const float* dlogits = nullptr, float* dcoords = nullptr) {   // dcoords [C][N] (with dlogits = dL/dlogits): also dL/dcoords
-    const int h = m.h, C = m.C, hs = w.hs, hp = w.hp, parts = splitk_parts(N);
+    const int h = m.h, C = m.C, hs = w.hs, hp = w.hp, parts = splitk_parts(N, h);
     float* gr = w.grads;
     int rc;
     float *dz = w.dza, *dzn = w.dzb;
@@ -527,7 +534,7 @@ inline int wide_backward(const WideMap& m, const WideWs& w, const InrModelDesc* 
         {   // dW_k [h x h] = dz^T Z_k: the contraction over the points, split into chunks of WIDE_CHUNK
             GemmArgs g{};
             g.A = dz; g.lda = hp; g.B = w.z[k]; g.ldb = hs; g.C = w.part; g.ldc = h;
-            g.M = h; g.N = h; g.K = (int)N; g.k_per_split = WIDE_CHUNK; g.c_split_stride = (long long)h * h; g.padA = g.padB = 1; g.buf = 1;
+            g.M = h; g.N = h; g.K = (int)N; g.k_per_split = wide_chunk(h); g.c_split_stride = (long long)h * h; g.padA = g.padB = 1; g.buf = 1;
             if ((rc = gemm_launch(s, true, false, g))) return rc;   // (its partials are added up with the (1, x) sums below: one launch)
             // (db_k | dS_k) = dz^T (1, X): summed by the kernel that wrote dz (wide_out_kernel for the last layer, the backward GEMM's
             // epilogue below for the others); only rows too long for wide_out_kernel's accumulators take a pass of their own
