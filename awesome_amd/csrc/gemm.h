@@ -122,7 +122,7 @@ __device__ __forceinline__ void gemm_load4_any(int flavour, const float* __restr
 
 // V4: both operands take 16-byte loads everywhere (aligned bases and row strides; no vector straddles the end of a row, or it may be
 // read: gemm_all_vec4) - the k-loop then has no branch in it.  The other instantiation picks a load flavour per operand and tile.
-template <bool TA, bool TB, int MODE>   // MODE 0: general, 1: V4, 2: V4 through buffer loads (GemmArgs::buf)
+template <bool TA, bool TB, int MODE, int EPI>   // MODE 0: general, 1: V4, 2: V4 through buffer loads (GemmArgs::buf); EPI: the epilogue (GemmArgs::epi)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? GM_WAVES : 2, GM_WAVES))) void gemm_kernel(const GemmArgs a) {
     constexpr bool V4 = MODE >= 1, BUF = MODE == 2;
     __shared__ __attribute__((aligned(16))) float As[2][GM_STAGE];
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? GM_W
     auto mrow = [&](int i, int r) { const int q = 4 * g + r; return m0 + wm * 64 + (TA ? 4 * q + i : 16 * i + q); };
     // HIDDEN: the per-column constants (bias, skip weights) of this lane's four columns once
     float bn[4] = {0.f, 0.f, 0.f, 0.f}, sn[4][3] = {};
-    if (a.epi == GEMM_EPI_HIDDEN) {
+    if (EPI == GEMM_EPI_HIDDEN) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = min(ncol(j), a.N - 1);
@@ -322,20 +322,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? GM_W
     }
     // a lane's four columns are consecutive (operand B contiguous along n) and its row of C / of the mask may be accessed as 16 bytes
     const bool vec_c = !TB && ncol(0) + 3 < a.N && (a.ldc & 3) == 0 && (((size_t)Cz) & 15) == 0;
-    const bool vec_mask = !TB && a.epi == GEMM_EPI_MASK && ncol(0) + 3 < a.N && (a.mask_ld & 3) == 0 && (((size_t)a.mask) & 15) == 0;
+    const bool vec_mask = !TB && EPI == GEMM_EPI_MASK && ncol(0) + 3 < a.N && (a.mask_ld & 3) == 0 && (((size_t)a.mask) & 15) == 0;
     float es[4][4] = {};   // NN + extsum: this lane's share of sum_m C[m][n] (1, x_m) for its four columns
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float xm[4][3] = {};
         f32x4 zm[4];
-        if (a.epi == GEMM_EPI_HIDDEN) {
+        if (EPI == GEMM_EPI_HIDDEN) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float* xp = a.ext + (size_t)min(mrow(i, r), a.M - 1) * a.ext_ld + 1;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) xm[r][c] = xp[c < a.C_in ? c : 0];
             }
-        } else if (a.epi == GEMM_EPI_MASK) {
+        } else if (EPI == GEMM_EPI_MASK) {
             if (!TA && !TB && a.extsum) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -362,12 +362,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? GM_W
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v = acc[i][j][r];
-                if (a.epi == GEMM_EPI_HIDDEN) {
+                if (EPI == GEMM_EPI_HIDDEN) {
                     v += bn[j];
 #pragma unroll
                     for (int c = 0; c < 3; ++c) v = fmaf(sn[j][c], xm[r][c], v);   // (unused channels: 0 * x)
                     v = fmaxf(v, 0.f);
-                } else if (a.epi == GEMM_EPI_MASK) {
+                } else if (EPI == GEMM_EPI_MASK) {
                     const float z = zm[r][j];
                     if (a.mask_act == INR_ACT_COS) v *= -hw_sin(z);
                     else if (a.mask_act == INR_ACT_SIN) v *= a.omega * hw_cos(a.omega * z);
@@ -391,12 +391,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? GM_W
                 for (int j = 0; j < 4; ++j) {
                     const int n = ncol(j);
                     if (n < a.N) Cz[(size_t)m * a.ldc + n] = o[j];
-                    else if (a.epi == GEMM_EPI_MASK && n < a.c_zero_to) Cz[(size_t)m * a.ldc + n] = 0.f;
+                    else if (EPI == GEMM_EPI_MASK && n < a.c_zero_to) Cz[(size_t)m * a.ldc + n] = 0.f;
                 }
             }
         }
     }
-    if (a.epi == GEMM_EPI_HIDDEN && a.ext_copy > 0 && bx == (int)gridDim.x - 1 && tid < GM_BM && m0 + tid < a.M) {
+    if (EPI == GEMM_EPI_HIDDEN && a.ext_copy > 0 && bx == (int)gridDim.x - 1 && tid < GM_BM && m0 + tid < a.M) {
         const float* src = a.ext + (size_t)(m0 + tid) * a.ext_ld;
         float* dst = Cz + (size_t)(m0 + tid) * a.ldc + a.N;
         for (int c = 0; c < a.ext_copy; ++c) dst[c] = src[c];
@@ -442,17 +442,24 @@ inline int gemm_launch(hipStream_t s, bool tA, bool tB, GemmArgs g) {
     const int contigA = tA ? g.M : g.K, contigB = tB ? g.K : g.N;
     if (g.buf && ((long long)(tA ? g.K : g.M) * g.lda * 4 >= (1ll << 31) || (long long)(tB ? g.N : g.K) * g.ldb * 4 >= (1ll << 31))) g.buf = 0;   // (32-bit byte offsets)
     const bool v4 = g.vecA == 4 && g.vecB == 4 && ((contigA & 3) == 0 || g.padA) && ((contigB & 3) == 0 || g.padB) && (g.k_per_split & 3) == 0;
-#define GEMM_GO(TA_, TB_)                                                                            \
-    do {                                                                                             \
-        if (v4 && g.buf) hipLaunchKernelGGL((gemm_kernel<TA_, TB_, 2>), grid, dim3(256), 0, s, g);   \
-        else if (v4) hipLaunchKernelGGL((gemm_kernel<TA_, TB_, 1>), grid, dim3(256), 0, s, g);       \
-        else hipLaunchKernelGGL((gemm_kernel<TA_, TB_, 0>), grid, dim3(256), 0, s, g);               \
+    // epilogues other than the plain store exist for the products that use them: HIDDEN on A . B^T (a layer's forward), MASK on A . B (its
+    // backward); each kernel holds the code of ONE epilogue
+    const int mode = v4 && g.buf ? 2 : (v4 ? 1 : 0);
+    if (g.epi == GEMM_EPI_HIDDEN && !(!tA && tB)) return INR_EINVAL;
+    if (g.epi == GEMM_EPI_MASK && !(!tA && !tB)) return INR_EINVAL;
+#define GEMM_GO3(TA_, TB_, EPI_)                                                                          \
+    do {                                                                                                  \
+        if (mode == 2) hipLaunchKernelGGL((gemm_kernel<TA_, TB_, 2, EPI_>), grid, dim3(256), 0, s, g);    \
+        else if (mode == 1) hipLaunchKernelGGL((gemm_kernel<TA_, TB_, 1, EPI_>), grid, dim3(256), 0, s, g); \
+        else hipLaunchKernelGGL((gemm_kernel<TA_, TB_, 0, EPI_>), grid, dim3(256), 0, s, g);              \
     } while (0)
-    if (!tA && tB) GEMM_GO(false, true);
-    else if (!tA && !tB) GEMM_GO(false, false);
-    else if (tA && !tB) GEMM_GO(true, false);
-    else GEMM_GO(true, true);
-#undef GEMM_GO
+    if (g.epi == GEMM_EPI_HIDDEN) GEMM_GO3(false, true, GEMM_EPI_HIDDEN);
+    else if (g.epi == GEMM_EPI_MASK) GEMM_GO3(false, false, GEMM_EPI_MASK);
+    else if (!tA && tB) GEMM_GO3(false, true, GEMM_EPI_STORE);
+    else if (!tA && !tB) GEMM_GO3(false, false, GEMM_EPI_STORE);
+    else if (tA && !tB) GEMM_GO3(true, false, GEMM_EPI_STORE);
+    else GEMM_GO3(true, true, GEMM_EPI_STORE);
+#undef GEMM_GO3
     return hipGetLastError() == hipSuccess ? INR_OK : INR_ELAUNCH;
 }
 
