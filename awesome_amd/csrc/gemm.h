@@ -45,7 +45,7 @@ constexpr int GM_LDK = 20;            // [row][k] layout: floats per row
 constexpr int GM_LDF = GM_BM + 4;     // [k][free] layout: floats per k-row
 constexpr int GM_STAGE = GM_BM * GM_LDK > GM_BK * GM_LDF ? GM_BM * GM_LDK : GM_BK * GM_LDF;   // floats per operand and buffer
 
-enum { GEMM_EPI_STORE = 0, GEMM_EPI_HIDDEN = 1, GEMM_EPI_MASK = 2 };
+enum { GEMM_EPI_STORE = 0, GEMM_EPI_HIDDEN = 1, GEMM_EPI_MASK = 2, GEMM_EPI_MASKP = 3 };   // (MASKP: kernel-side name of MASK with a periodic mask_act)
 
 struct GemmArgs {
     const float* A;        // TA ? [K][lda] : [M][lda]
@@ -124,7 +124,7 @@ __device__ __forceinline__ void gemm_load4_any(int flavour, const float* __restr
 // read: gemm_all_vec4) - the k-loop then has no branch in it.  The other instantiation picks a load flavour per operand and tile.
 template <bool TA, bool TB, int MODE, int EPI>   // MODE 0: general, 1: V4, 2: V4 through buffer loads (GemmArgs::buf); EPI: the epilogue (GemmArgs::epi)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? GM_WAVES : 2, GM_WAVES))) void gemm_kernel(const GemmArgs a) {
-    constexpr bool V4 = MODE >= 1, BUF = MODE == 2;
+    constexpr bool V4 = MODE >= 1, BUF = MODE == 2, ISMASK = EPI == GEMM_EPI_MASK || EPI == GEMM_EPI_MASKP;
     __shared__ __attribute__((aligned(16))) float As[2][GM_STAGE];
     __shared__ __attribute__((aligned(16))) float Bs[2][GM_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? GM_W
     }
     // a lane's four columns are consecutive (operand B contiguous along n) and its row of C / of the mask may be accessed as 16 bytes
     const bool vec_c = !TB && ncol(0) + 3 < a.N && (a.ldc & 3) == 0 && (((size_t)Cz) & 15) == 0;
-    const bool vec_mask = !TB && EPI == GEMM_EPI_MASK && ncol(0) + 3 < a.N && (a.mask_ld & 3) == 0 && (((size_t)a.mask) & 15) == 0;
+    const bool vec_mask = !TB && ISMASK && ncol(0) + 3 < a.N && (a.mask_ld & 3) == 0 && (((size_t)a.mask) & 15) == 0;
     float es[4][4] = {};   // NN + extsum: this lane's share of sum_m C[m][n] (1, x_m) for its four columns
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? GM_W
 #pragma unroll
                 for (int c = 0; c < 3; ++c) xm[r][c] = xp[c < a.C_in ? c : 0];
             }
-        } else if (EPI == GEMM_EPI_MASK) {
+        } else if (ISMASK) {
             if (!TA && !TB && a.extsum) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -367,10 +367,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? GM_W
 #pragma unroll
                     for (int c = 0; c < 3; ++c) v = fmaf(sn[j][c], xm[r][c], v);   // (unused channels: 0 * x)
                     v = fmaxf(v, 0.f);
-                } else if (EPI == GEMM_EPI_MASK) {
+                } else if (ISMASK) {
                     const float z = zm[r][j];
-                    if (a.mask_act == INR_ACT_COS) v *= -hw_sin(z);
-                    else if (a.mask_act == INR_ACT_SIN) v *= a.omega * hw_cos(a.omega * z);
+                    if (EPI == GEMM_EPI_MASKP) v *= a.mask_act == INR_ACT_COS ? -hw_sin(z) : a.omega * hw_cos(a.omega * z);
                     else v = z > 0.f ? v : 0.f;
                 }
                 o[j] = v;
@@ -391,7 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? GM_W
                 for (int j = 0; j < 4; ++j) {
                     const int n = ncol(j);
                     if (n < a.N) Cz[(size_t)m * a.ldc + n] = o[j];
-                    else if (EPI == GEMM_EPI_MASK && n < a.c_zero_to) Cz[(size_t)m * a.ldc + n] = 0.f;
+                    else if (ISMASK && n < a.c_zero_to) Cz[(size_t)m * a.ldc + n] = 0.f;
                 }
             }
         }
@@ -454,7 +453,8 @@ inline int gemm_launch(hipStream_t s, bool tA, bool tB, GemmArgs g) {
         else hipLaunchKernelGGL((gemm_kernel<TA_, TB_, 0, EPI_>), grid, dim3(256), 0, s, g);              \
     } while (0)
     if (g.epi == GEMM_EPI_HIDDEN) GEMM_GO3(false, true, GEMM_EPI_HIDDEN);
-    else if (g.epi == GEMM_EPI_MASK) GEMM_GO3(false, false, GEMM_EPI_MASK);
+    else if (g.epi == GEMM_EPI_MASK && g.mask_act == INR_ACT_RELU) GEMM_GO3(false, false, GEMM_EPI_MASK);
+    else if (g.epi == GEMM_EPI_MASK) GEMM_GO3(false, false, GEMM_EPI_MASKP);
     else if (!tA && tB) GEMM_GO3(false, true, GEMM_EPI_STORE);
     else if (!tA && !tB) GEMM_GO3(false, false, GEMM_EPI_STORE);
     else if (tA && !tB) GEMM_GO3(true, false, GEMM_EPI_STORE);
