@@ -29,7 +29,9 @@
 //   * an operand that is contiguous along its free index (A^T stored [K][M], B [K][N]) sits in LDS as [k][128 (+4)]; lane (g, l15)
 //     reads row k = 4 g + kk, columns 4 l15 .. 4 l15 + 3 - element i of the vector is its value for accumulator tile i, i.e. tile i
 //     holds the rows / columns 4 q + i instead of 16 i + q.  The permutation is undone where the tile is stored (for the columns it
-//     even helps: a lane's four tiles are four consecutive floats of C, one 16-byte store).
+//     even helps: a lane's four tiles are four consecutive floats of C, one 16-byte store).  A B operand stored [N][K] gets the same
+//     column order by a row permutation on its way INTO LDS (tile row 4 a + b of a 64-row half is written to LDS row 16 b + a): every operand
+//     form stores 16 bytes per lane and row.
 // The reference arithmetic these products serve: awesome/model/convex_net.py:205-214 (z_{k+1} = relu(W_k z_k + b_k + S_k x)) and its
 // backward pass; star.ipynb cell 2 / 3 for the star prior.
 #pragma once
@@ -207,7 +209,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? GM_W
             chunkB(kbase, h, rB, cB);
             const int la = BUF ? 4 : (rA < rmaxA ? cmaxA - cA : 0), lb = BUF ? 4 : (rB < rmaxB ? cmaxB - cB : 0);
             float* dA = !TA ? sA + ((tid >> 2) + 64 * h) * GM_LDK + (tid & 3) * 4 : sA + (tid >> 4) * GM_LDF + (tid & 15) * 4 + 64 * h;
-            float* dB = TB ? sB + ((tid >> 2) + 64 * h) * GM_LDK + (tid & 3) * 4 : sB + (tid >> 4) * GM_LDF + (tid & 15) * 4 + 64 * h;
+            // (B stored [N][K]: tile row 4 a + b of a 64-row half goes to LDS row 16 b + a, so that the reader's row 16 j + l15 is column
+            // 4 l15 + j of C - a lane's four tiles are four consecutive columns in every operand form: 16-byte stores)
+            float* dB = TB ? sB + (64 * h + 16 * ((tid >> 2) & 3) + (tid >> 4)) * GM_LDK + (tid & 3) * 4 : sB + (tid >> 4) * GM_LDF + (tid & 15) * 4 + 64 * h;
             f32x4 oa, ob;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? GM_W
     // Whatever the epilogue reads per output row (the point's coordinates; the mask values) is requested for FOUR rows at a time from
     // clamped addresses, ahead of the arithmetic that uses it: one wait per four rows instead of one per element.
     float* __restrict__ Cz = a.C + (size_t)bz * a.c_split_stride;
-    auto ncol = [&](int j) { return n0 + wn * 64 + (TB ? 16 * j + l15 : 4 * l15 + j); };
+    auto ncol = [&](int j) { return n0 + wn * 64 + 4 * l15 + j; };
     auto mrow = [&](int i, int r) { const int q = 4 * g + r; return m0 + wm * 64 + (TA ? 4 * q + i : 16 * i + q); };
     // HIDDEN: the per-column constants (bias, skip weights) of this lane's four columns once
     float bn[4] = {0.f, 0.f, 0.f, 0.f}, sn[4][3] = {};
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? GM_W
         }
     }
     // a lane's four columns are consecutive (operand B contiguous along n) and its row of C / of the mask may be accessed as 16 bytes
-    const bool vec_c = !TB && ncol(0) + 3 < a.N && (a.ldc & 3) == 0 && (((size_t)Cz) & 15) == 0;
+    const bool vec_c = ncol(0) + 3 < a.N && (a.ldc & 3) == 0 && (((size_t)Cz) & 15) == 0;
     const bool vec_mask = !TB && ISMASK && ncol(0) + 3 < a.N && (a.mask_ld & 3) == 0 && (((size_t)a.mask) & 15) == 0;
     float es[4][4] = {};   // NN + extsum: this lane's share of sum_m C[m][n] (1, x_m) for its four columns
 #pragma unroll
